@@ -1,0 +1,144 @@
+/*
+ * bt_oracle.h — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C restatement of the reference's terrain-tile preprocessing and
+ * tiling-prepass algorithms (kurtkuehnert/bevy_terrain @ 2025-03-14), used
+ * only as the checker in tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py.  Nothing in the product path
+ * (bevy_terrain_amd/, include/) may include, link or call this.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures
+ *  and cannot be built here (no Rust toolchain,
+ * un-vendored wgpu/naga).  The arithmetic of the path lives in the
+ * reference's own WGSL; this file restates it statement by statement and
+ * cites the file:line it follows.  Where the reference delegates to the GPU
+ * driver (hardware bilinear sampler, unorm conversions, 0/0) the definition
+ * chosen here is written next to the function.
+ */
+#ifndef BT_ORACLE_H
+#define BT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_INVALID 0xFFFFFFFFu /* terrain_data/mod.rs:34 INVALID_ATLAS_INDEX */
+
+/* AttachmentFormat::id — terrain_data/mod.rs:50-57 */
+#define ORC_FORMAT_RGBA8 0u
+#define ORC_FORMAT_R16 1u
+
+/* math/coordinate.rs:155-167 */
+typedef struct {
+    uint32_t side, lod, x, y;
+} orc_coord;
+
+/* terrain_data/tile_atlas.rs:30-35 (32 bytes with padding) */
+typedef struct {
+    orc_coord coordinate;
+    uint32_t atlas_index;
+    uint32_t _pad[3];
+} orc_atlas_tile;
+
+/* terrain_data/mod.rs:87-109 */
+typedef struct {
+    uint32_t texture_size;
+    uint32_t border_size;
+    uint32_t mip_level_count;
+    uint32_t format; /* ORC_FORMAT_* */
+} orc_attachment_config;
+
+/* preprocess/preprocessor.rs:35-55 */
+typedef struct {
+    uint32_t attachment_index;
+    uint32_t side;
+    float top_left[2];
+    float bottom_right[2];
+    uint32_t lod_begin, lod_end; /* lod_range = lod_begin..lod_end */
+} orc_dataset;
+
+typedef struct orc_atlas orc_atlas;
+
+/* ---- math/coordinate.rs ------------------------------------------------ */
+void orc_children(orc_coord c, orc_coord out[4]);
+void orc_neighbours(orc_coord c, int spherical, orc_coord out[8]);
+orc_coord orc_parent(orc_coord c);
+int orc_coord_is_invalid(orc_coord c);
+/* "{side}_{lod}_{x}_{y}" — coordinate.rs:282-286 */
+int orc_coord_name(orc_coord c, char* buf, size_t n);
+
+/* ---- terrain_data/tile_atlas.rs + preprocess ---------------------------- */
+orc_atlas* orc_atlas_new(uint32_t lod_count, uint32_t atlas_size, int spherical,
+                         uint32_t n_attachments, const orc_attachment_config* att);
+void orc_atlas_free(orc_atlas* a);
+void orc_clear_attachment(orc_atlas* a, uint32_t attachment_index);
+/* queue construction (preprocessor.rs:234-343); src rasters are W x H, tightly
+ * packed u16 (R16) or RGBA8, kept by pointer until orc_run(). */
+int orc_preprocess_tile(orc_atlas* a, const orc_dataset* d, const void* src, uint32_t w, uint32_t h);
+int orc_preprocess_spherical(orc_atlas* a, uint32_t attachment_index, uint32_t lod_begin,
+                             uint32_t lod_end, const void* const src[6], uint32_t w, uint32_t h);
+/* executes the queued tasks in order (barriers = sequential phases);
+ * threads<=1 -> scalar, else OpenMP over the tasks between two barriers. */
+int orc_run(orc_atlas* a, int threads);
+uint32_t orc_task_count(const orc_atlas* a, uint32_t counts[5]);
+
+uint32_t orc_tile_count(const orc_atlas* a); /* existing_tiles.len() */
+/* existing tiles in atlas-index order + their atlas indices */
+uint32_t orc_tiles(const orc_atlas* a, orc_coord* coords, uint32_t* atlas_indices, uint32_t cap);
+uint32_t orc_get_tile(const orc_atlas* a, orc_coord c); /* atlas index or INVALID */
+const void* orc_tile_data(const orc_atlas* a, uint32_t attachment_index, uint32_t atlas_index);
+size_t orc_tile_bytes(const orc_atlas* a, uint32_t attachment_index);
+
+/* tile_atlas.rs:77-116 + 605-612 : "{root}/data/{name}/{coord}.bin", "{root}/config.tc" */
+int orc_save_attachment(const orc_atlas* a, uint32_t attachment_index, const char* dir);
+int orc_save_tile_config(const orc_atlas* a, const char* path);
+/* formats/mod.rs:8-35 (bincode 2 standard config) */
+size_t orc_tc_encode(const orc_coord* tiles, uint32_t n, uint8_t* out, size_t cap);
+long orc_tc_decode(const uint8_t* in, size_t n, orc_coord* tiles, uint32_t cap);
+
+/* ---- per-task kernels exposed for unit tests --------------------------- */
+/* one pixel of split.wgsl:18-43; prev = previous atlas texel (unorm ints, 4 ch) */
+void orc_split_pixel(uint32_t format, uint32_t T, uint32_t b, orc_coord tile, const float tl[2],
+                     const float br[2], const void* src, uint32_t w, uint32_t h, uint32_t px,
+                     uint32_t py, const uint32_t prev[4], uint32_t out[4]);
+
+/* ---- terrain_data/mod.rs:143-219 -------------------------------------- */
+/* out holds all levels concatenated (level 0 copied first); returns texels written */
+size_t orc_generate_mipmaps(uint32_t format, uint32_t texture_size, uint32_t mip_level_count,
+                            const void* level0, void* out);
+
+/* ---- tiling prepass (shaders/tiling_prepass/*.wgsl, functions.wgsl) ----- */
+typedef struct {
+    int32_t view_xy[2];
+    float view_uv[2];
+} orc_side_parameter; /* terrain_model.rs:228-233 (only fields the prepass reads) */
+
+typedef struct {
+    uint32_t spherical;            /* SPHERICAL shader def, tiling_prepass.rs:61-78 */
+    uint32_t tile_count;           /* view_config.tile_count = geometry_tile_count */
+    uint32_t refinement_count;     /* tiling_prepass.rs:251 */
+    uint32_t vertices_per_tile;    /* terrain_view_bind_group.rs:106 */
+    float subdivision_distance;    /* terrain_view_bind_group.rs:111 */
+    uint32_t origin_lod;           /* terrain_model.rs:254 */
+    float approximate_height;      /* terrain_model.rs:255 */
+    orc_side_parameter sides[6];
+    float world_position[3];       /* culling_bind_group.rs:50 */
+    float world_from_local[12];    /* mesh[0].world_from_local: 3 columns + translation, column-major */
+    float local_from_world_transpose[9]; /* mesh[0].local_from_world_transpose_{a,b}, column-major 3x3 */
+} orc_view;
+
+/* runs prepare_root, refinement_count x (refine_tiles, prepare_next), refine_tiles,
+ * prepare_render sequentially in invocation-id order.  final_tiles gets the list in
+ * append order; returns count, or -1 if the buffers overflowed. indirect[4] = draw args. */
+long orc_refine(const orc_view* v, orc_coord* final_tiles, uint32_t cap, uint32_t indirect[4],
+                uint32_t* passes_tile_counts /* refinement_count+1 entries or NULL */);
+/* refine_tiles.wgsl:17-22 for one tile (exposed for tests) */
+int orc_should_be_divided(const orc_view* v, orc_coord tile, float* view_distance);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
