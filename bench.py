@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Headline benchmark: terrain tiles/s preprocessed on a synthetic 16384^2 heightmap (BASELINE.json).
+
+One step = one full pass of the hot path (split -> LOD pyramid -> border stitch -> atlas packing)
+over the resident 16k x 16k R16 heightmap into 1365 tiles of 512^2 (T=512, b=2, lod_count=6).
+Inputs are already in HBM when the timed region starts; value = tiles / s over all ranks.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1: launched by torch.distributed.run, one rank per GPU: the finest tile grid is split into
+column strips, every rank preprocesses its strip and one in-place RCCL all-gather per LOD
+assembles the full atlas on every rank (strong scaling: the 16k job is fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SIZE = 16384
+TEXTURE_SIZE, BORDER, LOD_COUNT, ATLAS_SIZE = 512, 2, 6, 2048
+SEED = 42
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def cpu_baseline(device, src_ptr):
+    """The CPU oracle (a port: the reference has no CPU path and cannot be built here) timed on a bounded
+    sample of the same workload: the top-left 4096^2 window of the same heightmap, lod_count 4, 85 tiles."""
+    import numpy as np
+
+    import _oracle as O
+
+    sample, lods = 4096, 4
+    window = np.empty((sample, sample), dtype=np.uint16)
+    rows = device.download(src_ptr, (sample, SIZE), np.uint16)  # first `sample` rows, all columns
+    window[:] = rows[:, :sample]
+    del rows
+    cores = os.cpu_count() or 1
+    a = O.OracleAtlas(lods, 128, False, [(TEXTURE_SIZE, BORDER, 1, O.FORMAT_R16)])
+    a.preprocess_tile(0, window, (0, lods))
+    t0 = time.perf_counter()
+    a.run(cores)
+    dt = time.perf_counter() - t0
+    tiles = len(a.tiles())
+    return {"value": tiles / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/bt_oracle.c (OpenMP) on the top-left {sample}x{sample} window of the same heightmap, "
+                      f"lod_count {lods}, {tiles} tiles of 512^2 in {dt:.2f} s"}, window, a
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--generic", action="store_true", help="force the reference-shaped batched kernels")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+
+    import bevy_terrain_amd as bt
+
+    device = bt.Device(local_rank)
+    src_ptr = device.synth_fbm_r16(SIZE, SIZE, SEED)
+
+    cfg = bt.TerrainConfig(lod_count=LOD_COUNT, atlas_size=ATLAS_SIZE, path="terrains/bench16k",
+                           model=bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=TEXTURE_SIZE, border_size=BORDER,
+                                           format=bt.AttachmentFormat.R16))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer().insert("synthetic/fbm16k", (src_ptr, SIZE, SIZE))
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas)
+    if world > 1:
+        from bevy_terrain_amd.shard import ShardedPreprocess
+
+        job = ShardedPreprocess(pre, atlas, server, "synthetic/fbm16k", range(0, LOD_COUNT), rank, world, generic=args.generic)
+    else:
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="synthetic/fbm16k", lod_range=range(0, LOD_COUNT)),
+                            server, atlas)
+        job = None
+
+    def step(profile=False):
+        if job is not None:
+            job.step()
+        else:
+            pre.run(atlas, generic=args.generic, keep_queue=True, sync=False, profile=profile)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    start.record()
+    for _ in range(args.steps):
+        step(profile=True)
+    stop.record()
+    fence()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    ms = start.elapsed_time(stop)
+    if world > 1:
+        t = torch.tensor([ms], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+    ms_per_step = ms / args.steps
+
+    stats = pre.stats() if job is None else job.stats()
+    tiles = stats["tiles"]
+    launches = pre.profile() if job is None else job.profile()
+    dominant = max(launches, key=lambda l: l["avg_ms"]) if launches else None
+
+    line = {
+        "metric": "terrain tiles/sec preprocessed (16k^2 heightmap)",
+        "value": tiles / (ms_per_step / 1e3),
+        "unit": "tiles/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak",
+        "vs_baseline": None,
+        "dtype": "f32 arithmetic on u16 texels",
+        "data": "synthetic",
+        "config": {"workload": f"synthetic {SIZE}x{SIZE} fBm R16 heightmap (seed {SEED}), T={TEXTURE_SIZE}, b={BORDER}, "
+                               f"lod_count={LOD_COUNT}: split + pyramid + stitch into {tiles} tiles",
+                   "path": "generic (batched split/downsample/stitch)" if stats["fused_jobs"] == 0 else "fused",
+                   "kernel_launches_per_step": stats["kernel_launches"],
+                   "algorithmic_bytes_per_step": stats["algorithmic_bytes"],
+                   "whole_step_GBps": stats["algorithmic_bytes"] / (ms_per_step / 1e3) / 1e9,
+                   "host_wall_ms_per_step": wall_ms / args.steps,
+                   "launches": launches},
+    }
+    if dominant:
+        achieved = dominant["algorithmic_bytes"] / (dominant["avg_ms"] / 1e3) / 1e9
+        line["roofline"] = {"bound": "hbm", "kernel": dominant["kind"], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                            "avg_launch_ms": dominant["avg_ms"], "algorithmic_bytes_per_launch": dominant["algorithmic_bytes"]}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"], window, oracle = cpu_baseline(device, src_ptr)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,172 @@
+"""ctypes binding of libbevy_terrain_amd.so (the C ABI in include/bevy_terrain_amd.h).
+
+The product path has no CPU fallback: if the HIP library is missing or fails to load this module
+raises, loudly.  PyTorch (when installed) is imported first so that the library binds to the same
+HIP runtime instance torch uses — device pointers and streams are then interchangeable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbevy_terrain_amd.so")
+
+INVALID_ATLAS_INDEX = 0xFFFFFFFF
+MAX_ATTACHMENTS = 8
+
+BT_OK = 0
+RUN_AUTO, RUN_GENERIC, RUN_KEEP_QUEUE, RUN_PROFILE = 0, 1, 2, 4
+
+
+class BtError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"bevy_terrain_amd: status {status}: {message}")
+        self.status = status
+
+
+class TileCoordinateC(C.Structure):
+    _fields_ = [("side", C.c_uint32), ("lod", C.c_uint32), ("x", C.c_uint32), ("y", C.c_uint32)]
+
+
+class AtlasTileC(C.Structure):
+    _fields_ = [("coordinate", TileCoordinateC), ("atlas_index", C.c_uint32), ("_padding", C.c_uint32 * 3)]
+
+
+class AttachmentConfigC(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("texture_size", C.c_uint32), ("border_size", C.c_uint32),
+                ("mip_level_count", C.c_uint32), ("format", C.c_uint32)]
+
+
+class TerrainConfigC(C.Structure):
+    _fields_ = [("lod_count", C.c_uint32), ("atlas_size", C.c_uint32), ("spherical", C.c_uint32),
+                ("attachment_count", C.c_uint32), ("attachments", AttachmentConfigC * MAX_ATTACHMENTS),
+                ("path", C.c_char * 256)]
+
+
+class RasterC(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("row_pitch", C.c_uint64),
+                ("format", C.c_uint32), ("on_device", C.c_uint32)]
+
+
+class PreprocessDatasetC(C.Structure):
+    _fields_ = [("attachment_index", C.c_uint32), ("side", C.c_uint32), ("top_left", C.c_float * 2),
+                ("bottom_right", C.c_float * 2), ("lod_begin", C.c_uint32), ("lod_end", C.c_uint32)]
+
+
+class SphericalDatasetC(C.Structure):
+    _fields_ = [("attachment_index", C.c_uint32), ("lod_begin", C.c_uint32), ("lod_end", C.c_uint32)]
+
+
+class RunStatsC(C.Structure):
+    _fields_ = [("kernel_launches", C.c_uint32), ("tiles", C.c_uint32), ("algorithmic_bytes", C.c_uint64),
+                ("fused_jobs", C.c_uint32), ("generic_jobs", C.c_uint32)]
+
+
+class LaunchProfileC(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("tasks", C.c_uint32), ("algorithmic_bytes", C.c_uint64), ("avg_ms", C.c_float),
+                ("samples", C.c_uint32)]
+
+
+class SideParameterC(C.Structure):
+    _fields_ = [("view_xy", C.c_int32 * 2), ("view_uv", C.c_float * 2)]
+
+
+class ViewStateC(C.Structure):
+    _fields_ = [("spherical", C.c_uint32), ("geometry_tile_count", C.c_uint32), ("refinement_count", C.c_uint32),
+                ("vertices_per_tile", C.c_uint32), ("subdivision_distance", C.c_float), ("origin_lod", C.c_uint32),
+                ("approximate_height", C.c_float), ("sides", SideParameterC * 6), ("world_position", C.c_float * 3),
+                ("world_from_local", C.c_float * 12), ("local_from_world_transpose", C.c_float * 9)]
+
+
+class IndirectC(C.Structure):
+    _fields_ = [("vertex_count", C.c_uint32), ("instance_count", C.c_uint32), ("base_vertex", C.c_uint32),
+                ("base_instance", C.c_uint32)]
+
+
+_vp, _u32, _u64, _i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+_P = C.POINTER
+
+# name -> (restype, argtypes); every function include/bevy_terrain_amd.h declares
+PROTOTYPES = {
+    "bt_abi_version": (_u32, []),
+    "bt_last_error": (C.c_char_p, []),
+    "bt_ctx_create": (_i32, [_i32, _vp, _P(_vp)]),
+    "bt_ctx_destroy": (None, [_vp]),
+    "bt_ctx_set_stream": (_i32, [_vp, _vp]),
+    "bt_ctx_stream": (_vp, [_vp]),
+    "bt_ctx_synchronize": (_i32, [_vp]),
+    "bt_ctx_timer_begin": (_i32, [_vp]),
+    "bt_ctx_timer_end": (_i32, [_vp, _P(C.c_float)]),
+    "bt_device_malloc": (_i32, [_vp, C.c_size_t, _P(_vp)]),
+    "bt_device_free": (_i32, [_vp, _vp]),
+    "bt_memcpy_h2d": (_i32, [_vp, _vp, _vp, C.c_size_t]),
+    "bt_memcpy_d2h": (_i32, [_vp, _vp, _vp, C.c_size_t]),
+    "bt_tile_children": (None, [TileCoordinateC, _P(TileCoordinateC)]),
+    "bt_tile_neighbours": (None, [TileCoordinateC, _u32, _P(TileCoordinateC)]),
+    "bt_tile_parent": (TileCoordinateC, [TileCoordinateC]),
+    "bt_tile_name": (_i32, [TileCoordinateC, C.c_char_p, C.c_size_t]),
+    "bt_atlas_create": (_i32, [_vp, _P(TerrainConfigC), _P(_vp)]),
+    "bt_atlas_destroy": (None, [_vp]),
+    "bt_atlas_get_tile": (_i32, [_vp, TileCoordinateC, _P(AtlasTileC)]),
+    "bt_atlas_get_or_allocate_tile": (_i32, [_vp, TileCoordinateC, _P(AtlasTileC)]),
+    "bt_atlas_tiles": (_u32, [_vp, _P(TileCoordinateC), _P(_u32), _u32]),
+    "bt_atlas_attachment_storage": (_i32, [_vp, _u32, _P(_vp), _P(_u64), _P(_u32)]),
+    "bt_atlas_download_tiles": (_i32, [_vp, _u32, _u32, _u32, _vp, _u64]),
+    "bt_atlas_upload_tile": (_i32, [_vp, _u32, _u32, _vp, _u64]),
+    "bt_atlas_save_attachment": (_i32, [_vp, _u32, C.c_char_p]),
+    "bt_atlas_save_tile_config": (_i32, [_vp, C.c_char_p]),
+    "bt_atlas_load_tile_config": (_i32, [_vp, C.c_char_p]),
+    "bt_tc_encode": (_u64, [_P(TileCoordinateC), _u32, _vp, _u64]),
+    "bt_tc_decode": (C.c_int64, [_vp, _u64, _P(TileCoordinateC), _u32]),
+    "bt_generate_mipmaps": (_i32, [_vp, _u32, _u32, _u32, _vp, _vp, _u64]),
+    "bt_atlas_generate_mipmaps": (_i32, [_vp, _u32, _u32, _u32]),
+    "bt_atlas_mip_storage": (_i32, [_vp, _u32, _u32, _P(_vp), _P(_u64)]),
+    "bt_preprocessor_create": (_i32, [_vp, _P(_vp)]),
+    "bt_preprocessor_destroy": (None, [_vp]),
+    "bt_preprocessor_clear_attachment": (_i32, [_vp, _vp, _u32, C.c_char_p]),
+    "bt_preprocessor_preprocess_tile": (_i32, [_vp, _vp, _P(PreprocessDatasetC), _P(RasterC)]),
+    "bt_preprocessor_preprocess_spherical": (_i32, [_vp, _vp, _P(SphericalDatasetC), _P(RasterC)]),
+    "bt_preprocessor_task_counts": (_u32, [_vp, _P(_u32)]),
+    "bt_preprocessor_run": (_i32, [_vp, _vp, _u32]),
+    "bt_preprocessor_save": (_i32, [_vp, _vp, C.c_char_p]),
+    "bt_preprocessor_last_run_stats": (_i32, [_vp, _P(RunStatsC)]),
+    "bt_preprocessor_profile": (_i32, [_vp, _P(LaunchProfileC), _u32, _P(_u32)]),
+    "bt_tiling_prepass_create": (_i32, [_vp, _u32, _P(_vp)]),
+    "bt_tiling_prepass_destroy": (None, [_vp]),
+    "bt_tiling_prepass_run": (_i32, [_vp, _P(ViewStateC)]),
+    "bt_tiling_prepass_buffers": (_i32, [_vp, _P(_vp), _P(_vp)]),
+    "bt_tiling_prepass_read": (_i32, [_vp, _P(TileCoordinateC), _u32, _P(_u32), _P(IndirectC)]),
+    "bt_synth_fbm_r16": (_i32, [_vp, _vp, _u32, _u32, _u64, _u32, _u32, _u32, _u32, _u32]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it is missing: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C bevy_terrain_amd/csrc`). bevy_terrain_amd has no CPU fallback.")
+    try:  # bind to torch's HIP runtime when torch is present (see module docstring)
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(L, name)  # AttributeError = ABI mismatch, also loud
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if L.bt_abi_version() != 1:
+        raise ImportError("libbevy_terrain_amd.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != BT_OK:
+        raise BtError(status, lib().bt_last_error().decode(errors="replace"))

@@ -1,0 +1,837 @@
+// Host half of libbevy_terrain_amd.so: context, TileCoordinate maths, the TileAtlas index allocator,
+// the Preprocessor task queue (the integer tile-index contract) and the tile / config file writers.
+// Mirrors the reference's CPU-side behaviour (file:line citations relative to the reference checkout);
+// the arithmetic on texels lives in bt_kernels.hip and bt_fused.hip.
+#include <dirent.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "bt_internal.hpp"
+
+namespace bt {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+}
+
+bt_status hip_fail(hipError_t e, const char* what) {
+    set_error("HIP error %d (%s) in %s", int(e), hipGetErrorString(e), what);
+    return BT_ERR_DEVICE;
+}
+
+// ------------------------------------------------------------------ TileCoordinate (coordinate.rs)
+
+// coordinate.rs:9-16: for each side: itself, then the side behind its -x, -y, +x, +y edge.
+static const uint32_t kNeighbouringSides[6][5] = {
+    {0, 4, 2, 1, 5}, {1, 0, 2, 3, 5}, {2, 0, 4, 3, 1}, {3, 2, 4, 5, 1}, {4, 2, 0, 5, 3}, {5, 4, 0, 1, 3},
+};
+
+// coordinate.rs:18-53: how a tile position on `side` maps onto `other` (per output axis).
+enum Axis : uint8_t { kZero, kLast, kS, kT };
+static const Axis kEven[6][2] = {{kS, kT}, {kZero, kT}, {kZero, kS}, {kT, kS}, {kT, kZero}, {kS, kZero}};
+static const Axis kOdd[6][2] = {{kS, kT}, {kS, kLast}, {kT, kLast}, {kT, kS}, {kLast, kS}, {kLast, kT}};
+
+void tile_children(bt_tile_coordinate c, bt_tile_coordinate out[4]) {
+    for (uint32_t i = 0; i < 4; i++) out[i] = {c.side, c.lod + 1, (c.x << 1) + (i & 1u), (c.y << 1) + (i >> 1)};
+}
+
+static bt_tile_coordinate neighbour_at(bt_tile_coordinate c, int nx, int ny, bool spherical) {
+    const bt_tile_coordinate invalid = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    const int n = int(1u << c.lod);
+    const bool out_x = nx < 0 || nx >= n, out_y = ny < 0 || ny >= n;
+    if (!spherical) {
+        if (out_x || out_y) return invalid;
+        return {c.side, c.lod, uint32_t(nx), uint32_t(ny)};
+    }
+    if (out_x && out_y) return invalid;  // cube corner: no diagonal neighbour (coordinate.rs:231-239)
+    const int edge = nx < 0 ? 1 : ny < 0 ? 2 : nx >= n ? 3 : ny >= n ? 4 : 0;
+    const uint32_t s = uint32_t(std::clamp(nx, 0, n - 1)), t = uint32_t(std::clamp(ny, 0, n - 1));
+    const uint32_t other = kNeighbouringSides[c.side][edge];
+    const Axis* info = (c.side % 2 == 0 ? kEven : kOdd)[(6 + other - c.side) % 6];
+    uint32_t xy[2];
+    for (int k = 0; k < 2; k++)
+        xy[k] = info[k] == kZero ? 0u : info[k] == kLast ? uint32_t(n - 1) : info[k] == kS ? s : t;
+    return {other, c.lod, xy[0], xy[1]};
+}
+
+void tile_neighbours(bt_tile_coordinate c, bool spherical, bt_tile_coordinate out[8]) {
+    // N, E, S, W, NW, NE, SE, SW (coordinate.rs:209-218) == the region order of stitch.wgsl:57-66
+    static const int kOffsets[8][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}, {-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
+    for (int i = 0; i < 8; i++) out[i] = neighbour_at(c, int(c.x) + kOffsets[i][0], int(c.y) + kOffsets[i][1], spherical);
+}
+
+// ------------------------------------------------------------------ bincode varints (formats/mod.rs)
+
+static uint64_t put_varint(uint64_t v, uint8_t* out, uint64_t pos, uint64_t cap) {
+    uint8_t tmp[9];
+    uint32_t n = 1;
+    if (v < 251) {
+        tmp[0] = uint8_t(v);
+    } else {
+        const uint32_t bytes = v < (1ull << 16) ? 2 : v < (1ull << 32) ? 4 : 8;
+        tmp[0] = bytes == 2 ? 251 : bytes == 4 ? 252 : 253;
+        for (uint32_t k = 0; k < bytes; k++) tmp[1 + k] = uint8_t(v >> (8 * k));
+        n = 1 + bytes;
+    }
+    if (out && pos + n <= cap) memcpy(out + pos, tmp, n);
+    return pos + n;
+}
+
+static bool get_varint(const uint8_t* in, uint64_t n, uint64_t& pos, uint64_t& v) {
+    if (pos >= n) return false;
+    const uint8_t tag = in[pos++];
+    if (tag < 251) {
+        v = tag;
+        return true;
+    }
+    const uint32_t bytes = tag == 251 ? 2 : tag == 252 ? 4 : tag == 253 ? 8 : 0;
+    if (!bytes || pos + bytes > n) return false;
+    v = 0;
+    for (uint32_t k = 0; k < bytes; k++) v |= uint64_t(in[pos + k]) << (8 * k);
+    pos += bytes;
+    return true;
+}
+
+static bt_status write_file(const std::string& path, const void* data, size_t bytes) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) {
+        set_error("cannot open %s: %s", path.c_str(), strerror(errno));
+        return BT_ERR_IO;
+    }
+    const size_t wr = fwrite(data, 1, bytes, f);
+    fclose(f);
+    if (wr != bytes) {
+        set_error("short write to %s", path.c_str());
+        return BT_ERR_IO;
+    }
+    return BT_OK;
+}
+
+static void remove_tree(const std::string& dir) {
+    DIR* d = opendir(dir.c_str());
+    if (!d) return;
+    while (dirent* e = readdir(d)) {
+        if (!strcmp(e->d_name, ".") || !strcmp(e->d_name, "..")) continue;
+        const std::string p = dir + "/" + e->d_name;
+        struct stat st;
+        if (lstat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode))
+            remove_tree(p);
+        else
+            unlink(p.c_str());
+    }
+    closedir(d);
+    rmdir(dir.c_str());
+}
+
+static bt_status make_dirs(const std::string& dir) {
+    std::string cur;
+    for (size_t i = 0; i <= dir.size(); i++) {
+        if (i == dir.size() || dir[i] == '/') {
+            if (!cur.empty() && mkdir(cur.c_str(), 0777) != 0 && errno != EEXIST) {
+                set_error("mkdir %s: %s", cur.c_str(), strerror(errno));
+                return BT_ERR_IO;
+            }
+        }
+        if (i < dir.size()) cur.push_back(dir[i]);
+    }
+    return BT_OK;
+}
+
+}  // namespace bt
+
+using namespace bt;
+
+// =====================================================================================  context
+
+extern "C" {
+
+uint32_t bt_abi_version(void) { return BT_ABI_VERSION; }
+const char* bt_last_error(void) { return g_error; }
+
+bt_status bt_ctx_create(int32_t device, void* stream, bt_ctx** out) {
+    if (!out) return BT_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    BT_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) {
+        set_error("device %d out of range (%d visible)", device, count);
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    BT_HIP(hipSetDevice(device));
+    bt_ctx* ctx = new bt_ctx();
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = hipStream_t(stream);
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return hip_fail(e, "hipStreamCreateWithFlags");
+        }
+        ctx->own_stream = true;
+    }
+    hipEventCreate(&ctx->ev_begin);
+    hipEventCreate(&ctx->ev_end);
+    *out = ctx;
+    return BT_OK;
+}
+
+void bt_ctx_destroy(bt_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->ev_begin) hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) hipEventDestroy(ctx->ev_end);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+bt_status bt_ctx_set_stream(bt_ctx* ctx, void* stream) {
+    if (!ctx) return BT_ERR_INVALID_ARGUMENT;
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    ctx->own_stream = false;
+    ctx->stream = hipStream_t(stream);
+    return BT_OK;
+}
+
+void* bt_ctx_stream(const bt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+bt_status bt_ctx_synchronize(bt_ctx* ctx) {
+    if (!ctx) return BT_ERR_INVALID_ARGUMENT;
+    BT_HIP(hipSetDevice(ctx->device));
+    BT_HIP(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+bt_status bt_ctx_timer_begin(bt_ctx* ctx) {
+    if (!ctx) return BT_ERR_INVALID_ARGUMENT;
+    BT_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
+    return BT_OK;
+}
+
+bt_status bt_ctx_timer_end(bt_ctx* ctx, float* elapsed_ms) {
+    if (!ctx || !elapsed_ms) return BT_ERR_INVALID_ARGUMENT;
+    BT_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
+    BT_HIP(hipEventSynchronize(ctx->ev_end));
+    BT_HIP(hipEventElapsedTime(elapsed_ms, ctx->ev_begin, ctx->ev_end));
+    return BT_OK;
+}
+
+bt_status bt_device_malloc(bt_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return BT_ERR_INVALID_ARGUMENT;
+    BT_HIP(hipSetDevice(ctx->device));
+    BT_HIP(hipMalloc(out, bytes ? bytes : 1));
+    return BT_OK;
+}
+
+bt_status bt_device_free(bt_ctx* ctx, void* ptr) {
+    if (!ctx) return BT_ERR_INVALID_ARGUMENT;
+    BT_HIP(hipSetDevice(ctx->device));
+    BT_HIP(hipFree(ptr));
+    return BT_OK;
+}
+
+bt_status bt_memcpy_h2d(bt_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return BT_ERR_INVALID_ARGUMENT;
+    BT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    BT_HIP(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+bt_status bt_memcpy_d2h(bt_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return BT_ERR_INVALID_ARGUMENT;
+    BT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BT_HIP(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+// ==============================================================================  TileCoordinate
+
+void bt_tile_children(bt_tile_coordinate c, bt_tile_coordinate out[4]) { tile_children(c, out); }
+void bt_tile_neighbours(bt_tile_coordinate c, uint32_t spherical, bt_tile_coordinate out[8]) {
+    tile_neighbours(c, spherical != 0, out);
+}
+bt_tile_coordinate bt_tile_parent(bt_tile_coordinate c) { return {c.side, c.lod - 1u, c.x >> 1, c.y >> 1}; }
+int32_t bt_tile_name(bt_tile_coordinate c, char* buf, size_t cap) {
+    return snprintf(buf, cap, "%u_%u_%u_%u", c.side, c.lod, c.x, c.y);
+}
+
+// ===================================================================================  TileAtlas
+
+bt_status bt_atlas_create(bt_ctx* ctx, const bt_terrain_config* config, bt_atlas** out) {
+    if (!ctx || !config || !out) return BT_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (config->attachment_count > BT_MAX_ATTACHMENTS) {
+        set_error("at most %u attachments", BT_MAX_ATTACHMENTS);
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    BT_HIP(hipSetDevice(ctx->device));
+    bt_atlas* a = new bt_atlas();
+    a->ctx = ctx;
+    a->config = *config;
+    for (uint32_t i = 0; i < config->atlas_size; i++) a->unused_tiles.push_back(i);
+    for (uint32_t i = 0; i < config->attachment_count; i++) {
+        const bt_attachment_config& c = config->attachments[i];
+        Attachment at;
+        at.cfg = c;
+        if (c.texture_size == 0 || 2 * c.border_size >= c.texture_size) {
+            set_error("attachment %u: texture_size %u / border_size %u", i, c.texture_size, c.border_size);
+            bt_atlas_destroy(a);
+            return BT_ERR_INVALID_ARGUMENT;
+        }
+        // pixel sizes: terrain_data/mod.rs:77-84
+        const uint32_t px = c.format == BT_FORMAT_R16 ? 2 : c.format == BT_FORMAT_RGB8 ? 3 : 4;
+        at.meta = {c.format, c.texture_size, c.border_size, c.texture_size - 2 * c.border_size, config->atlas_size, px};
+        at.tile_bytes = uint64_t(c.texture_size) * c.texture_size * px;
+        const size_t bytes = size_t(at.tile_bytes) * config->atlas_size;
+        hipError_t e = hipMalloc(&at.level0, bytes ? bytes : 1);
+        if (e == hipSuccess) e = hipMemsetAsync(at.level0, 0, bytes, ctx->stream);  // wgpu textures start zeroed
+        if (e != hipSuccess) {
+            bt_atlas_destroy(a);
+            return hip_fail(e, "atlas allocation");
+        }
+        at.mips.assign(c.mip_level_count ? c.mip_level_count : 1, nullptr);
+        a->attachments.push_back(at);
+    }
+    *out = a;
+    return BT_OK;
+}
+
+void bt_atlas_destroy(bt_atlas* a) {
+    if (!a) return;
+    hipSetDevice(a->ctx->device);
+    for (Attachment& at : a->attachments) {
+        if (at.level0) hipFree(at.level0);
+        for (void* m : at.mips)
+            if (m) hipFree(m);
+    }
+    delete a;
+}
+
+// tile_atlas.rs:369-381
+bt_status bt_atlas_get_tile(bt_atlas* a, bt_tile_coordinate c, bt_atlas_tile* out) {
+    if (!a || !out) return BT_ERR_INVALID_ARGUMENT;
+    *out = {c, BT_INVALID_ATLAS_INDEX, {0, 0, 0}};
+    if (is_invalid(c)) return BT_OK;
+    auto it = a->tile_states.find(c);
+    if (it != a->tile_states.end() && it->second.existing) out->atlas_index = it->second.atlas_index;
+    return BT_OK;
+}
+
+// tile_atlas.rs:383-416
+bt_status bt_atlas_get_or_allocate_tile(bt_atlas* a, bt_tile_coordinate c, bt_atlas_tile* out) {
+    if (!a || !out) return BT_ERR_INVALID_ARGUMENT;
+    *out = {c, BT_INVALID_ATLAS_INDEX, {0, 0, 0}};
+    if (is_invalid(c)) return BT_OK;
+    auto it = a->tile_states.find(c);
+    if (it == a->tile_states.end()) it = a->tile_states.emplace(c, TileState{BT_INVALID_ATLAS_INDEX, true}).first;
+    if (it->second.atlas_index == BT_INVALID_ATLAS_INDEX) {
+        if (a->unused_tiles.empty()) {
+            set_error("Atlas out of indices (atlas_size %u)", a->config.atlas_size);
+            return BT_ERR_ATLAS_OUT_OF_INDICES;
+        }
+        it->second.atlas_index = a->unused_tiles.front();
+        a->unused_tiles.pop_front();
+        a->allocated = std::max(a->allocated, it->second.atlas_index + 1);
+    }
+    it->second.existing = true;
+    out->atlas_index = it->second.atlas_index;
+    return BT_OK;
+}
+
+uint32_t bt_atlas_tiles(const bt_atlas* a, bt_tile_coordinate* coords, uint32_t* idx, uint32_t cap) {
+    if (!a) return 0;
+    std::vector<std::pair<uint32_t, bt_tile_coordinate>> v;
+    v.reserve(a->tile_states.size());
+    for (const auto& kv : a->tile_states)
+        if (kv.second.existing) v.push_back({kv.second.atlas_index, kv.first});
+    std::sort(v.begin(), v.end(), [](const auto& l, const auto& r) { return l.first < r.first; });
+    for (uint32_t i = 0; i < v.size() && i < cap; i++) {
+        if (coords) coords[i] = v[i].second;
+        if (idx) idx[i] = v[i].first;
+    }
+    return uint32_t(v.size());
+}
+
+bt_status bt_atlas_attachment_storage(const bt_atlas* a, uint32_t ai, void** ptr, uint64_t* tile_bytes, uint32_t* layers) {
+    if (!a || ai >= a->attachments.size()) return BT_ERR_INVALID_ARGUMENT;
+    if (ptr) *ptr = a->attachments[ai].level0;
+    if (tile_bytes) *tile_bytes = a->attachments[ai].tile_bytes;
+    if (layers) *layers = a->config.atlas_size;
+    return BT_OK;
+}
+
+bt_status bt_atlas_download_tiles(bt_atlas* a, uint32_t ai, uint32_t first, uint32_t count, void* dst, uint64_t dst_bytes) {
+    if (!a || ai >= a->attachments.size() || !dst) return BT_ERR_INVALID_ARGUMENT;
+    const Attachment& at = a->attachments[ai];
+    if (uint64_t(first) + count > a->config.atlas_size || dst_bytes < at.tile_bytes * count) {
+        set_error("download range/size");
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    BT_HIP(hipMemcpyAsync(dst, (const uint8_t*)at.level0 + at.tile_bytes * first, at.tile_bytes * count,
+                          hipMemcpyDeviceToHost, a->ctx->stream));
+    BT_HIP(hipStreamSynchronize(a->ctx->stream));
+    return BT_OK;
+}
+
+bt_status bt_atlas_upload_tile(bt_atlas* a, uint32_t ai, uint32_t layer, const void* src, uint64_t src_bytes) {
+    if (!a || ai >= a->attachments.size() || !src) return BT_ERR_INVALID_ARGUMENT;
+    const Attachment& at = a->attachments[ai];
+    if (layer >= a->config.atlas_size || src_bytes != at.tile_bytes) return BT_ERR_INVALID_ARGUMENT;
+    BT_HIP(hipMemcpyAsync((uint8_t*)at.level0 + at.tile_bytes * layer, src, src_bytes, hipMemcpyHostToDevice, a->ctx->stream));
+    BT_HIP(hipStreamSynchronize(a->ctx->stream));
+    return BT_OK;
+}
+
+bt_status bt_atlas_save_attachment(bt_atlas* a, uint32_t ai, const char* directory) {
+    if (!a || ai >= a->attachments.size() || !directory) return BT_ERR_INVALID_ARGUMENT;
+    const Attachment& at = a->attachments[ai];
+    const uint32_t n = bt_atlas_tiles(a, nullptr, nullptr, 0);
+    std::vector<bt_tile_coordinate> coords(n);
+    std::vector<uint32_t> idx(n);
+    bt_atlas_tiles(a, coords.data(), idx.data(), n);
+    if (bt_status s = make_dirs(directory)) return s;
+    // stream the tiles out in chunks through one pinned buffer: D2H at PCIe rate, then fs::write
+    const uint32_t chunk = 64;
+    void* pinned = nullptr;
+    BT_HIP(hipHostMalloc(&pinned, at.tile_bytes * chunk, hipHostMallocDefault));
+    bt_status rc = BT_OK;
+    uint32_t i = 0;
+    while (i < n && rc == BT_OK) {
+        // consecutive atlas indices download as one copy
+        uint32_t run = 1;
+        while (i + run < n && run < chunk && idx[i + run] == idx[i] + run) run++;
+        hipError_t e = hipMemcpyAsync(pinned, (const uint8_t*)at.level0 + at.tile_bytes * idx[i], at.tile_bytes * run,
+                                      hipMemcpyDeviceToHost, a->ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(a->ctx->stream);
+        if (e != hipSuccess) {
+            rc = hip_fail(e, "tile download");
+            break;
+        }
+        for (uint32_t k = 0; k < run && rc == BT_OK; k++) {
+            char name[64];
+            bt_tile_name(coords[i + k], name, sizeof name);
+            rc = write_file(std::string(directory) + "/" + name + ".bin", (const uint8_t*)pinned + at.tile_bytes * k, at.tile_bytes);
+        }
+        i += run;
+    }
+    hipHostFree(pinned);
+    return rc;
+}
+
+uint64_t bt_tc_encode(const bt_tile_coordinate* tiles, uint32_t count, uint8_t* out, uint64_t cap) {
+    uint64_t pos = put_varint(count, out, 0, cap);
+    for (uint32_t i = 0; i < count; i++) {
+        pos = put_varint(tiles[i].side, out, pos, cap);
+        pos = put_varint(tiles[i].lod, out, pos, cap);
+        pos = put_varint(tiles[i].x, out, pos, cap);
+        pos = put_varint(tiles[i].y, out, pos, cap);
+    }
+    return pos;
+}
+
+int64_t bt_tc_decode(const uint8_t* data, uint64_t bytes, bt_tile_coordinate* tiles, uint32_t cap) {
+    uint64_t pos = 0, len = 0;
+    if (!data || !get_varint(data, bytes, pos, len)) return -1;
+    for (uint64_t i = 0; i < len; i++) {
+        uint64_t v[4];
+        for (int k = 0; k < 4; k++)
+            if (!get_varint(data, bytes, pos, v[k]) || v[k] > 0xFFFFFFFFull) return -1;
+        if (tiles && i < cap) tiles[i] = {uint32_t(v[0]), uint32_t(v[1]), uint32_t(v[2]), uint32_t(v[3])};
+    }
+    return int64_t(len);
+}
+
+bt_status bt_atlas_save_tile_config(const bt_atlas* a, const char* file_path) {
+    if (!a || !file_path) return BT_ERR_INVALID_ARGUMENT;
+    const uint32_t n = bt_atlas_tiles(a, nullptr, nullptr, 0);
+    std::vector<bt_tile_coordinate> coords(n);
+    bt_atlas_tiles(a, coords.data(), nullptr, n);
+    // the reference writes HashSet iteration order (tile_atlas.rs:605-609); sorted here, compare as a set
+    std::sort(coords.begin(), coords.end(), [](const bt_tile_coordinate& l, const bt_tile_coordinate& r) {
+        if (l.side != r.side) return l.side < r.side;
+        if (l.lod != r.lod) return l.lod < r.lod;
+        if (l.x != r.x) return l.x < r.x;
+        return l.y < r.y;
+    });
+    std::vector<uint8_t> buf(bt_tc_encode(coords.data(), n, nullptr, 0));
+    bt_tc_encode(coords.data(), n, buf.data(), buf.size());
+    return write_file(file_path, buf.data(), buf.size());
+}
+
+bt_status bt_atlas_load_tile_config(bt_atlas* a, const char* file_path) {
+    if (!a || !file_path) return BT_ERR_INVALID_ARGUMENT;
+    FILE* f = fopen(file_path, "rb");
+    if (!f) {
+        set_error("Tile config not found: %s", file_path);  // tile_atlas.rs:620
+        return BT_ERR_IO;
+    }
+    std::vector<uint8_t> buf;
+    uint8_t tmp[65536];
+    size_t r;
+    while ((r = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + r);
+    fclose(f);
+    const int64_t n = bt_tc_decode(buf.data(), buf.size(), nullptr, 0);
+    if (n < 0) {
+        set_error("malformed tile config %s", file_path);
+        return BT_ERR_IO;
+    }
+    std::vector<bt_tile_coordinate> coords(size_t(n) ? size_t(n) : 1);
+    bt_tc_decode(buf.data(), buf.size(), coords.data(), uint32_t(n));
+    for (int64_t i = 0; i < n; i++) {
+        // existing_tiles only: a tile gets an atlas index when it is requested or preprocessed
+        auto it = a->tile_states.find(coords[i]);
+        if (it != a->tile_states.end()) it->second.existing = true;
+        else a->tile_states.emplace(coords[i], TileState{BT_INVALID_ATLAS_INDEX, true});
+    }
+    return BT_OK;
+}
+
+// ------------------------------------------------------------------------------------- mip chain
+
+static uint32_t mip_pixel_size(uint32_t format) { return format == BT_FORMAT_R16 ? 2 : 4; }
+
+bt_status bt_generate_mipmaps(bt_ctx* ctx, uint32_t format, uint32_t T, uint32_t levels, const void* level0, void* out,
+                              uint64_t out_bytes) {
+    if (!ctx || !level0 || !out || levels == 0) return BT_ERR_INVALID_ARGUMENT;
+    if (format != BT_FORMAT_R16 && format != BT_FORMAT_RGBA8) {
+        set_error("generate_mipmaps: format %u is a no-op in the reference (terrain_data/mod.rs:211-213)", format);
+        return BT_ERR_UNSUPPORTED;
+    }
+    const uint32_t px = mip_pixel_size(format);
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < levels; k++) total += uint64_t(T >> k) * (T >> k) * px;
+    if (out_bytes < total) return BT_ERR_INVALID_ARGUMENT;
+    BT_HIP(hipSetDevice(ctx->device));
+    uint8_t* dev = nullptr;
+    BT_HIP(hipMalloc((void**)&dev, total));
+    bt_status rc = BT_OK;
+    hipError_t e = hipMemcpyAsync(dev, level0, uint64_t(T) * T * px, hipMemcpyHostToDevice, ctx->stream);
+    uint64_t off = 0;
+    uint32_t size = T;
+    for (uint32_t k = 1; k < levels && e == hipSuccess && rc == BT_OK; k++) {
+        const uint64_t next = off + uint64_t(size) * size * px;
+        rc = launch_mip_level(ctx, format, dev + off, dev + next, size, 1);
+        off = next;
+        size >>= 1;
+    }
+    if (e == hipSuccess && rc == BT_OK) e = hipMemcpyAsync(out, dev, total, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == BT_OK) e = hipStreamSynchronize(ctx->stream);
+    hipFree(dev);
+    if (e != hipSuccess) return hip_fail(e, "bt_generate_mipmaps");
+    return rc;
+}
+
+bt_status bt_atlas_generate_mipmaps(bt_atlas* a, uint32_t ai, uint32_t first, uint32_t count) {
+    if (!a || ai >= a->attachments.size()) return BT_ERR_INVALID_ARGUMENT;
+    Attachment& at = a->attachments[ai];
+    if (at.meta.format != BT_FORMAT_R16 && at.meta.format != BT_FORMAT_RGBA8) return BT_ERR_UNSUPPORTED;
+    if (uint64_t(first) + count > a->config.atlas_size) return BT_ERR_INVALID_ARGUMENT;
+    BT_HIP(hipSetDevice(a->ctx->device));
+    const uint32_t px = at.meta.pixel_size;
+    uint32_t size = at.meta.texture_size;
+    const uint8_t* parent = (const uint8_t*)at.level0 + at.tile_bytes * first;
+    for (uint32_t k = 1; k < at.mips.size(); k++) {
+        const uint32_t child = size >> 1;
+        const uint64_t child_tile = uint64_t(child) * child * px;
+        if (!at.mips[k]) {
+            BT_HIP(hipMalloc(&at.mips[k], child_tile * a->config.atlas_size ? child_tile * a->config.atlas_size : 1));
+            BT_HIP(hipMemsetAsync(at.mips[k], 0, child_tile * a->config.atlas_size, a->ctx->stream));
+        }
+        uint8_t* dst = (uint8_t*)at.mips[k] + child_tile * first;
+        if (bt_status s = launch_mip_level(a->ctx, at.meta.format, parent, dst, size, count)) return s;
+        parent = dst;
+        size = child;
+    }
+    return BT_OK;
+}
+
+bt_status bt_atlas_mip_storage(const bt_atlas* a, uint32_t ai, uint32_t level, void** ptr, uint64_t* tile_bytes) {
+    if (!a || ai >= a->attachments.size() || level >= a->attachments[ai].mips.size()) return BT_ERR_INVALID_ARGUMENT;
+    const Attachment& at = a->attachments[ai];
+    const uint32_t s = at.meta.texture_size >> level;
+    if (ptr) *ptr = level == 0 ? at.level0 : at.mips[level];
+    if (tile_bytes) *tile_bytes = uint64_t(s) * s * at.meta.pixel_size;
+    return BT_OK;
+}
+
+bt_status bt_synth_fbm_r16(bt_ctx* ctx, void* dst, uint32_t w, uint32_t h, uint64_t pitch, uint32_t x0, uint32_t y0,
+                           uint32_t base_cell, uint32_t octaves, uint32_t seed) {
+    if (!ctx || !dst || !w || !h || !base_cell || !octaves || octaves > 16) return BT_ERR_INVALID_ARGUMENT;
+    BT_HIP(hipSetDevice(ctx->device));
+    return launch_synth_fbm(ctx, dst, w, h, pitch ? pitch : uint64_t(w) * 2, x0, y0, base_cell, octaves, seed);
+}
+
+// ================================================================================  Preprocessor
+
+bt_status bt_preprocessor_create(bt_ctx* ctx, bt_preprocessor** out) {
+    if (!ctx || !out) return BT_ERR_INVALID_ARGUMENT;
+    *out = new bt_preprocessor();
+    (*out)->ctx = ctx;
+    return BT_OK;
+}
+
+static void release_rasters(bt_preprocessor* p) {
+    for (Raster& r : p->rasters)
+        if (r.owned && r.dev.data) hipFree((void*)r.dev.data);
+    p->rasters.clear();
+}
+
+void bt_preprocessor_destroy(bt_preprocessor* p) {
+    if (!p) return;
+    hipSetDevice(p->ctx->device);
+    release_rasters(p);
+    for (hipEvent_t e : p->events) hipEventDestroy(e);
+    if (p->tasks_dev) hipFree(p->tasks_dev);
+    if (p->rasters_dev) hipFree(p->rasters_dev);
+    delete p;
+}
+
+bt_status bt_preprocessor_clear_attachment(bt_preprocessor* p, bt_atlas* a, uint32_t ai, const char* directory) {
+    if (!p || !a || ai >= a->attachments.size()) return BT_ERR_INVALID_ARGUMENT;
+    for (auto& kv : a->tile_states) kv.second.existing = false;  // existing_tiles.clear() — for ALL attachments, like :292
+    if (directory) {
+        // reset_directory (preprocessor.rs:18-22)
+        unlink((std::string(directory) + "/../../config.tc").c_str());
+        remove_tree(directory);
+        return make_dirs(directory);
+    }
+    return BT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct TileRange {
+    uint32_t lx, ly, ux, uy;
+};
+
+// PreprocessDataset::overlapping_tiles (preprocessor.rs:58-66): f32 maths, as_uvec2 truncation
+TileRange overlapping_tiles(const bt_preprocess_dataset& d, uint32_t lod) {
+    const float n = float(1u << lod);
+    return {uint32_t(d.top_left[0] * n), uint32_t(d.top_left[1] * n), uint32_t(std::ceil(d.bottom_right[0] * n)),
+            uint32_t(std::ceil(d.bottom_right[1] * n))};
+}
+
+bt_status add_raster(bt_preprocessor* p, const bt_atlas* a, uint32_t ai, const bt_raster* src, int32_t* index) {
+    if (!src || !src->data || !src->width || !src->height) {
+        set_error("source raster missing");
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    const uint32_t fmt = a->attachments[ai].meta.format;
+    if (fmt != BT_FORMAT_R16 && fmt != BT_FORMAT_RGBA8) {
+        set_error("attachment format %u is not processed (reference: preprocessing.wgsl:73-90 has no branch for it)", fmt);
+        return BT_ERR_UNSUPPORTED;
+    }
+    if (src->format != fmt) {
+        set_error("raster format %u != attachment format %u", src->format, fmt);
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    const uint32_t px = fmt == BT_FORMAT_R16 ? 2 : 4;
+    const uint64_t pitch = src->row_pitch ? src->row_pitch : uint64_t(src->width) * px;
+    Raster r;
+    r.format = fmt;
+    r.owned = false;
+    r.dev = {src->data, src->width, src->height, pitch};
+    if (!src->on_device) {
+        void* dev = nullptr;
+        BT_HIP(hipSetDevice(p->ctx->device));
+        BT_HIP(hipMalloc(&dev, pitch * src->height));
+        hipError_t e = hipMemcpyAsync(dev, src->data, pitch * src->height, hipMemcpyHostToDevice, p->ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
+        if (e != hipSuccess) {
+            hipFree(dev);
+            return hip_fail(e, "raster upload");
+        }
+        r.dev.data = dev;
+        r.owned = true;
+    }
+    *index = int32_t(p->rasters.size());
+    p->rasters.push_back(r);
+    return BT_OK;
+}
+
+Task make_task(TaskType type, const bt_atlas_tile& tile, const bt_preprocess_dataset& d, uint32_t job) {
+    Task t{};
+    t.type = type;
+    t.coord = tile.coordinate;
+    t.atlas_index = tile.atlas_index;
+    t.attachment_index = d.attachment_index;
+    t.tl[0] = d.top_left[0];
+    t.tl[1] = d.top_left[1];
+    t.br[0] = d.bottom_right[0];
+    t.br[1] = d.bottom_right[1];
+    t.raster = -1;
+    t.job = job;
+    return t;
+}
+
+void push_barrier(bt_preprocessor* p, uint32_t job) {
+    Task t{};
+    t.type = kBarrier;
+    t.raster = -1;
+    t.job = job;
+    p->queue.push_back(t);
+}
+
+// Preprocessor::split_and_downsample (preprocessor.rs:234-269)
+bt_status split_and_downsample(bt_preprocessor* p, bt_atlas* a, const bt_preprocess_dataset& d, int32_t raster, uint32_t job) {
+    uint32_t lod = d.lod_end - 1;
+    TileRange r = overlapping_tiles(d, lod);
+    for (uint32_t x = r.lx; x < r.ux; x++)
+        for (uint32_t y = r.ly; y < r.uy; y++) {
+            bt_atlas_tile tile;
+            if (bt_status s = bt_atlas_get_or_allocate_tile(a, {d.side, lod, x, y}, &tile)) return s;
+            Task t = make_task(kSplit, tile, d, job);
+            t.raster = raster;
+            p->queue.push_back(t);
+        }
+    while (lod > d.lod_begin) {
+        lod--;
+        push_barrier(p, job);
+        r = overlapping_tiles(d, lod);
+        for (uint32_t x = r.lx; x < r.ux; x++)
+            for (uint32_t y = r.ly; y < r.uy; y++) {
+                bt_atlas_tile tile;
+                if (bt_status s = bt_atlas_get_or_allocate_tile(a, {d.side, lod, x, y}, &tile)) return s;
+                Task t = make_task(kDownsample, tile, d, job);
+                bt_tile_coordinate ch[4];
+                tile_children(tile.coordinate, ch);
+                for (int i = 0; i < 4; i++) bt_atlas_get_tile(a, ch[i], &t.rel[i]);
+                p->queue.push_back(t);
+            }
+    }
+    return BT_OK;
+}
+
+// Preprocessor::stitch_and_save_layer (preprocessor.rs:271-288)
+bt_status stitch_and_save_layer(bt_preprocessor* p, bt_atlas* a, const bt_preprocess_dataset& d, uint32_t lod, uint32_t job) {
+    const TileRange r = overlapping_tiles(d, lod);
+    for (int pass = 0; pass < 2; pass++) {
+        for (uint32_t x = r.lx; x < r.ux; x++)
+            for (uint32_t y = r.ly; y < r.uy; y++) {
+                bt_atlas_tile tile;
+                if (bt_status s = bt_atlas_get_or_allocate_tile(a, {d.side, lod, x, y}, &tile)) return s;
+                Task t = make_task(pass == 0 ? kStitch : kSave, tile, d, job);
+                if (pass == 0) {
+                    bt_tile_coordinate nb[8];
+                    tile_neighbours(tile.coordinate, a->config.spherical != 0, nb);
+                    for (int i = 0; i < 8; i++) bt_atlas_get_tile(a, nb[i], &t.rel[i]);
+                }
+                p->queue.push_back(t);
+            }
+        if (pass == 0) push_barrier(p, job);
+    }
+    return BT_OK;
+}
+
+bt_status check_dataset(const bt_atlas* a, uint32_t ai, uint32_t lod_begin, uint32_t lod_end) {
+    if (ai >= a->attachments.size()) {
+        set_error("attachment_index %u out of range", ai);
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    if (lod_end <= lod_begin || lod_end > 31) {
+        set_error("lod_range %u..%u", lod_begin, lod_end);
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    const AttachmentMeta& m = a->attachments[ai].meta;
+    if (lod_end - lod_begin > 1 && (m.center_size & 1u)) {
+        // downsample.wgsl:18-20 indexes child_tiles[0..4) with center_size/2; odd sizes run out of bounds upstream
+        set_error("center_size %u must be even to downsample", m.center_size);
+        return BT_ERR_UNSUPPORTED;
+    }
+    if ((uint64_t(m.texture_size) * m.pixel_size) % 4u) {
+        set_error("texture row must be a whole number of 32-bit entries");
+        return BT_ERR_UNSUPPORTED;
+    }
+    return BT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Preprocessor::preprocess_tile (preprocessor.rs:298-312)
+bt_status bt_preprocessor_preprocess_tile(bt_preprocessor* p, bt_atlas* a, const bt_preprocess_dataset* d, const bt_raster* src) {
+    if (!p || !a || !d) return BT_ERR_INVALID_ARGUMENT;
+    if (bt_status s = check_dataset(a, d->attachment_index, d->lod_begin, d->lod_end)) return s;
+    if (!(d->bottom_right[0] > d->top_left[0]) || !(d->bottom_right[1] > d->top_left[1])) {
+        set_error("empty dataset rectangle");
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    int32_t raster;
+    if (bt_status s = add_raster(p, a, d->attachment_index, src, &raster)) return s;
+    const uint32_t job = p->jobs++;
+    p->compiled = false;
+    if (bt_status s = split_and_downsample(p, a, *d, raster, job)) return s;
+    push_barrier(p, job);
+    for (uint32_t lod = d->lod_begin; lod < d->lod_end; lod++)
+        if (bt_status s = stitch_and_save_layer(p, a, *d, lod, job)) return s;
+    return BT_OK;
+}
+
+// Preprocessor::preprocess_spherical (preprocessor.rs:314-343)
+bt_status bt_preprocessor_preprocess_spherical(bt_preprocessor* p, bt_atlas* a, const bt_spherical_dataset* sd, const bt_raster sources[6]) {
+    if (!p || !a || !sd || !sources) return BT_ERR_INVALID_ARGUMENT;
+    if (bt_status s = check_dataset(a, sd->attachment_index, sd->lod_begin, sd->lod_end)) return s;
+    const uint32_t job = p->jobs++;
+    p->compiled = false;
+    bt_preprocess_dataset side[6];
+    int32_t raster[6];
+    for (uint32_t s = 0; s < 6; s++) {
+        side[s] = {sd->attachment_index, s, {0.0f, 0.0f}, {1.0f, 1.0f}, sd->lod_begin, sd->lod_end};
+        if (bt_status rc = add_raster(p, a, sd->attachment_index, &sources[s], &raster[s])) return rc;
+    }
+    for (uint32_t s = 0; s < 6; s++)
+        if (bt_status rc = split_and_downsample(p, a, side[s], raster[s], job)) return rc;
+    push_barrier(p, job);
+    for (uint32_t lod = sd->lod_begin; lod < sd->lod_end; lod++)
+        for (uint32_t s = 0; s < 6; s++)
+            if (bt_status rc = stitch_and_save_layer(p, a, side[s], lod, job)) return rc;
+    return BT_OK;
+}
+
+uint32_t bt_preprocessor_task_counts(const bt_preprocessor* p, uint32_t counts[5]) {
+    if (!p) return 0;
+    if (counts) {
+        memset(counts, 0, 5 * sizeof(uint32_t));
+        for (const Task& t : p->queue) counts[t.type]++;
+    }
+    return uint32_t(p->queue.size());
+}
+
+bt_status bt_preprocessor_save(bt_preprocessor* p, bt_atlas* a, const char* assets_root) {
+    if (!p || !a || !assets_root) return BT_ERR_INVALID_ARGUMENT;
+    // which attachments have pending Save tasks
+    const bool* wanted = p->save_pending;
+    const std::string terrain = std::string(assets_root) + "/" + a->config.path;
+    for (uint32_t ai = 0; ai < a->attachments.size(); ai++) {
+        if (!wanted[ai]) continue;
+        // AtlasAttachment::new: path = "assets/{path}/data/{name}" (tile_atlas.rs:175)
+        const std::string dir = terrain + "/data/" + a->attachments[ai].cfg.name;
+        if (bt_status s = bt_atlas_save_attachment(a, ai, dir.c_str())) return s;
+    }
+    memset(p->save_pending, 0, sizeof p->save_pending);
+    if (bt_status s = make_dirs(terrain)) return s;
+    return bt_atlas_save_tile_config(a, (terrain + "/config.tc").c_str());
+}
+
+bt_status bt_preprocessor_last_run_stats(const bt_preprocessor* p, bt_run_stats* out) {
+    if (!p || !out) return BT_ERR_INVALID_ARGUMENT;
+    *out = p->stats;
+    return BT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,172 @@
+// Internal declarations shared by the host (.cpp) and device (.hip) halves of libbevy_terrain_amd.so.
+// Nothing here is part of the ABI; the ABI is include/bevy_terrain_amd.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <deque>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "bevy_terrain_amd.h"
+
+namespace bt {
+
+void set_error(const char* fmt, ...);
+bt_status hip_fail(hipError_t e, const char* what);
+
+#define BT_HIP(expr)                                          \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return bt::hip_fail(_e, #expr); \
+    } while (0)
+
+inline bool operator_eq(const bt_tile_coordinate& a, const bt_tile_coordinate& b) {
+    return a.side == b.side && a.lod == b.lod && a.x == b.x && a.y == b.y;
+}
+inline bool is_invalid(const bt_tile_coordinate& c) {
+    return c.side == 0xFFFFFFFFu && c.lod == 0xFFFFFFFFu && c.x == 0xFFFFFFFFu && c.y == 0xFFFFFFFFu;
+}
+
+struct CoordHash {
+    size_t operator()(const bt_tile_coordinate& c) const {
+        uint64_t h = (uint64_t(c.side) << 59) ^ (uint64_t(c.lod) << 53) ^ (uint64_t(c.x) << 26) ^ uint64_t(c.y);
+        h ^= h >> 31;
+        h *= 0x9E3779B97F4A7C15ull;
+        return size_t(h ^ (h >> 29));
+    }
+};
+struct CoordEq {
+    bool operator()(const bt_tile_coordinate& a, const bt_tile_coordinate& b) const { return operator_eq(a, b); }
+};
+
+// ---- device-visible descriptors -------------------------------------------------------------
+
+// AttachmentMeta of the reference (gpu_tile_atlas.rs:45-56) reduced to what the kernels read.
+struct AttachmentMeta {
+    uint32_t format;        // BT_FORMAT_R16 / BT_FORMAT_RGBA8
+    uint32_t texture_size;  // T
+    uint32_t border_size;   // b
+    uint32_t center_size;   // c = T - 2b
+    uint32_t atlas_size;    // layers
+    uint32_t pixel_size;    // bytes
+};
+
+struct RasterDev {
+    const void* data;
+    uint32_t width, height;
+    uint64_t pitch;  // bytes per row
+};
+
+// One queued Split / Downsample / Stitch task in the form the batched kernels read.
+struct TaskDev {
+    uint32_t atlas_index;
+    uint32_t side, lod, x, y;
+    float tlx, tly, brx, bry;
+    uint32_t raster;
+    uint32_t rel_index[8];  // children (4) or neighbours (8): atlas indices, INVALID if absent
+    uint32_t rel_side[8];   // neighbour sides (stitch across cube faces)
+};
+
+// ---- host state -------------------------------------------------------------------------------
+
+struct Attachment {
+    bt_attachment_config cfg;
+    AttachmentMeta meta;
+    uint64_t tile_bytes = 0;
+    void* level0 = nullptr;           // atlas_size x T x T texels
+    std::vector<void*> mips;          // level k (k>=1): atlas_size x (T>>k)^2 texels; lazily allocated
+};
+
+struct TileState {
+    uint32_t atlas_index;
+    bool existing;
+};
+
+enum TaskType : uint32_t { kSplit = 0, kStitch = 1, kDownsample = 2, kSave = 3, kBarrier = 4 };
+
+struct Task {
+    TaskType type;
+    bt_tile_coordinate coord;
+    uint32_t atlas_index;
+    uint32_t attachment_index;
+    bt_atlas_tile rel[8];
+    float tl[2], br[2];
+    int32_t raster;  // index into bt_preprocessor::rasters
+    uint32_t job;    // which preprocess_tile / preprocess_spherical call queued it
+};
+
+struct Raster {
+    RasterDev dev;
+    uint32_t format;
+    bool owned;
+};
+
+}  // namespace bt
+
+struct bt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+};
+
+struct bt_atlas {
+    bt_ctx* ctx = nullptr;
+    bt_terrain_config config{};
+    std::vector<bt::Attachment> attachments;
+    std::unordered_map<bt_tile_coordinate, bt::TileState, bt::CoordHash, bt::CoordEq> tile_states;
+    std::deque<uint32_t> unused_tiles;  // FIFO of atlas indices (tile_atlas.rs:307-309)
+    uint32_t allocated = 0;             // high-water mark of handed-out indices
+};
+
+namespace bt {
+
+// One launch of the compiled plan.
+enum LaunchKind : uint32_t { kLaunchSplit, kLaunchDownsample, kLaunchStitch, kLaunchFusedMain, kLaunchFusedTail };
+struct Launch {
+    LaunchKind kind;
+    uint32_t attachment;
+    uint32_t first_task, task_count;  // into the device task array
+    uint32_t aux0 = 0, aux1 = 0;
+    uint64_t algorithmic_bytes = 0;  // inputs read once + outputs written once
+};
+
+// host-side launchers implemented in bt_kernels.hip
+bt_status launch_split(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const TaskDev* tasks, uint32_t n,
+                       const RasterDev* rasters);
+bt_status launch_downsample(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const TaskDev* tasks, uint32_t n);
+bt_status launch_stitch(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const TaskDev* tasks, uint32_t n);
+bt_status launch_mip_level(bt_ctx* ctx, uint32_t format, const void* parent, void* child, uint32_t parent_size,
+                           uint32_t layers);
+bt_status launch_synth_fbm(bt_ctx* ctx, void* dst, uint32_t w, uint32_t h, uint64_t pitch, uint32_t x0, uint32_t y0,
+                           uint32_t base_cell, uint32_t octaves, uint32_t seed);
+
+// coordinate math (bt_host.cpp)
+void tile_children(bt_tile_coordinate c, bt_tile_coordinate out[4]);
+void tile_neighbours(bt_tile_coordinate c, bool spherical, bt_tile_coordinate out[8]);
+
+}  // namespace bt
+
+struct bt_preprocessor {
+    bt_ctx* ctx = nullptr;
+    std::vector<bt::Task> queue;
+    bool save_pending[BT_MAX_ATTACHMENTS] = {};
+    std::vector<bt::Raster> rasters;
+    uint32_t jobs = 0;
+    // compiled plan (rebuilt when the queue changes)
+    bool compiled = false;
+    uint32_t compiled_flags = 0;
+    std::vector<bt::Launch> plan;
+    bt::TaskDev* tasks_dev = nullptr;
+    size_t tasks_dev_cap = 0;
+    bt::RasterDev* rasters_dev = nullptr;
+    size_t rasters_dev_cap = 0;
+    bt_run_stats stats{};
+    // BT_RUN_PROFILE: events[run * (plan.size() + 1) + i]; event 0 of a run precedes its first launch
+    std::vector<hipEvent_t> events;
+    uint32_t profiled_runs = 0;
+};

@@ -1,0 +1,452 @@
+// Reference-shaped batched kernels: one launch per queue phase instead of one dispatch per tile.
+//   split      <- shaders/preprocess/split.wgsl:18-43
+//   downsample <- shaders/preprocess/downsample.wgsl:12-40
+//   stitch     <- shaders/preprocess/stitch.wgsl:12-118
+//   mip level  <- terrain_data/mod.rs:143-219
+// These are the general path (any dataset rectangle, any tile-existence pattern, cube faces, both
+// formats); the fused split+pyramid kernels in bt_fused.hip cover the common case faster.
+//
+// Arithmetic contract (identical to oracle/bt_oracle.c, checked bit-for-bit by tests/): IEEE binary32,
+// one rounding per written operation — this file is compiled with -ffp-contract=off; `/` and sqrtf are
+// correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+//
+// Unlike the WGSL these kernels work in place on the atlas layers: the reference's write-section round
+// trip (preprocess/mod.rs:169-210) exists only because a storage texture cannot be read and written in
+// one pass.  split reads only its own texel's previous value, downsample reads child layers, stitch
+// reads centres and writes aprons, so no task of a phase reads what another task of that phase writes.
+#include "bt_internal.hpp"
+
+namespace bt {
+
+namespace {
+
+constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+
+__device__ __forceinline__ float unorm16_to_float(uint32_t t) { return float(t) / 65535.0f; }
+__device__ __forceinline__ float unorm8_to_float(uint32_t t) { return float(t) / 255.0f; }
+
+// pack2x16unorm / pack4x8unorm component: floor(0.5 + N * clamp(e, 0, 1))
+__device__ __forceinline__ uint32_t float_to_unorm(float e, float n) {
+    const float cl = e < 0.0f ? 0.0f : (e > 1.0f ? 1.0f : e);
+    return uint32_t(floorf(0.5f + n * cl));
+}
+
+// WGSL mix(a, b, t) = a * (1 - t) + b * t
+__device__ __forceinline__ float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+
+struct Axis {
+    int i0, i1;  // clamped texel indices of the bilinear footprint
+    float fr;    // fractional weight
+};
+
+// One axis of split.wgsl:25-32 for texture pixel p of tile index `tile`:
+// tile_coords = (p - b) / c ; source = (tile + tile_coords) / 2^lod ; uv = inverse_mix(lo, hi, source);
+// sampler: texel centres at uv*dim - 0.5, clamp-to-edge.
+__device__ __forceinline__ Axis split_axis(uint32_t p, uint32_t b, uint32_t c, uint32_t tile, float scale, float lo,
+                                           float hi, uint32_t dim) {
+    const float tc = float(p - b) / float(c);
+    const float s = (float(tile) + tc) / scale;
+    const float u = (s - lo) / (hi - lo);
+    const float q = u * float(dim) - 0.5f;
+    const float fl = floorf(q);
+    Axis a;
+    a.fr = q - fl;
+    const int i = int(fl);
+    const int last = int(dim) - 1;
+    a.i0 = min(max(i, 0), last);
+    a.i1 = min(max(i + 1, 0), last);
+    return a;
+}
+
+template <uint32_t FORMAT>
+struct Texel;
+
+template <>
+struct Texel<BT_FORMAT_R16> {
+    using type = uint16_t;
+    static constexpr uint32_t kPerEntry = 2;
+};
+template <>
+struct Texel<BT_FORMAT_RGBA8> {
+    using type = uint32_t;
+    static constexpr uint32_t kPerEntry = 1;
+};
+
+__device__ __forceinline__ bool is_border(uint32_t px, uint32_t py, uint32_t b, uint32_t c) {
+    return !(px >= b && px < b + c && py >= b && py < b + c);
+}
+
+// ------------------------------------------------------------------------------------------ split
+
+// value of one centre pixel as a texel (u16 or packed rgba8); `previous` = the atlas texel before the task
+template <uint32_t FORMAT>
+__device__ __forceinline__ uint32_t split_texel(const RasterDev& r, const Axis& ax, const Axis& ay, uint32_t previous) {
+    const uint8_t* row0 = (const uint8_t*)r.data + uint64_t(ay.i0) * r.pitch;
+    const uint8_t* row1 = (const uint8_t*)r.data + uint64_t(ay.i1) * r.pitch;
+    if constexpr (FORMAT == BT_FORMAT_R16) {
+        const uint32_t t00 = ((const uint16_t*)row0)[ax.i0], t10 = ((const uint16_t*)row0)[ax.i1];
+        const uint32_t t01 = ((const uint16_t*)row1)[ax.i0], t11 = ((const uint16_t*)row1)[ax.i1];
+        const bool valid = t00 != 0 && t10 != 0 && t01 != 0 && t11 != 0;  // textureGather(0, ..) != 0
+        if (!valid) return previous;
+        const float top = mixf(unorm16_to_float(t00), unorm16_to_float(t10), ax.fr);
+        const float bot = mixf(unorm16_to_float(t01), unorm16_to_float(t11), ax.fr);
+        return float_to_unorm(mixf(top, bot, ay.fr), 65535.0f);
+    } else {
+        const uint32_t t00 = ((const uint32_t*)row0)[ax.i0], t10 = ((const uint32_t*)row0)[ax.i1];
+        const uint32_t t01 = ((const uint32_t*)row1)[ax.i0], t11 = ((const uint32_t*)row1)[ax.i1];
+        const bool valid = (t00 & 0xFFu) != 0 && (t10 & 0xFFu) != 0 && (t01 & 0xFFu) != 0 && (t11 & 0xFFu) != 0;
+        if (!valid) return previous;
+        uint32_t out = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t sh = 8 * k;
+            const float top = mixf(unorm8_to_float((t00 >> sh) & 0xFFu), unorm8_to_float((t10 >> sh) & 0xFFu), ax.fr);
+            const float bot = mixf(unorm8_to_float((t01 >> sh) & 0xFFu), unorm8_to_float((t11 >> sh) & 0xFFu), ax.fr);
+            out |= float_to_unorm(mixf(top, bot, ay.fr), 255.0f) << sh;
+        }
+        return out;
+    }
+}
+
+// grid.x = tasks * ceil(T / kRows); 256 threads sweep kRows rows of one tile, one 32-bit entry per step
+// (the reference's thread = one u32 entry, preprocessing.wgsl:59-90)
+constexpr uint32_t kRows = 8;
+
+template <uint32_t FORMAT>
+__global__ __launch_bounds__(256) void split_kernel(AttachmentMeta m, void* __restrict__ atlas,
+                                                    const TaskDev* __restrict__ tasks,
+                                                    const RasterDev* __restrict__ rasters, uint32_t row_blocks) {
+    using T = typename Texel<FORMAT>::type;
+    constexpr uint32_t kPer = Texel<FORMAT>::kPerEntry;
+    const uint32_t task_index = blockIdx.x / row_blocks;
+    const uint32_t row0 = (blockIdx.x % row_blocks) * kRows;
+    const TaskDev task = tasks[task_index];
+    const RasterDev raster = rasters[task.raster];
+    const uint32_t Tsz = m.texture_size, b = m.border_size, c = m.center_size;
+    const uint32_t entries_per_row = Tsz / kPer;
+    const float scale = float(1u << task.lod);  // tile_count(lod), functions.wgsl:156
+    T* tile = (T*)atlas + uint64_t(task.atlas_index) * Tsz * Tsz;
+
+    const uint32_t rows = min(kRows, Tsz - row0);
+    for (uint32_t e = threadIdx.x; e < entries_per_row * rows; e += blockDim.x) {
+        const uint32_t py = row0 + e / entries_per_row;
+        const uint32_t ex = e % entries_per_row;
+        uint32_t texels[kPer];
+        Axis ay{};
+        const bool row_is_centre = py >= b && py < b + c;
+        if (row_is_centre) ay = split_axis(py, b, c, task.y, scale, task.tly, task.bry, raster.height);
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; k++) {
+            const uint32_t px = ex * kPer + k;
+            if (!row_is_centre || px < b || px >= b + c) {
+                texels[k] = 0;  // split.wgsl:19-21: border pixels are zero until stitch fills them
+                continue;
+            }
+            const Axis ax = split_axis(px, b, c, task.x, scale, task.tlx, task.brx, raster.width);
+            const uint32_t previous = tile[uint64_t(py) * Tsz + px];
+            texels[k] = split_texel<FORMAT>(raster, ax, ay, previous);
+        }
+        if constexpr (FORMAT == BT_FORMAT_R16)
+            ((uint32_t*)tile)[(uint64_t(py) * Tsz) / 2 + ex] = texels[0] | (texels[1] << 16);
+        else
+            tile[uint64_t(py) * Tsz + ex] = texels[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------- downsample
+
+template <uint32_t FORMAT>
+__device__ __forceinline__ uint32_t downsample_texel(const typename Texel<FORMAT>::type* __restrict__ child,
+                                                     uint32_t Tsz, uint32_t cx, uint32_t cy) {
+    // OFFSETS (0,0),(0,1),(1,0),(1,1) as (dx,dy): downsample.wgsl:25
+    uint32_t t[4];
+    if (child) {
+        t[0] = child[uint64_t(cy) * Tsz + cx];
+        t[1] = child[uint64_t(cy + 1) * Tsz + cx];
+        t[2] = child[uint64_t(cy) * Tsz + cx + 1];
+        t[3] = child[uint64_t(cy + 1) * Tsz + cx + 1];
+    } else {
+        t[0] = t[1] = t[2] = t[3] = 0;  // child tile absent: the layer reads as zero
+    }
+    if constexpr (FORMAT == BT_FORMAT_R16) {
+        float value = 0.0f, count = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (t[i] != 0) {  // any(child_value.xyz != 0) with xyz = (r, 0, 0)
+                value += unorm16_to_float(t[i]);
+                count += 1.0f;
+            }
+        if (count == 0.0f) return 0;  // 0/0: defined as "no data" (oracle)
+        return float_to_unorm(value / count, 65535.0f);
+    } else {
+        float value[4] = {0.0f, 0.0f, 0.0f, 0.0f}, count = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if ((t[i] & 0x00FFFFFFu) != 0) {  // rgb != 0, alpha ignored
+#pragma unroll
+                for (int k = 0; k < 4; k++) value[k] += unorm8_to_float((t[i] >> (8 * k)) & 0xFFu);
+                count += 1.0f;
+            }
+        if (count == 0.0f) return 0;
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) out |= float_to_unorm(value[k] / count, 255.0f) << (8 * k);
+        return out;
+    }
+}
+
+template <uint32_t FORMAT>
+__global__ __launch_bounds__(256) void downsample_kernel(AttachmentMeta m, void* __restrict__ atlas,
+                                                         const TaskDev* __restrict__ tasks, uint32_t row_blocks) {
+    using T = typename Texel<FORMAT>::type;
+    constexpr uint32_t kPer = Texel<FORMAT>::kPerEntry;
+    const uint32_t task_index = blockIdx.x / row_blocks;
+    const uint32_t row0 = (blockIdx.x % row_blocks) * kRows;
+    const TaskDev task = tasks[task_index];
+    const uint32_t Tsz = m.texture_size, b = m.border_size, c = m.center_size;
+    const uint32_t entries_per_row = Tsz / kPer;
+    const uint32_t child_size = c / 2u;
+    T* base = (T*)atlas;
+    T* tile = base + uint64_t(task.atlas_index) * Tsz * Tsz;
+
+    const uint32_t rows = min(kRows, Tsz - row0);
+    for (uint32_t e = threadIdx.x; e < entries_per_row * rows; e += blockDim.x) {
+        const uint32_t py = row0 + e / entries_per_row;
+        const uint32_t ex = e % entries_per_row;
+        uint32_t texels[kPer];
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; k++) {
+            const uint32_t px = ex * kPer + k;
+            if (is_border(px, py, b, c)) {
+                texels[k] = 0;
+                continue;
+            }
+            const uint32_t tx = px - b, ty = py - b;
+            const uint32_t child_index = tx / child_size + 2u * (ty / child_size);
+            const uint32_t layer = task.rel_index[child_index & 3u];
+            const T* child = layer < m.atlas_size ? base + uint64_t(layer) * Tsz * Tsz : nullptr;
+            texels[k] = downsample_texel<FORMAT>(child, Tsz, 2u * (tx % child_size) + b, 2u * (ty % child_size) + b);
+        }
+        if constexpr (FORMAT == BT_FORMAT_R16)
+            ((uint32_t*)tile)[(uint64_t(py) * Tsz) / 2 + ex] = texels[0] | (texels[1] << 16);
+        else
+            tile[uint64_t(py) * Tsz + ex] = texels[0];
+    }
+}
+
+// ----------------------------------------------------------------------------------------- stitch
+
+// stitch.wgsl:12-51; PS/PT/NS/NT = +x, +y, T-1-x, T-1-y of the input coordinate
+__device__ __forceinline__ uint2 project_to_side(uint32_t x, uint32_t y, uint32_t Tsz, uint32_t own, uint32_t other) {
+    // two bits per output axis, low = x: 0 PS, 1 PT, 2 NS, 3 NT
+    constexpr uint32_t kEven[6] = {0 | 1 << 2, 0 | 1 << 2, 3 | 0 << 2, 3 | 2 << 2, 1 | 2 << 2, 0 | 1 << 2};
+    constexpr uint32_t kOdd[6] = {0 | 1 << 2, 0 | 1 << 2, 1 | 2 << 2, 1 | 0 << 2, 3 | 0 << 2, 0 | 1 << 2};
+    const uint32_t index = (6u + other - own) % 6u;
+    const uint32_t info = (own % 2u == 0u) ? kEven[index] : kOdd[index];
+    const uint32_t v[4] = {x, y, Tsz - 1u - x, Tsz - 1u - y};
+    return make_uint2(v[info & 3u], v[(info >> 2) & 3u]);
+}
+
+// apron pixel -> (layer, x, y) it copies, per stitch.wgsl:53-118
+__device__ __forceinline__ void stitch_source(const TaskDev& task, uint32_t px, uint32_t py, uint32_t Tsz, uint32_t b,
+                                              uint32_t c, uint32_t& layer, uint32_t& sx, uint32_t& sy) {
+    const uint32_t o = b + c;
+    // region ids of neighbour_index(): 0 top, 1 right, 2 bottom, 3 left, 4 TL, 5 TR, 6 BR, 7 BL
+    const int rx = px < b ? -1 : (px >= o ? 1 : 0);
+    const int ry = py < b ? -1 : (py >= o ? 1 : 0);
+    uint32_t region;
+    if (ry < 0) region = rx < 0 ? 4u : (rx > 0 ? 5u : 0u);
+    else if (ry > 0) region = rx < 0 ? 7u : (rx > 0 ? 6u : 2u);
+    else region = rx > 0 ? 1u : 3u;
+    const uint32_t nb = task.rel_index[region];
+    if (nb == kInvalid) {  // repeat_data: clamp into the own centre
+        layer = task.atlas_index;
+        sx = min(max(px, b), o - 1u);
+        sy = min(max(py, b), o - 1u);
+        return;
+    }
+    // neighbour_data: offsets[region] = -(neighbour offset) * c
+    const uint32_t qx = uint32_t(int(px) - rx * int(c));
+    const uint32_t qy = uint32_t(int(py) - ry * int(c));
+    const uint2 q = project_to_side(qx, qy, Tsz, task.side, task.rel_side[region]);
+    layer = nb;
+    sx = q.x;
+    sy = q.y;
+}
+
+// one thread per apron pixel: 2*b*T (top+bottom rows) + 2*b*c (left+right columns) per tile
+template <typename T>
+__global__ __launch_bounds__(256) void stitch_kernel(AttachmentMeta m, void* __restrict__ atlas,
+                                                     const TaskDev* __restrict__ tasks, uint32_t blocks_per_tile) {
+    const uint32_t task_index = blockIdx.x / blocks_per_tile;
+    const uint32_t i = (blockIdx.x % blocks_per_tile) * blockDim.x + threadIdx.x;
+    const uint32_t Tsz = m.texture_size, b = m.border_size, c = m.center_size;
+    const uint32_t n_rows = 2u * b * Tsz;
+    if (i >= n_rows + 2u * b * c) return;
+    const TaskDev task = tasks[task_index];
+    uint32_t px, py;
+    if (i < n_rows) {
+        const uint32_t r = i / Tsz;
+        px = i % Tsz;
+        py = r < b ? r : (c + r);  // rows 0..b-1 and b+c..T-1
+    } else {
+        const uint32_t j = i - n_rows;
+        const uint32_t k = j % (2u * b);
+        py = b + j / (2u * b);
+        px = k < b ? k : (c + k);
+    }
+    uint32_t layer, sx, sy;
+    stitch_source(task, px, py, Tsz, b, c, layer, sx, sy);
+    T* base = (T*)atlas;
+    T v = 0;
+    if (layer < m.atlas_size && sx < Tsz && sy < Tsz) v = base[uint64_t(layer) * Tsz * Tsz + uint64_t(sy) * Tsz + sx];
+    base[uint64_t(task.atlas_index) * Tsz * Tsz + uint64_t(py) * Tsz + px] = v;
+}
+
+// -------------------------------------------------------------------------------------- mip chain
+
+// AttachmentData::generate_mipmaps: R16 = truncating mean of the non-zero texels, RGBA8 = sum / 4
+__global__ __launch_bounds__(256) void mip_r16_kernel(const uint16_t* __restrict__ parent, uint16_t* __restrict__ child,
+                                                      uint32_t parent_size, uint32_t layers) {
+    const uint32_t cs = parent_size >> 1;
+    const uint64_t total = uint64_t(cs) * cs * layers;
+    for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += uint64_t(gridDim.x) * blockDim.x) {
+        const uint32_t cx = uint32_t(i % cs), cy = uint32_t((i / cs) % cs);
+        const uint64_t layer = i / (uint64_t(cs) * cs);
+        const uint16_t* p = parent + layer * parent_size * parent_size + uint64_t(2 * cy) * parent_size + 2 * cx;
+        const uint32_t v[4] = {p[0], p[parent_size], p[1], p[parent_size + 1]};
+        uint32_t value = 0, count = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (v[k] != 0) {
+                value += v[k];
+                count++;
+            }
+        child[i] = count == 0 ? uint16_t(0) : uint16_t(value / count);
+    }
+}
+
+__global__ __launch_bounds__(256) void mip_rgba8_kernel(const uint32_t* __restrict__ parent, uint32_t* __restrict__ child,
+                                                        uint32_t parent_size, uint32_t layers) {
+    const uint32_t cs = parent_size >> 1;
+    const uint64_t total = uint64_t(cs) * cs * layers;
+    for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += uint64_t(gridDim.x) * blockDim.x) {
+        const uint32_t cx = uint32_t(i % cs), cy = uint32_t((i / cs) % cs);
+        const uint64_t layer = i / (uint64_t(cs) * cs);
+        const uint32_t* p = parent + layer * parent_size * parent_size + uint64_t(2 * cy) * parent_size + 2 * cx;
+        const uint32_t v[4] = {p[0], p[1], p[parent_size], p[parent_size + 1]};
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t sh = 8 * k;
+            const uint32_t sum = ((v[0] >> sh) & 0xFFu) + ((v[1] >> sh) & 0xFFu) + ((v[2] >> sh) & 0xFFu) + ((v[3] >> sh) & 0xFFu);
+            out |= (sum / 4u) << sh;
+        }
+        child[i] = out;
+    }
+}
+
+// -------------------------------------------------------------------- synthetic fBm (bench input)
+
+__device__ __forceinline__ uint64_t hash2(uint64_t ix, uint64_t iy, uint32_t seed) {
+    uint64_t h = (ix * 0x85EBCA6Bull + iy * 0xC2B2AE35ull + seed) & 0xFFFFFFFFull;
+    h ^= h >> 15;
+    h = (h * 0x2C1B3C6Dull) & 0xFFFFFFFFull;
+    h ^= h >> 12;
+    h = (h * 0x297A2D39ull) & 0xFFFFFFFFull;
+    h ^= h >> 15;
+    return h & 0xFFFFull;
+}
+
+__device__ __forceinline__ uint64_t value_noise(uint64_t x, uint64_t y, uint64_t cell, uint32_t seed) {
+    const uint64_t ix = x / cell, fx = x % cell, iy = y / cell, fy = y % cell;
+    const uint64_t wx = (fx * 4096ull) / cell, wy = (fy * 4096ull) / cell;
+    const uint64_t v00 = hash2(ix, iy, seed), v10 = hash2(ix + 1, iy, seed);
+    const uint64_t v01 = hash2(ix, iy + 1, seed), v11 = hash2(ix + 1, iy + 1, seed);
+    const uint64_t top = v00 * (4096ull - wx) + v10 * wx;
+    const uint64_t bot = v01 * (4096ull - wx) + v11 * wx;
+    return (top * (4096ull - wy) + bot * wy) >> 24;
+}
+
+__global__ __launch_bounds__(256) void synth_fbm_kernel(uint8_t* __restrict__ dst, uint32_t w, uint32_t h, uint64_t pitch,
+                                                        uint32_t x0, uint32_t y0, uint32_t base_cell, uint32_t octaves,
+                                                        uint32_t seed) {
+    const uint64_t total = uint64_t(w) * h;
+    for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += uint64_t(gridDim.x) * blockDim.x) {
+        const uint32_t x = uint32_t(i % w), y = uint32_t(i / w);
+        uint64_t sum = 0, amp_total = 0, cell = base_cell;
+        for (uint32_t o = 0; o < octaves; o++) {
+            if (cell < 1) cell = 1;
+            const uint64_t amp = 1ull << (octaves - 1 - o);
+            sum += value_noise(uint64_t(x) + x0, uint64_t(y) + y0, cell, seed + 0x9E3779B9u * (o + 1)) * amp;
+            amp_total += amp;
+            cell /= 2;
+        }
+        const uint64_t v = sum / amp_total;
+        ((uint16_t*)(dst + uint64_t(y) * pitch))[x] = uint16_t(1ull + (v * 65534ull) / 65535ull);
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------- launchers
+
+static bt_status check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, what);
+    return BT_OK;
+}
+
+bt_status launch_split(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const TaskDev* tasks, uint32_t n,
+                       const RasterDev* rasters) {
+    if (!n) return BT_OK;
+    const uint32_t row_blocks = (m.texture_size + kRows - 1) / kRows;
+    if (m.format == BT_FORMAT_R16)
+        split_kernel<BT_FORMAT_R16><<<n * row_blocks, 256, 0, ctx->stream>>>(m, atlas, tasks, rasters, row_blocks);
+    else
+        split_kernel<BT_FORMAT_RGBA8><<<n * row_blocks, 256, 0, ctx->stream>>>(m, atlas, tasks, rasters, row_blocks);
+    return check_launch("split_kernel");
+}
+
+bt_status launch_downsample(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const TaskDev* tasks, uint32_t n) {
+    if (!n) return BT_OK;
+    const uint32_t row_blocks = (m.texture_size + kRows - 1) / kRows;
+    if (m.format == BT_FORMAT_R16)
+        downsample_kernel<BT_FORMAT_R16><<<n * row_blocks, 256, 0, ctx->stream>>>(m, atlas, tasks, row_blocks);
+    else
+        downsample_kernel<BT_FORMAT_RGBA8><<<n * row_blocks, 256, 0, ctx->stream>>>(m, atlas, tasks, row_blocks);
+    return check_launch("downsample_kernel");
+}
+
+bt_status launch_stitch(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const TaskDev* tasks, uint32_t n) {
+    if (!n || m.border_size == 0) return BT_OK;
+    const uint32_t apron = 2u * m.border_size * (m.texture_size + m.center_size);
+    const uint32_t blocks = (apron + 255u) / 256u;
+    if (m.format == BT_FORMAT_R16)
+        stitch_kernel<uint16_t><<<n * blocks, 256, 0, ctx->stream>>>(m, atlas, tasks, blocks);
+    else
+        stitch_kernel<uint32_t><<<n * blocks, 256, 0, ctx->stream>>>(m, atlas, tasks, blocks);
+    return check_launch("stitch_kernel");
+}
+
+bt_status launch_mip_level(bt_ctx* ctx, uint32_t format, const void* parent, void* child, uint32_t parent_size,
+                           uint32_t layers) {
+    const uint64_t total = uint64_t(parent_size >> 1) * (parent_size >> 1) * layers;
+    if (!total) return BT_OK;
+    const uint32_t grid = uint32_t(std::min<uint64_t>((total + 255) / 256, 256ull * 16));
+    if (format == BT_FORMAT_R16)
+        mip_r16_kernel<<<grid, 256, 0, ctx->stream>>>((const uint16_t*)parent, (uint16_t*)child, parent_size, layers);
+    else
+        mip_rgba8_kernel<<<grid, 256, 0, ctx->stream>>>((const uint32_t*)parent, (uint32_t*)child, parent_size, layers);
+    return check_launch("mip kernel");
+}
+
+bt_status launch_synth_fbm(bt_ctx* ctx, void* dst, uint32_t w, uint32_t h, uint64_t pitch, uint32_t x0, uint32_t y0,
+                           uint32_t base_cell, uint32_t octaves, uint32_t seed) {
+    const uint64_t total = uint64_t(w) * h;
+    const uint32_t grid = uint32_t(std::min<uint64_t>((total + 255) / 256, 256ull * 32));
+    synth_fbm_kernel<<<grid, 256, 0, ctx->stream>>>((uint8_t*)dst, w, h, pitch, x0, y0, base_cell, octaves, seed);
+    return check_launch("synth_fbm_kernel");
+}
+
+}  // namespace bt

@@ -1,0 +1,223 @@
+// bt_preprocessor_run: compiles the task queue into a launch plan and enqueues it on the stream.
+//
+// The reference drains its queue at most 32 tasks per attachment per frame, with a per-task uniform
+// buffer + bind group, four tile copies per task and a one-frame readback (select_ready_tasks
+// preprocessor.rs:346-399, GpuPreprocessor::prepare gpu_preprocessor.rs:120-223,
+// TerrainPreprocessNode::run preprocess/mod.rs:143-218).  Here a phase (the tasks between two
+// Barrier tasks) becomes ONE batched launch per task type, reading a device array of task records;
+// where a job qualifies, split + the top of the LOD pyramid + aprons are fused (bt_fused.hip).
+#include <algorithm>
+#include <cstring>
+
+#include "bt_internal.hpp"
+
+using namespace bt;
+
+namespace bt {
+bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, std::vector<Launch>& plan);
+bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l);
+}  // namespace bt
+
+namespace {
+
+TaskDev to_device_task(const Task& t) {
+    TaskDev d{};
+    d.atlas_index = t.atlas_index;
+    d.side = t.coord.side;
+    d.lod = t.coord.lod;
+    d.x = t.coord.x;
+    d.y = t.coord.y;
+    d.tlx = t.tl[0];
+    d.tly = t.tl[1];
+    d.brx = t.br[0];
+    d.bry = t.br[1];
+    d.raster = t.raster < 0 ? 0u : uint32_t(t.raster);
+    for (int i = 0; i < 8; i++) {
+        d.rel_index[i] = t.rel[i].atlas_index;
+        d.rel_side[i] = t.rel[i].coordinate.side;
+    }
+    if (t.type == kDownsample)
+        for (int i = 4; i < 8; i++) d.rel_index[i] = BT_INVALID_ATLAS_INDEX;
+    return d;
+}
+
+// reference-shaped plan: every maximal run of same-type, same-attachment tasks inside a phase is a launch
+void generic_plan(const bt_preprocessor* p, const bt_atlas* a, std::vector<TaskDev>& tasks, std::vector<Launch>& plan) {
+    size_t i = 0;
+    const std::vector<Task>& q = p->queue;
+    while (i < q.size()) {
+        const Task& t = q[i];
+        if (t.type == kBarrier || t.type == kSave) {
+            i++;
+            continue;
+        }
+        size_t j = i;
+        const uint32_t first = uint32_t(tasks.size());
+        while (j < q.size() && q[j].type == t.type && q[j].attachment_index == t.attachment_index) {
+            tasks.push_back(to_device_task(q[j]));
+            j++;
+        }
+        Launch l{};
+        l.kind = t.type == kSplit ? kLaunchSplit : t.type == kDownsample ? kLaunchDownsample : kLaunchStitch;
+        l.attachment = t.attachment_index;
+        l.first_task = first;
+        l.task_count = uint32_t(j - i);
+        {   // algorithmic bytes of this launch
+            const AttachmentMeta& m = a->attachments[t.attachment_index].meta;
+            const uint64_t bpp = m.pixel_size, T = m.texture_size, c = m.center_size, b = m.border_size;
+            if (t.type == kSplit) {
+                std::vector<bool> seen(p->rasters.size(), false);
+                for (size_t k = i; k < j; k++)
+                    if (q[k].raster >= 0 && !seen[q[k].raster]) {
+                        seen[q[k].raster] = true;
+                        l.algorithmic_bytes += uint64_t(p->rasters[q[k].raster].dev.width) * p->rasters[q[k].raster].dev.height * bpp;
+                    }
+                l.algorithmic_bytes += uint64_t(j - i) * T * T * bpp;
+            } else if (t.type == kDownsample) {
+                l.algorithmic_bytes = uint64_t(j - i) * (4 * c * c + T * T) * bpp;  // 4 child texels per centre pixel
+            } else {
+                l.algorithmic_bytes = uint64_t(j - i) * 2 * (2 * b * (T + c)) * bpp;  // apron read + written
+            }
+        }
+        plan.push_back(l);
+        i = j;
+    }
+}
+
+bt_status ensure_device_array(void** ptr, size_t* cap, size_t bytes) {
+    if (*cap >= bytes && *ptr) return BT_OK;
+    if (*ptr) hipFree(*ptr);
+    *ptr = nullptr;
+    *cap = 0;
+    BT_HIP(hipMalloc(ptr, bytes ? bytes : 1));
+    *cap = bytes;
+    return BT_OK;
+}
+
+}  // namespace
+
+extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32_t flags) {
+    if (!p || !a) return BT_ERR_INVALID_ARGUMENT;
+    if (p->ctx != a->ctx) {
+        set_error("preprocessor and atlas belong to different contexts");
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    BT_HIP(hipSetDevice(p->ctx->device));
+    const uint32_t mode = flags & BT_RUN_GENERIC;
+
+    if (!p->compiled || p->compiled_flags != mode) {
+        std::vector<TaskDev> tasks;
+        p->plan.clear();
+        bool fused = false;
+        if (!mode) fused = fused_plan(p, a, tasks, p->plan);
+        if (!fused) {
+            tasks.clear();
+            p->plan.clear();
+            generic_plan(p, a, tasks, p->plan);
+        }
+        std::vector<RasterDev> rasters;
+        for (const Raster& r : p->rasters) rasters.push_back(r.dev);
+        if (bt_status s = ensure_device_array((void**)&p->tasks_dev, &p->tasks_dev_cap, tasks.size() * sizeof(TaskDev))) return s;
+        if (bt_status s = ensure_device_array((void**)&p->rasters_dev, &p->rasters_dev_cap, rasters.size() * sizeof(RasterDev))) return s;
+        // synchronous staging of two small arrays; done once per queue, not per run
+        if (!tasks.empty()) BT_HIP(hipMemcpy(p->tasks_dev, tasks.data(), tasks.size() * sizeof(TaskDev), hipMemcpyHostToDevice));
+        if (!rasters.empty()) BT_HIP(hipMemcpy(p->rasters_dev, rasters.data(), rasters.size() * sizeof(RasterDev), hipMemcpyHostToDevice));
+
+        // statistics: algorithmic bytes = every source texel once + every produced tile texel once
+        bt_run_stats st{};
+        std::vector<bool> raster_used(p->rasters.size(), false);
+        for (const Task& t : p->queue) {
+            if (t.type == kSplit && t.raster >= 0 && !raster_used[t.raster]) {
+                raster_used[t.raster] = true;
+                const Raster& r = p->rasters[t.raster];
+                st.algorithmic_bytes += uint64_t(r.dev.width) * r.dev.height * (r.format == BT_FORMAT_R16 ? 2 : 4);
+            }
+            if (t.type == kStitch) {  // every tile of a job is stitched exactly once
+                st.tiles++;
+                st.algorithmic_bytes += a->attachments[t.attachment_index].tile_bytes;
+            }
+        }
+        st.kernel_launches = uint32_t(p->plan.size());
+        st.fused_jobs = fused ? p->jobs : 0;
+        st.generic_jobs = fused ? 0 : p->jobs;
+        p->stats = st;
+        p->compiled = true;
+        p->compiled_flags = mode;
+        for (hipEvent_t e : p->events) hipEventDestroy(e);
+        p->events.clear();
+        p->profiled_runs = 0;
+    }
+
+    const bool profile = (flags & BT_RUN_PROFILE) != 0 && p->profiled_runs < 256;
+    auto record = [&](void) -> bt_status {
+        hipEvent_t e;
+        BT_HIP(hipEventCreate(&e));
+        p->events.push_back(e);
+        BT_HIP(hipEventRecord(e, p->ctx->stream));
+        return BT_OK;
+    };
+    if (profile)
+        if (bt_status s = record()) return s;
+
+    for (const Launch& l : p->plan) {
+        const Attachment& at = a->attachments[l.attachment];
+        bt_status s = BT_OK;
+        switch (l.kind) {
+            case kLaunchSplit:
+                s = launch_split(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count, p->rasters_dev);
+                break;
+            case kLaunchDownsample:
+                s = launch_downsample(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count);
+                break;
+            case kLaunchStitch:
+                s = launch_stitch(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count);
+                break;
+            default:
+                s = fused_launch(p, a, l);
+                break;
+        }
+        if (s) return s;
+        if (profile)
+            if (bt_status s2 = record()) return s2;
+    }
+    if (profile) p->profiled_runs++;
+
+    // Save tasks: remembered until bt_preprocessor_save (the reference starts them as tasks drain)
+    for (const Task& t : p->queue)
+        if (t.type == kSave) p->save_pending[t.attachment_index] = true;
+    if (!(flags & BT_RUN_KEEP_QUEUE)) {
+        BT_HIP(hipStreamSynchronize(p->ctx->stream));  // borrowed rasters may be released by the caller afterwards
+        p->queue.clear();
+        for (Raster& r : p->rasters)
+            if (r.owned && r.dev.data) hipFree((void*)r.dev.data);
+        p->rasters.clear();
+        p->jobs = 0;
+        p->compiled = false;
+    }
+    return BT_OK;
+}
+
+extern "C" bt_status bt_preprocessor_profile(bt_preprocessor* p, bt_launch_profile* out, uint32_t cap, uint32_t* count) {
+    if (!p || !count) return BT_ERR_INVALID_ARGUMENT;
+    const uint32_t n = uint32_t(p->plan.size());
+    *count = n;
+    BT_HIP(hipStreamSynchronize(p->ctx->stream));
+    for (uint32_t i = 0; i < n && i < cap; i++) {
+        const Launch& l = p->plan[i];
+        double total = 0.0;
+        for (uint32_t r = 0; r < p->profiled_runs; r++) {
+            float ms = 0.0f;
+            BT_HIP(hipEventElapsedTime(&ms, p->events[size_t(r) * (n + 1) + i], p->events[size_t(r) * (n + 1) + i + 1]));
+            total += ms;
+        }
+        out[i].kind = uint32_t(l.kind);
+        out[i].tasks = l.task_count;
+        out[i].algorithmic_bytes = l.algorithmic_bytes;
+        out[i].samples = p->profiled_runs;
+        out[i].avg_ms = p->profiled_runs ? float(total / p->profiled_runs) : 0.0f;
+    }
+    for (hipEvent_t e : p->events) hipEventDestroy(e);
+    p->events.clear();
+    p->profiled_runs = 0;
+    return BT_OK;
+}

@@ -1,0 +1,187 @@
+"""Preprocessor / PreprocessDataset / SphericalDataset (src/preprocess/preprocessor.rs) over the C ABI.
+
+The builder API is the reference's: `Preprocessor.new().clear_attachment(i, atlas).preprocess_tile(
+dataset, asset_server, atlas)`.  Where the reference then lets Bevy's schedule drain the queue over
+many frames (`commands.spawn((tile_atlas, preprocessor))`), the host calls `.run(atlas)` — the whole
+queue becomes a handful of kernel launches on the device's stream — and `.save(atlas, assets_root)`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _ffi
+from .terrain import AttachmentFormat
+from .tile_atlas import TileAtlas
+
+
+class AssetServer:
+    """Stands in for Bevy's AssetServer: `load(path)` returns the source raster registered under `path`
+    (numpy array, torch CUDA tensor, or a (device_ptr, width, height, format) tuple) or decodes an image
+    file below `root` (16-bit PNG / TIFF via Pillow — formats/tiff.rs forces R16Unorm the same way)."""
+
+    def __init__(self, root: str = "assets"):
+        self.root = root
+        self._rasters: Dict[str, object] = {}
+
+    def insert(self, path: str, raster) -> "AssetServer":
+        self._rasters[path] = raster
+        return self
+
+    def load(self, path: str):
+        if path in self._rasters:
+            return self._rasters[path]
+        full = os.path.join(self.root, path)
+        if not os.path.exists(full):
+            raise FileNotFoundError(f"source raster {path!r} neither registered nor found at {full}")
+        if full.endswith(".npy"):
+            return np.load(full)
+        from PIL import Image
+
+        Image.MAX_IMAGE_PIXELS = None
+        img = Image.open(full)
+        arr = np.array(img)
+        if arr.ndim == 2:
+            return arr.astype(np.uint16) if arr.dtype != np.uint16 else arr
+        if arr.shape[2] == 3:
+            arr = np.concatenate([arr, np.full(arr.shape[:2] + (1,), 255, arr.dtype)], axis=2)
+        return arr.astype(np.uint8)
+
+
+@dataclass
+class PreprocessDataset:  # preprocessor.rs:35-55
+    attachment_index: int = 0
+    path: str = ""
+    side: int = 0
+    top_left: Tuple[float, float] = (0.0, 0.0)
+    bottom_right: Tuple[float, float] = (1.0, 1.0)
+    lod_range: range = range(0, 1)
+
+
+@dataclass
+class SphericalDataset:  # preprocessor.rs:29-33
+    attachment_index: int = 0
+    paths: List[str] = field(default_factory=list)
+    lod_range: range = range(0, 1)
+
+
+def _raster_struct(raster, fmt: AttachmentFormat, keep: list) -> _ffi.RasterC:
+    r = _ffi.RasterC()
+    r.format = fmt.id()
+    if isinstance(raster, tuple):  # (device_ptr, width, height[, row_pitch])
+        r.data, r.width, r.height = raster[0], raster[1], raster[2]
+        r.row_pitch = raster[3] if len(raster) > 3 else 0
+        r.on_device = 1
+        return r
+    if hasattr(raster, "data_ptr"):  # torch tensor
+        t = raster
+        if t.is_cuda:
+            if t.stride(-1) != 1 and not (t.dim() == 3 and t.stride(-1) == 1):
+                raise ValueError("source tensor rows must be contiguous")
+            keep.append(t)
+            r.data, r.height, r.width = t.data_ptr(), t.shape[0], t.shape[1]
+            r.row_pitch = t.stride(0) * t.element_size()
+            r.on_device = 1
+            return r
+        raster = t.numpy()
+    a = np.ascontiguousarray(raster)
+    want = np.uint16 if fmt == AttachmentFormat.R16 else np.uint8
+    if a.dtype != want or (fmt == AttachmentFormat.Rgba8 and (a.ndim != 3 or a.shape[2] != 4)):
+        raise ValueError(f"raster dtype/shape {a.dtype}{a.shape} does not match attachment format {fmt.value}")
+    keep.append(a)
+    r.data, r.height, r.width = a.ctypes.data, a.shape[0], a.shape[1]
+    r.row_pitch = 0
+    r.on_device = 0
+    return r
+
+
+class Preprocessor:
+    def __init__(self, device=None):
+        self._device = device
+        self._h = None
+        self._keep: list = []
+
+    @staticmethod
+    def new() -> "Preprocessor":
+        return Preprocessor()
+
+    def _handle(self, tile_atlas: TileAtlas):
+        if self._h is None:
+            self._device = self._device or tile_atlas.device
+            h = C.c_void_p()
+            _ffi.check(_ffi.lib().bt_preprocessor_create(self._device._h, C.byref(h)))
+            self._h = h
+        return self._h
+
+    def clear_attachment(self, attachment_index: int, tile_atlas: TileAtlas, assets_root: Optional[str] = None) -> "Preprocessor":
+        """existing_tiles.clear() and, when `assets_root` is given, reset_directory() of the attachment
+        folder (preprocessor.rs:18-22, 290-296)."""
+        d = tile_atlas.attachment_directory(assets_root, attachment_index).encode() if assets_root else None
+        _ffi.check(_ffi.lib().bt_preprocessor_clear_attachment(self._handle(tile_atlas), tile_atlas._h, attachment_index, d))
+        return self
+
+    def preprocess_tile(self, dataset: PreprocessDataset, asset_server: AssetServer, tile_atlas: TileAtlas) -> "Preprocessor":
+        fmt = tile_atlas.config.attachments[dataset.attachment_index].format
+        raster = _raster_struct(asset_server.load(dataset.path), fmt, self._keep)
+        d = _ffi.PreprocessDatasetC(dataset.attachment_index, dataset.side, (C.c_float * 2)(*dataset.top_left),
+                                    (C.c_float * 2)(*dataset.bottom_right), dataset.lod_range.start, dataset.lod_range.stop)
+        _ffi.check(_ffi.lib().bt_preprocessor_preprocess_tile(self._handle(tile_atlas), tile_atlas._h, C.byref(d), C.byref(raster)))
+        return self
+
+    def preprocess_spherical(self, dataset: SphericalDataset, asset_server: AssetServer, tile_atlas: TileAtlas) -> "Preprocessor":
+        fmt = tile_atlas.config.attachments[dataset.attachment_index].format
+        rasters = (_ffi.RasterC * 6)(*[_raster_struct(asset_server.load(p), fmt, self._keep) for p in dataset.paths])
+        d = _ffi.SphericalDatasetC(dataset.attachment_index, dataset.lod_range.start, dataset.lod_range.stop)
+        _ffi.check(_ffi.lib().bt_preprocessor_preprocess_spherical(self._handle(tile_atlas), tile_atlas._h, C.byref(d), rasters))
+        return self
+
+    def task_counts(self) -> Dict[str, int]:
+        counts = (C.c_uint32 * 5)()
+        if self._h is not None:
+            _ffi.lib().bt_preprocessor_task_counts(self._h, counts)
+        return dict(zip(("split", "stitch", "downsample", "save", "barrier"), list(counts)))
+
+    def run(self, tile_atlas: TileAtlas, *, generic: bool = False, keep_queue: bool = False, sync: bool = True,
+            profile: bool = False) -> "Preprocessor":
+        flags = ((_ffi.RUN_GENERIC if generic else 0) | (_ffi.RUN_KEEP_QUEUE if keep_queue else 0)
+                 | (_ffi.RUN_PROFILE if profile else 0))
+        _ffi.check(_ffi.lib().bt_preprocessor_run(self._handle(tile_atlas), tile_atlas._h, flags))
+        if sync:
+            self._device.synchronize()
+        if not keep_queue:
+            self._keep.clear()
+        return self
+
+    def stats(self) -> Dict[str, int]:
+        s = _ffi.RunStatsC()
+        _ffi.check(_ffi.lib().bt_preprocessor_last_run_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    KINDS = ("split", "downsample", "stitch", "fused_main", "fused_tail")
+
+    def profile(self) -> List[dict]:
+        """Average device time per launch of the runs made with profile=True (hipEvents on the stream)."""
+        n = C.c_uint32()
+        out = (_ffi.LaunchProfileC * 256)()
+        _ffi.check(_ffi.lib().bt_preprocessor_profile(self._h, out, 256, C.byref(n)))
+        return [dict(kind=self.KINDS[out[i].kind], tasks=out[i].tasks, algorithmic_bytes=out[i].algorithmic_bytes,
+                     avg_ms=out[i].avg_ms, samples=out[i].samples) for i in range(min(n.value, 256))]
+
+    def save(self, tile_atlas: TileAtlas, assets_root: str = "assets") -> "Preprocessor":
+        _ffi.check(_ffi.lib().bt_preprocessor_save(self._handle(tile_atlas), tile_atlas._h, assets_root.encode()))
+        return self
+
+    def close(self):
+        if self._h is not None:
+            _ffi.lib().bt_preprocessor_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,284 @@
+/*
+ * bevy_terrain_amd.h — C ABI of the MI355X-native terrain preprocessing + tiling-prepass backend.
+ *
+ * This is the drop-in boundary.  The reference (kurtkuehnert/bevy_terrain @ 2025-03-14) has no
+ * FFI: its preprocessing and tile refinement run as wgpu compute passes inside a Bevy render
+ * graph.  A Rust host keeps the public API (TerrainPlugin / TerrainPreprocessPlugin /
+ * Preprocessor / TileAtlas / TileTree) and replaces the internal seam
+ *     GpuPreprocessor::prepare + TerrainPreprocessNode::run + GpuAtlasAttachment::{copy_*,
+ *     download_tiles, start_downloading_tiles}           (src/preprocess/mod.rs:143-218,
+ *                                                         src/preprocess/gpu_preprocessor.rs:120-223,
+ *                                                         src/terrain_data/gpu_tile_atlas.rs:276-412)
+ *     TilingPrepassNode::run + TerrainViewData buffers   (src/render/tiling_prepass.rs:204-272,
+ *                                                         src/render/terrain_view_bind_group.rs:118-247)
+ * with calls into this library (see INTEGRATION.md for the `extern "C"` block).
+ *
+ * Conventions: opaque handles; POD structs with explicit layout; every function returns a
+ * bt_status (0 = ok, < 0 = error) and never throws or aborts; bt_last_error() returns the text of
+ * the last error of the calling thread; no callbacks; no global state besides that error string;
+ * one bt_ctx per GPU and per host thread that drives it.  All file:line citations are relative to the reference checkout.
+ */
+#ifndef BEVY_TERRAIN_AMD_H
+#define BEVY_TERRAIN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BT_ABI_VERSION 1u
+
+typedef int32_t bt_status;
+enum {
+    BT_OK = 0,
+    BT_ERR_INVALID_ARGUMENT = -1,
+    BT_ERR_ATLAS_OUT_OF_INDICES = -2, /* the reference panics "Atlas out of indices", tile_atlas.rs:384 */
+    BT_ERR_DEVICE = -3,               /* a HIP call failed; text in bt_last_error() */
+    BT_ERR_IO = -4,
+    BT_ERR_UNSUPPORTED = -5, /* e.g. AttachmentFormat::Rgb8 / Rg16: silently unprocessed upstream */
+    BT_ERR_OUT_OF_MEMORY = -6,
+    BT_ERR_OVERFLOW = -7, /* tile buffer of the tiling prepass too small */
+};
+
+#define BT_INVALID_ATLAS_INDEX 0xFFFFFFFFu /* terrain_data/mod.rs:34 */
+#define BT_INVALID_LOD 0xFFFFFFFFu         /* terrain_data/mod.rs:35 */
+#define BT_MAX_ATTACHMENTS 8u              /* shaders/bindings.wgsl:16-31 */
+
+/* AttachmentFormat (terrain_data/mod.rs:37-57); values are AttachmentFormat::id(). */
+enum {
+    BT_FORMAT_RGBA8 = 0,
+    BT_FORMAT_R16 = 1,
+    BT_FORMAT_RG16 = 3, /* accepted in configs, not processed (like the reference) -> BT_ERR_UNSUPPORTED */
+    BT_FORMAT_RGB8 = 5, /* dito */
+};
+
+/* TileCoordinate (math/coordinate.rs:155-167) — 16 bytes, also the GPU layout (types.wgsl:25-29). */
+typedef struct bt_tile_coordinate {
+    uint32_t side, lod, x, y;
+} bt_tile_coordinate;
+
+/* AtlasTile (terrain_data/tile_atlas.rs:30-35) — 32 bytes, GPU layout preprocessing.wgsl:16-22. */
+typedef struct bt_atlas_tile {
+    bt_tile_coordinate coordinate;
+    uint32_t atlas_index;
+    uint32_t _padding[3];
+} bt_atlas_tile;
+
+/* AttachmentConfig (terrain_data/mod.rs:87-109). */
+typedef struct bt_attachment_config {
+    char name[64];
+    uint32_t texture_size;    /* default 512 */
+    uint32_t border_size;     /* default 1 */
+    uint32_t mip_level_count; /* default 1 */
+    uint32_t format;          /* BT_FORMAT_* ; default R16 */
+} bt_attachment_config;
+
+/* TerrainConfig (terrain.rs:26-49); only the fields the path reads. */
+typedef struct bt_terrain_config {
+    uint32_t lod_count;    /* default 1 */
+    uint32_t atlas_size;   /* default 1024 */
+    uint32_t spherical;    /* TerrainModel::is_spherical(), math/terrain_model.rs:54-60 */
+    uint32_t attachment_count;
+    bt_attachment_config attachments[BT_MAX_ATTACHMENTS];
+    char path[256];        /* terrain folder below the assets root */
+} bt_terrain_config;
+
+/* A source raster handed to Preprocessor::preprocess_tile in place of asset_server.load(path)
+ * (preprocessor.rs:240).  Texels: u16 (R16) or RGBA8, row-major, `row_pitch` bytes per row. */
+typedef struct bt_raster {
+    const void* data;
+    uint32_t width, height;
+    uint64_t row_pitch;  /* bytes; 0 = tightly packed */
+    uint32_t format;     /* BT_FORMAT_R16 or BT_FORMAT_RGBA8; must equal the attachment's */
+    uint32_t on_device;  /* 0: host memory (copied to the GPU by the call), 1: device pointer (borrowed
+                            until the preprocessor has run) */
+} bt_raster;
+
+/* PreprocessDataset (preprocessor.rs:35-55). */
+typedef struct bt_preprocess_dataset {
+    uint32_t attachment_index;
+    uint32_t side;
+    float top_left[2];     /* default (0,0) */
+    float bottom_right[2]; /* default (1,1) */
+    uint32_t lod_begin, lod_end; /* lod_range = lod_begin..lod_end, default 0..1 */
+} bt_preprocess_dataset;
+
+/* SphericalDataset (preprocessor.rs:29-33); rasters are passed next to it, one per cube side. */
+typedef struct bt_spherical_dataset {
+    uint32_t attachment_index;
+    uint32_t lod_begin, lod_end;
+} bt_spherical_dataset;
+
+typedef struct bt_ctx bt_ctx;                   /* one GPU + one stream */
+typedef struct bt_atlas bt_atlas;               /* TileAtlas + GpuTileAtlas */
+typedef struct bt_preprocessor bt_preprocessor; /* Preprocessor + GpuPreprocessor */
+typedef struct bt_tiling_prepass bt_tiling_prepass; /* TerrainViewData buffers + TilingPrepassNode */
+
+/* ------------------------------------------------------------------ context */
+uint32_t bt_abi_version(void);
+const char* bt_last_error(void);
+/* `stream` is a hipStream_t owned by the caller (NULL = the library creates its own). */
+bt_status bt_ctx_create(int32_t device, void* stream, bt_ctx** out);
+void bt_ctx_destroy(bt_ctx* ctx);
+bt_status bt_ctx_set_stream(bt_ctx* ctx, void* stream);
+void* bt_ctx_stream(const bt_ctx* ctx);
+bt_status bt_ctx_synchronize(bt_ctx* ctx);
+/* hipEvent pair on the context's stream: begin .. end -> elapsed milliseconds (end synchronises) */
+bt_status bt_ctx_timer_begin(bt_ctx* ctx);
+bt_status bt_ctx_timer_end(bt_ctx* ctx, float* elapsed_ms);
+bt_status bt_device_malloc(bt_ctx* ctx, size_t bytes, void** out);
+bt_status bt_device_free(bt_ctx* ctx, void* ptr);
+bt_status bt_memcpy_h2d(bt_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
+bt_status bt_memcpy_d2h(bt_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
+
+/* --------------------------------------------- TileCoordinate (coordinate.rs) */
+void bt_tile_children(bt_tile_coordinate c, bt_tile_coordinate out[4]);                     /* :196-206 */
+void bt_tile_neighbours(bt_tile_coordinate c, uint32_t spherical, bt_tile_coordinate out[8]); /* :208-279 */
+bt_tile_coordinate bt_tile_parent(bt_tile_coordinate c);                                    /* :187-194 */
+/* "{side}_{lod}_{x}_{y}" (:282-286); returns the length written (without NUL) */
+int32_t bt_tile_name(bt_tile_coordinate c, char* buf, size_t cap);
+
+/* ------------------------------------- TileAtlas (terrain_data/tile_atlas.rs) */
+/* TileAtlas::new (:531-551): allocates atlas_size x T x T texels per attachment in HBM (zeroed,
+ * like a fresh wgpu texture), the index allocator and the existing-tile set. */
+bt_status bt_atlas_create(bt_ctx* ctx, const bt_terrain_config* config, bt_atlas** out);
+void bt_atlas_destroy(bt_atlas* atlas);
+/* TileAtlas::get_tile / get_or_allocate_tile (:553-559, 369-416). */
+bt_status bt_atlas_get_tile(bt_atlas* atlas, bt_tile_coordinate c, bt_atlas_tile* out);
+bt_status bt_atlas_get_or_allocate_tile(bt_atlas* atlas, bt_tile_coordinate c, bt_atlas_tile* out);
+/* existing_tiles in atlas-index (= allocation) order. Returns the tile count; fills up to `cap`. */
+uint32_t bt_atlas_tiles(const bt_atlas* atlas, bt_tile_coordinate* coords, uint32_t* atlas_indices, uint32_t cap);
+/* Device storage of one attachment: layer `i` starts at ptr + i*tile_bytes; rows are T*pixel_size
+ * bytes, tightly packed, texel layout = the `.bin` tile file layout. */
+bt_status bt_atlas_attachment_storage(const bt_atlas* atlas, uint32_t attachment_index, void** device_ptr,
+                                      uint64_t* tile_bytes, uint32_t* layers);
+/* download + de-pad (gpu_tile_atlas.rs:338-412): `count` consecutive layers into host memory. */
+bt_status bt_atlas_download_tiles(bt_atlas* atlas, uint32_t attachment_index, uint32_t first_layer,
+                                  uint32_t count, void* dst_host, uint64_t dst_bytes);
+/* upload_tiles level 0 (gpu_tile_atlas.rs:309-336). */
+bt_status bt_atlas_upload_tile(bt_atlas* atlas, uint32_t attachment_index, uint32_t layer, const void* src_host,
+                               uint64_t src_bytes);
+/* AtlasTileAttachmentWithData::start_saving (:77-116): writes "{directory}/{coord}.bin" for every
+ * existing tile.  TileAtlas::save_tile_config (:605-612): bincode-2 TC file (tiles sorted). */
+bt_status bt_atlas_save_attachment(bt_atlas* atlas, uint32_t attachment_index, const char* directory);
+bt_status bt_atlas_save_tile_config(const bt_atlas* atlas, const char* file_path);
+/* load_tile_config (:616-623): marks the listed tiles as existing. */
+bt_status bt_atlas_load_tile_config(bt_atlas* atlas, const char* file_path);
+/* formats/mod.rs:8-35 — bincode 2 `config::standard()` of Vec<TileCoordinate>. */
+uint64_t bt_tc_encode(const bt_tile_coordinate* tiles, uint32_t count, uint8_t* out, uint64_t cap);
+int64_t bt_tc_decode(const uint8_t* data, uint64_t bytes, bt_tile_coordinate* tiles, uint32_t cap);
+
+/* AttachmentData::generate_mipmaps (terrain_data/mod.rs:143-219) on the GPU.
+ * Single tile, host in/out: `out` receives all levels concatenated (level 0 first). */
+bt_status bt_generate_mipmaps(bt_ctx* ctx, uint32_t format, uint32_t texture_size, uint32_t mip_level_count,
+                              const void* level0_host, void* out_host, uint64_t out_bytes);
+/* Whole atlas: builds mip levels 1.. of `count` layers starting at `first_layer` into the atlas's mip
+ * storage (GpuAtlasAttachment::new allocates mip_level_count levels, gpu_tile_atlas.rs:195-237). */
+bt_status bt_atlas_generate_mipmaps(bt_atlas* atlas, uint32_t attachment_index, uint32_t first_layer, uint32_t count);
+bt_status bt_atlas_mip_storage(const bt_atlas* atlas, uint32_t attachment_index, uint32_t mip_level,
+                               void** device_ptr, uint64_t* tile_bytes);
+
+/* ------------------------------- Preprocessor (preprocess/preprocessor.rs) */
+bt_status bt_preprocessor_create(bt_ctx* ctx, bt_preprocessor** out); /* Preprocessor::new :224-232 */
+void bt_preprocessor_destroy(bt_preprocessor* p);
+/* clear_attachment (:290-296): existing_tiles.clear(); if `directory` is non-NULL also reset_directory
+ * (:18-22): remove "{directory}/../../config.tc", rm -r + mkdir -p the directory. */
+bt_status bt_preprocessor_clear_attachment(bt_preprocessor* p, bt_atlas* atlas, uint32_t attachment_index,
+                                           const char* directory);
+/* preprocess_tile (:298-312) / preprocess_spherical (:314-343): build the task queue and assign atlas
+ * indices in the reference's order. Nothing runs on the GPU yet. */
+bt_status bt_preprocessor_preprocess_tile(bt_preprocessor* p, bt_atlas* atlas, const bt_preprocess_dataset* dataset,
+                                          const bt_raster* source);
+bt_status bt_preprocessor_preprocess_spherical(bt_preprocessor* p, bt_atlas* atlas, const bt_spherical_dataset* dataset,
+                                               const bt_raster sources[6]);
+/* queued task counts in the order split, stitch, downsample, save, barrier (PreprocessTaskType :68-82) */
+uint32_t bt_preprocessor_task_counts(const bt_preprocessor* p, uint32_t counts[5]);
+
+enum {
+    BT_RUN_AUTO = 0,    /* fused split+pyramid kernels where the job qualifies, else reference-shaped */
+    BT_RUN_GENERIC = 1, /* one batched launch per queue phase: split / downsample / stitch */
+    BT_RUN_KEEP_QUEUE = 2, /* do not clear the queue (benchmarks re-run the same queue) */
+    BT_RUN_PROFILE = 4,    /* record a hipEvent after every launch; read with bt_preprocessor_profile() */
+};
+/* Replaces select_ready_tasks + GpuPreprocessor::prepare + TerrainPreprocessNode::run for the whole
+ * queue: enqueues every kernel on the context's stream and returns (asynchronous).  Save tasks are
+ * remembered; bt_preprocessor_save() writes their files. */
+bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* atlas, uint32_t flags);
+/* Executes the pending Save tasks: "{assets_root}/{config.path}/data/{name}/{coord}.bin" and, like
+ * select_ready_tasks on completion (:358-371), "{assets_root}/{config.path}/config.tc". */
+bt_status bt_preprocessor_save(bt_preprocessor* p, bt_atlas* atlas, const char* assets_root);
+/* Launch statistics of the last bt_preprocessor_run: kernels launched, algorithmic bytes
+ * (source texels read once + tile texels written once), tiles produced. */
+typedef struct bt_run_stats {
+    uint32_t kernel_launches;
+    uint32_t tiles;
+    uint64_t algorithmic_bytes;
+    uint32_t fused_jobs, generic_jobs;
+} bt_run_stats;
+bt_status bt_preprocessor_last_run_stats(const bt_preprocessor* p, bt_run_stats* out);
+/* Per-launch device time of the runs made with BT_RUN_PROFILE since the last call (hipEvents on the
+ * context's stream, averaged over those runs).  `kind`: 0 split, 1 downsample, 2 stitch, 3 fused main,
+ * 4 fused tail.  `algorithmic_bytes`: that launch's inputs read once + outputs written once.
+ * Synchronises the stream.  Returns the number of launches per run through *count. */
+typedef struct bt_launch_profile {
+    uint32_t kind;
+    uint32_t tasks;
+    uint64_t algorithmic_bytes;
+    float avg_ms;
+    uint32_t samples;
+} bt_launch_profile;
+bt_status bt_preprocessor_profile(bt_preprocessor* p, bt_launch_profile* out, uint32_t cap, uint32_t* count);
+
+/* ---------------- tiling prepass (render/tiling_prepass.rs, shaders/tiling_prepass) */
+/* SideParameter fields the prepass reads (math/terrain_model.rs:228-233; named view_xy/view_uv in
+ * types.wgsl:78-80). */
+typedef struct bt_side_parameter {
+    int32_t view_xy[2];
+    float view_uv[2];
+} bt_side_parameter;
+
+/* Everything `refine_tiles` reads each frame. */
+typedef struct bt_view_state {
+    uint32_t spherical;                  /* SPHERICAL shader def (tiling_prepass.rs:61-78) */
+    uint32_t geometry_tile_count;        /* TerrainViewConfigUniform (terrain_view_bind_group.rs:81-116) */
+    uint32_t refinement_count;
+    uint32_t vertices_per_tile;
+    float subdivision_distance;
+    uint32_t origin_lod;                 /* TerrainModelApproximation (terrain_model.rs:252-259) */
+    float approximate_height;
+    bt_side_parameter sides[6];
+    float world_position[3];             /* CullingUniform.world_position (culling_bind_group.rs:41-55) */
+    float world_from_local[12];          /* mesh[0].world_from_local: 3x3 columns then translation */
+    float local_from_world_transpose[9]; /* mesh[0].local_from_world_transpose_{a,b}: 3x3 columns */
+} bt_view_state;
+
+/* Indirect (terrain_view_bind_group.rs:65-71) as prepare_render leaves it. */
+typedef struct bt_indirect {
+    uint32_t vertex_count, instance_count, base_vertex, base_instance;
+} bt_indirect;
+
+/* TerrainViewData::new (:130-142): final_tiles + temporary_tiles of `geometry_tile_count` entries. */
+bt_status bt_tiling_prepass_create(bt_ctx* ctx, uint32_t geometry_tile_count, bt_tiling_prepass** out);
+void bt_tiling_prepass_destroy(bt_tiling_prepass* t);
+/* TilingPrepassNode::run (:204-272): prepare_root, refinement_count x (refine_tiles, prepare_next),
+ * refine_tiles, prepare_render — as ONE persistent launch.  Asynchronous on the context's stream. */
+bt_status bt_tiling_prepass_run(bt_tiling_prepass* t, const bt_view_state* view);
+/* Device buffers a renderer binds: final_tiles (bt_tile_coordinate[]), indirect args, counters. */
+bt_status bt_tiling_prepass_buffers(const bt_tiling_prepass* t, void** final_tiles_device, void** indirect_device);
+/* Synchronises and copies the final tile list (in the reference's sequential append order). */
+bt_status bt_tiling_prepass_read(bt_tiling_prepass* t, bt_tile_coordinate* final_tiles_host, uint32_t cap,
+                                 uint32_t* count, bt_indirect* indirect);
+
+/* ---------------------------------------------------------------- synthetic inputs */
+/* Deterministic integer fBm heightmap in [1, 65535] written straight into HBM (bench / tests: the
+ * reference's Gaia and GEBCO source rasters are not in its checkout).  The window
+ * (x0, y0, width, height) of the infinite field is produced, so shards can generate only their part. */
+bt_status bt_synth_fbm_r16(bt_ctx* ctx, void* dst_device, uint32_t width, uint32_t height, uint64_t row_pitch,
+                           uint32_t x0, uint32_t y0, uint32_t base_cell, uint32_t octaves, uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEVY_TERRAIN_AMD_H */

@@ -1,0 +1,171 @@
+"""Parity of the HIP preprocess path (through the C ABI) against the CPU oracle: bit-exact tiles."""
+import os
+
+import numpy as np
+import pytest
+
+import _cases as K
+import _model as M
+import _oracle as O
+import bevy_terrain_amd as bt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def device():
+    d = bt.Device(0)
+    yield d
+
+
+@pytest.mark.parametrize("generic", [True, False])
+@pytest.mark.parametrize("fmt", [O.FORMAT_R16, O.FORMAT_RGBA8])
+@pytest.mark.parametrize("T,b,lod_count,W,H", [(16, 2, 3, 53, 56), (12, 1, 2, 40, 40), (64, 2, 3, 300, 257), (20, 4, 3, 97, 97)])
+def test_planar_random_with_holes(device, generic, fmt, T, b, lod_count, W, H):
+    src = K.random_raster(fmt, H, W, seed=T * 1000 + W, holes=0.03)
+    atlas, _ = K.product_planar(device, src, lod_count, T, b, fmt, generic=generic)
+    oracle = K.oracle_planar(src, lod_count, T, b, fmt)
+    assert K.assert_atlas_equal(atlas, oracle) == sum(4 ** l for l in range(lod_count))
+
+
+@pytest.mark.parametrize("generic", [True, False])
+def test_planar_reference_tile_shape_512(device, generic):
+    # the reference's tile shape (T=512, b=2) on a 2k raster, lod_count 3 -> 21 tiles
+    src = K.smooth_raster(2048, 2048, seed=1234)
+    src[100:140, 900:1000] = 0
+    atlas, pre = K.product_planar(device, src, 3, 512, 2, O.FORMAT_R16, generic=generic)
+    oracle = K.oracle_planar(src, 3, 512, 2, O.FORMAT_R16)
+    assert K.assert_atlas_equal(atlas, oracle) == 21
+    st = pre.stats()
+    assert st["tiles"] == 21 and st["algorithmic_bytes"] == 2048 * 2048 * 2 + 21 * 512 * 512 * 2
+
+
+def test_config2_planar_4k_height_and_albedo(device):
+    """BASELINE config 2: 4096^2 height (R16) + albedo (Rgba8), lod_count 4, 85 tiles each, bit-compare."""
+    height = K.smooth_raster(4096, 4096, seed=1234)
+    rng = np.random.default_rng(1235)
+    albedo = rng.integers(1, 256, size=(4096, 4096, 4), dtype=np.uint8)
+    albedo[..., 3] = 255
+    cfg = bt.TerrainConfig(lod_count=4, path="terrains/planar", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=512, border_size=2, format=bt.AttachmentFormat.R16))
+    cfg.add_attachment(bt.AttachmentConfig(name="albedo", texture_size=512, border_size=2, format=bt.AttachmentFormat.Rgba8))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer().insert("terrains/planar/source/height.png", height).insert("terrains/planar/source/albedo.png", albedo)
+    pre = (bt.Preprocessor.new().clear_attachment(0, atlas).clear_attachment(1, atlas)
+           .preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="terrains/planar/source/height.png", lod_range=range(0, 4)), server, atlas)
+           .preprocess_tile(bt.PreprocessDataset(attachment_index=1, path="terrains/planar/source/albedo.png", lod_range=range(0, 4)), server, atlas))
+    assert pre.task_counts() == {"split": 128, "stitch": 170, "downsample": 42, "save": 170, "barrier": 16}
+    pre.run(atlas)
+    oracle = O.OracleAtlas(4, 1024, False, [(512, 2, 1, O.FORMAT_R16), (512, 2, 1, O.FORMAT_RGBA8)])
+    oracle.clear_attachment(0).clear_attachment(1)
+    oracle.preprocess_tile(0, height, (0, 4)).preprocess_tile(1, albedo, (0, 4)).run(8)
+    assert K.assert_atlas_equal(atlas, oracle, 0) == 85
+    assert K.assert_atlas_equal(atlas, oracle, 1) == 85
+
+
+@pytest.mark.parametrize("generic", [True, False])
+def test_dataset_subrect(device, generic):
+    src = K.random_raster(O.FORMAT_R16, 80, 90, seed=9)
+    ds = dict(top_left=(0.25, 0.0), bottom_right=(0.75, 0.5))
+    atlas, _ = K.product_planar(device, src, 3, 16, 2, O.FORMAT_R16, generic=generic, **ds)
+    oracle = K.oracle_planar(src, 3, 16, 2, O.FORMAT_R16, **ds)
+    assert K.assert_atlas_equal(atlas, oracle) > 0
+
+
+@pytest.mark.parametrize("generic", [True, False])
+def test_overlay_keeps_previous_where_nodata(device, generic):
+    T, b = 32, 2
+    base = K.random_raster(O.FORMAT_R16, 100, 100, seed=1)
+    over = K.random_raster(O.FORMAT_R16, 64, 64, seed=2, holes=0.3)
+    cfg = bt.TerrainConfig(lod_count=2, atlas_size=16, path="t", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=T, border_size=b))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer().insert("base", base).insert("over", over)
+    pre = bt.Preprocessor.new()
+    pre.preprocess_tile(bt.PreprocessDataset(path="base", lod_range=range(0, 2)), server, atlas).run(atlas, generic=generic)
+    pre.preprocess_tile(bt.PreprocessDataset(path="over", lod_range=range(0, 2)), server, atlas).run(atlas, generic=generic)
+    oracle = O.OracleAtlas(2, 16, False, [(T, b, 1, O.FORMAT_R16)])
+    oracle.preprocess_tile(0, base, (0, 2)).run()
+    oracle.preprocess_tile(0, over, (0, 2)).run()
+    assert K.assert_atlas_equal(atlas, oracle) == 5
+
+
+@pytest.mark.parametrize("generic", [True, False])
+@pytest.mark.parametrize("fmt", [O.FORMAT_R16, O.FORMAT_RGBA8])
+def test_spherical_cube_faces(device, generic, fmt):
+    T, b, lod_count, W = 32, 2, 3, 100
+    faces = [K.random_raster(fmt, W, W, seed=70 + s, holes=0.02) for s in range(6)]
+    cfg = bt.TerrainConfig(lod_count=lod_count, atlas_size=256, path="terrains/spherical")
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=T, border_size=b, format=K.FMT[fmt]))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer()
+    paths = [f"face{s}" for s in range(6)]
+    for p, f in zip(paths, faces):
+        server.insert(p, f)
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_spherical(
+        bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lod_count)), server, atlas)
+    pre.run(atlas, generic=generic)
+    oracle = O.OracleAtlas(lod_count, 256, True, [(T, b, 1, fmt)])
+    oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lod_count)).run(8)
+    assert K.assert_atlas_equal(atlas, oracle) == 6 * 21
+
+
+def test_atlas_out_of_indices_is_an_error_not_a_panic(device):
+    src = K.random_raster(O.FORMAT_R16, 64, 64, seed=3)
+    with pytest.raises(bt._ffi.BtError) as e:
+        K.product_planar(device, src, 3, 16, 2, O.FORMAT_R16, atlas_size=20)
+    assert e.value.status == -2
+
+
+def test_unsupported_formats_are_rejected(device):
+    cfg = bt.TerrainConfig(lod_count=1, atlas_size=4, path="t", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="n", texture_size=16, border_size=1, format=bt.AttachmentFormat.Rg16))
+    atlas = bt.TileAtlas.new(cfg, device)
+    with pytest.raises(Exception):
+        bt.Preprocessor.new().preprocess_tile(bt.PreprocessDataset(path="x"), bt.AssetServer().insert("x", np.zeros((8, 8), np.uint16)), atlas)
+
+
+@pytest.mark.parametrize("fmt", [O.FORMAT_R16, O.FORMAT_RGBA8])
+def test_generate_mipmaps_exact(device, fmt):
+    T = 64
+    level0 = K.random_raster(fmt, T, T, seed=11, holes=0.2 if fmt == O.FORMAT_R16 else 0.0)
+    ours = bt.generate_mipmaps(device, K.FMT[fmt], level0, 5)
+    assert np.array_equal(ours, O.generate_mipmaps(fmt, level0, 5))
+
+
+def test_atlas_mip_chain_and_files(device, tmp_path):
+    src = K.random_raster(O.FORMAT_R16, 200, 200, seed=21, holes=0.05)
+    atlas, pre = K.product_planar(device, src, 3, 32, 2, O.FORMAT_R16, mips=4)
+    oracle = K.oracle_planar(src, 3, 32, 2, O.FORMAT_R16)
+    atlas.generate_mipmaps(0, 0, 21)
+    for (coord, idx) in oracle.tiles()[::5]:
+        chain = O.generate_mipmaps(O.FORMAT_R16, oracle.tile(0, idx), 4)
+        off = 32 * 32
+        for mip in (1, 2, 3):
+            s = 32 >> mip
+            assert np.array_equal(atlas.download_mip(0, mip, idx).ravel(), chain[off:off + s * s]), (coord, mip)
+            off += s * s
+    # files: "{root}/{path}/data/{name}/{side}_{lod}_{x}_{y}.bin" + config.tc, byte-identical to the oracle's
+    root = str(tmp_path / "assets")
+    pre.save(atlas, root)
+    d = os.path.join(root, "terrains/test/data/att")
+    odir = str(tmp_path / "oracle")
+    os.makedirs(odir)
+    oracle.save_attachment(0, odir)
+    names = sorted(os.listdir(d))
+    assert names == sorted(os.listdir(odir)) and len(names) == 21 and "0_2_3_1.bin" in names
+    for n in names:
+        assert open(os.path.join(d, n), "rb").read() == open(os.path.join(odir, n), "rb").read()
+    tc = open(os.path.join(root, "terrains/test/config.tc"), "rb").read()
+    assert sorted((t.side, t.lod, t.x, t.y) for t in bt.tc_decode(tc)) == sorted(c for c, _ in oracle.tiles())
+    assert set(O.tc_decode(tc)) == {c for c, _ in oracle.tiles()}
+
+
+def test_synth_fbm_matches_integer_model(device):
+    w, h = 300, 200
+    ptr = device.synth_fbm_r16(w, h, seed=42, x0=1000, y0=77, base_cell=64)
+    ours = device.download(ptr, (h, w), np.uint16)
+    device.free(ptr)
+    exp = M.fbm_u16(w, h, 42, x0=1000, y0=77, base_cell=64)
+    assert np.array_equal(ours, exp)
+    assert ours.min() >= 1

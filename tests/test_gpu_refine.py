@@ -1,0 +1,105 @@
+"""Tiling prepass: HIP persistent kernel vs the oracle's sequential run — identical final tile LIST."""
+import math
+
+import numpy as np
+import pytest
+
+import _oracle as O
+import bevy_terrain_amd as bt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def device():
+    return bt.Device(0)
+
+
+def oracle_view(v):
+    return O.make_view(spherical=v.spherical, tile_count=v.geometry_tile_count, refinement_count=v.refinement_count,
+                       vertices_per_tile=v.vertices_per_tile, subdivision_distance=v.subdivision_distance,
+                       origin_lod=v.origin_lod, approximate_height=v.approximate_height,
+                       sides=[((s.view_xy[0], s.view_xy[1]), (s.view_uv[0], s.view_uv[1])) for s in v.sides],
+                       world_position=list(v.world_position), world_from_local=list(v.world_from_local),
+                       local_from_world_transpose=list(v.local_from_world_transpose))
+
+
+def spiral(n, radius, h0, h1, seed=99):
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        t = i / max(n - 1, 1)
+        a = 2 * math.pi * 3 * t + rng.random() * 0.01
+        r = radius * (1 - 0.9 * t)
+        yield (r * math.cos(a), h0 + (h1 - h0) * t, r * math.sin(a))
+
+
+def check_quadtree(tiles, roots):
+    # final tiles are pairwise disjoint (no tile is an ancestor of another)
+    s = {tuple(t) for t in tiles.tolist()}
+    assert len(s) == len(tiles)
+    for side, lod, x, y in s:
+        l, xx, yy = lod, x, y
+        while l > 0:
+            l, xx, yy = l - 1, xx >> 1, yy >> 1
+            assert (side, l, xx, yy) not in s
+
+
+def test_planar_camera_path(device):
+    model = bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 250.0)  # examples/minimal.rs
+    cfg = bt.TerrainViewConfig(geometry_tile_count=200000)
+    prepass = bt.TilingPrepass(device, cfg.geometry_tile_count)
+    total = 0
+    for pos in spiral(24, 700.0, 900.0, 130.0):
+        v = bt.make_view_state(model, cfg, pos)
+        prepass.run(v)
+        ours, indirect = prepass.read()
+        exp, exp_indirect, _ = O.refine(oracle_view(v))
+        assert np.array_equal(ours, exp), pos
+        assert list(indirect) == exp_indirect
+        check_quadtree(ours, 1)
+        total += len(ours)
+    assert total > 24 * 10
+
+
+def test_spherical_camera_path(device):
+    model = bt.TerrainModel.sphere((0.0, 0.0, 0.0), 6371000.0, -12000.0, 9000.0)
+    cfg = bt.TerrainViewConfig(geometry_tile_count=300000)
+    prepass = bt.TilingPrepass(device, cfg.geometry_tile_count)
+    counts = []
+    for i, (x, h, z) in enumerate(spiral(16, 1.0, 4.0e6, 2.0e3)):
+        d = np.array([0.3 + x, 0.9, 0.2 + z])
+        d = d / np.linalg.norm(d)
+        pos = tuple(d * (6371000.0 + h))
+        v = bt.make_view_state(model, cfg, pos)
+        prepass.run(v)
+        ours, indirect = prepass.read()
+        exp, exp_indirect, passes = O.refine(oracle_view(v))
+        assert np.array_equal(ours, exp), (i, pos)
+        assert list(indirect) == exp_indirect
+        check_quadtree(ours, 6)
+        counts.append(len(ours))
+    assert max(counts) > 300 and min(counts) >= 6
+
+
+def test_refinement_count_limits_depth_and_drops_dividing_tiles(device):
+    model = bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 0.0)
+    cfg = bt.TerrainViewConfig(geometry_tile_count=100000, refinement_count=3)
+    v = bt.make_view_state(model, cfg, (10.0, 5.0, 10.0))
+    prepass = bt.TilingPrepass(device, cfg.geometry_tile_count)
+    prepass.run(v)
+    ours, _ = prepass.read()
+    exp, _, passes = O.refine(oracle_view(v))
+    assert np.array_equal(ours, exp)
+    assert ours[:, 1].max() <= 3  # lods 0..refinement_count only
+    assert len(ours) < sum(passes)  # the still-dividing lod-3 tiles were dropped
+
+
+def test_overflow_is_reported(device):
+    model = bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 0.0)
+    cfg = bt.TerrainViewConfig(geometry_tile_count=64)
+    v = bt.make_view_state(model, cfg, (0.0, 1.0, 0.0))
+    prepass = bt.TilingPrepass(device, 64)
+    prepass.run(v)
+    with pytest.raises(bt._ffi.BtError) as e:
+        prepass.read()
+    assert e.value.status == -7
