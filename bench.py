@@ -33,13 +33,13 @@ def cpu_baseline(device, src_ptr):
 
     import _oracle as O
 
-    sample, lods = 4096, 4
+    sample, lods = 8192, 5
     window = np.empty((sample, sample), dtype=np.uint16)
     rows = device.download(src_ptr, (sample, SIZE), np.uint16)  # first `sample` rows, all columns
     window[:] = rows[:, :sample]
     del rows
     cores = os.cpu_count() or 1
-    a = O.OracleAtlas(lods, 128, False, [(TEXTURE_SIZE, BORDER, 1, O.FORMAT_R16)])
+    a = O.OracleAtlas(lods, 512, False, [(TEXTURE_SIZE, BORDER, 1, O.FORMAT_R16)])
     a.preprocess_tile(0, window, (0, lods))
     t0 = time.perf_counter()
     a.run(cores)

@@ -22,7 +22,14 @@ def random_raster(fmt, h, w, seed, holes=0.0):
     return src
 
 
-def smooth_raster(h, w, seed):
+def smooth_raster(h, w, seed, device=None):
+    """fBm heightmap in [1, 65535]; large sizes come from the HIP generator (which the GPU tests check
+    against the integer numpy model), small ones from the model itself."""
+    if device is not None:
+        ptr = device.synth_fbm_r16(w, h, seed)
+        out = device.download(ptr, (h, w), np.uint16)
+        device.free(ptr)
+        return out
     import _model as M
     return M.fbm_u16(w, h, seed)
 

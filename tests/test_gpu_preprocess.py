@@ -31,7 +31,7 @@ def test_planar_random_with_holes(device, generic, fmt, T, b, lod_count, W, H):
 @pytest.mark.parametrize("generic", [True, False])
 def test_planar_reference_tile_shape_512(device, generic):
     # the reference's tile shape (T=512, b=2) on a 2k raster, lod_count 3 -> 21 tiles
-    src = K.smooth_raster(2048, 2048, seed=1234)
+    src = K.smooth_raster(2048, 2048, seed=1234, device=device)
     src[100:140, 900:1000] = 0
     atlas, pre = K.product_planar(device, src, 3, 512, 2, O.FORMAT_R16, generic=generic)
     oracle = K.oracle_planar(src, 3, 512, 2, O.FORMAT_R16)
@@ -42,7 +42,7 @@ def test_planar_reference_tile_shape_512(device, generic):
 
 def test_config2_planar_4k_height_and_albedo(device):
     """BASELINE config 2: 4096^2 height (R16) + albedo (Rgba8), lod_count 4, 85 tiles each, bit-compare."""
-    height = K.smooth_raster(4096, 4096, seed=1234)
+    height = K.smooth_raster(4096, 4096, seed=1234, device=device)
     rng = np.random.default_rng(1235)
     albedo = rng.integers(1, 256, size=(4096, 4096, 4), dtype=np.uint8)
     albedo[..., 3] = 255
