@@ -27,27 +27,48 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
 
 
 def cpu_baseline(device, src_ptr):
-    """The CPU oracle (a port: the reference has no CPU path and cannot be built here) timed on a bounded
-    sample of the same workload: the top-left 4096^2 window of the same heightmap, lod_count 4, 85 tiles."""
+    """The CPU oracle (a port: the reference has no CPU path and cannot be built here) timed on the host
+    cores.  With >= 32 cores the whole 16k workload is run (about 10 s); on smaller hosts a bounded sample:
+    the top-left 8192^2 window of the same heightmap with lod_count 5 (341 tiles)."""
     import numpy as np
 
     import _oracle as O
 
-    sample, lods = 8192, 5
-    window = np.empty((sample, sample), dtype=np.uint16)
-    rows = device.download(src_ptr, (sample, SIZE), np.uint16)  # first `sample` rows, all columns
-    window[:] = rows[:, :sample]
-    del rows
     cores = os.cpu_count() or 1
-    a = O.OracleAtlas(lods, 512, False, [(TEXTURE_SIZE, BORDER, 1, O.FORMAT_R16)])
+    sample, lods = (SIZE, LOD_COUNT) if cores >= 32 else (8192, 5)
+    rows = device.download(src_ptr, (sample, SIZE), np.uint16)  # first `sample` rows, all columns
+    window = np.ascontiguousarray(rows[:, :sample])
+    del rows
+    a = O.OracleAtlas(lods, ATLAS_SIZE, False, [(TEXTURE_SIZE, BORDER, 1, O.FORMAT_R16)])
     a.preprocess_tile(0, window, (0, lods))
     t0 = time.perf_counter()
     a.run(cores)
     dt = time.perf_counter() - t0
     tiles = len(a.tiles())
+    what = "the whole workload" if sample == SIZE else f"the top-left {sample}x{sample} window of the same heightmap"
     return {"value": tiles / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/bt_oracle.c (OpenMP) on the top-left {sample}x{sample} window of the same heightmap, "
-                      f"lod_count {lods}, {tiles} tiles of 512^2 in {dt:.2f} s"}, window, a
+            "sample": f"oracle/bt_oracle.c (OpenMP over the tasks of a phase) on {what}, lod_count {lods}: "
+                      f"{tiles} tiles of 512^2 in {dt:.2f} s"}, a, (sample, lods)
+
+
+def verify_against(atlas, oracle, shape):
+    """Byte-compare the GPU atlas with the oracle's (same coordinates at the same atlas indices)."""
+    import numpy as np
+
+    sample, lods = shape
+    if sample != SIZE:
+        return None  # the oracle ran on a window: tile contents differ by construction
+    ours = [((c.side, c.lod, c.x, c.y), i) for c, i in atlas.tiles()]
+    theirs = oracle.tiles()
+    if ours != theirs:
+        return {"tiles": len(theirs), "identical": 0, "index_contract": False}
+    identical = 0
+    for first in range(0, len(theirs), 128):
+        count = min(128, len(theirs) - first)
+        data = atlas.download_tiles(0, first, count)
+        for k in range(count):
+            identical += int(np.array_equal(data[k], oracle.tile(0, first + k)))
+    return {"tiles": len(theirs), "identical": identical, "index_contract": True}
 
 
 def main():
@@ -57,6 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--generic", action="store_true", help="force the reference-shaped batched kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="byte-compare all tiles with the oracle run of cpu_baseline")
     args = ap.parse_args()
 
     import torch
@@ -103,15 +125,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the context launches on device.torch_stream; the events are recorded on that same stream
+    stream = device.torch_stream
     for _ in range(args.warmup):
         step()
     fence()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    start.record()
+    start.record(stream)
     for _ in range(args.steps):
         step(profile=True)
-    stop.record()
+    stop.record(stream)
     fence()
     wall_ms = (time.perf_counter() - t0) * 1e3
     ms = start.elapsed_time(stop)
@@ -154,7 +178,9 @@ def main():
                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                             "avg_launch_ms": dominant["avg_ms"], "algorithmic_bytes_per_launch": dominant["algorithmic_bytes"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"], window, oracle = cpu_baseline(device, src_ptr)
+        line["cpu_baseline"], oracle, shape = cpu_baseline(device, src_ptr)
+        if args.verify:
+            line["verify_vs_oracle"] = verify_against(atlas, oracle, shape)
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

@@ -592,6 +592,7 @@ void bt_preprocessor_destroy(bt_preprocessor* p) {
     if (!p) return;
     hipSetDevice(p->ctx->device);
     release_rasters(p);
+    fused_release(p);
     for (hipEvent_t e : p->events) hipEventDestroy(e);
     if (p->tasks_dev) hipFree(p->tasks_dev);
     if (p->rasters_dev) hipFree(p->rasters_dev);

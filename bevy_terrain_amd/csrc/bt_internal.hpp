@@ -13,6 +13,8 @@
 
 #include "bevy_terrain_amd.h"
 
+struct bt_preprocessor;
+
 namespace bt {
 
 void set_error(const char* fmt, ...);
@@ -144,6 +146,9 @@ bt_status launch_mip_level(bt_ctx* ctx, uint32_t format, const void* parent, voi
                            uint32_t layers);
 bt_status launch_synth_fbm(bt_ctx* ctx, void* dst, uint32_t w, uint32_t h, uint64_t pitch, uint32_t x0, uint32_t y0,
                            uint32_t base_cell, uint32_t octaves, uint32_t seed);
+
+// fused-path device buffers of a preprocessor (bt_fused.hip)
+void fused_release(struct ::bt_preprocessor* p);
 
 // coordinate math (bt_host.cpp)
 void tile_children(bt_tile_coordinate c, bt_tile_coordinate out[4]);

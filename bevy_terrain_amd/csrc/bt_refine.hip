@@ -198,8 +198,9 @@ __global__ __launch_bounds__(kThreads) void tiling_prepass_kernel(bt_view_state 
                 if (children_so_far + int(tile_count) > N || s_final_index > N) s_overflow = 1;
             }
             __syncthreads();
+            if (s_overflow) break;  // uniform: the buffers are too small, stop before indices run wild
         }
-        if (pass == view.refinement_count) break;
+        if (s_overflow || pass == view.refinement_count) break;
         // prepare_next (prepare_prepass.wgsl:25-36)
         if (tid == 0) {
             if (s_counter == 1) {

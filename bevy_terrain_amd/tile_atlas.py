@@ -17,13 +17,17 @@ class Device:
 
     def __init__(self, index: int = 0, stream: Optional[int] = None):
         L = _ffi.lib()
+        self.torch_stream = None
         if stream is None:
             try:
                 import torch
 
                 if torch.cuda.is_available():
+                    # a dedicated torch stream: kernels, torch.cuda.Event timing and torch.distributed
+                    # collectives issued under `with torch.cuda.stream(device.torch_stream)` share one queue
                     torch.cuda.set_device(index)
-                    stream = torch.cuda.current_stream(index).cuda_stream or None
+                    self.torch_stream = torch.cuda.Stream(device=index)
+                    stream = self.torch_stream.cuda_stream
             except ImportError:
                 stream = None
         h = C.c_void_p()

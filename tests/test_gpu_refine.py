@@ -83,7 +83,7 @@ def test_spherical_camera_path(device):
 
 def test_refinement_count_limits_depth_and_drops_dividing_tiles(device):
     model = bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 0.0)
-    cfg = bt.TerrainViewConfig(geometry_tile_count=100000, refinement_count=3)
+    cfg = bt.TerrainViewConfig(geometry_tile_count=100000, refinement_count=3, morph_distance=1.0)
     v = bt.make_view_state(model, cfg, (10.0, 5.0, 10.0))
     prepass = bt.TilingPrepass(device, cfg.geometry_tile_count)
     prepass.run(v)
