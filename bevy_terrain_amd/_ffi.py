@@ -137,6 +137,7 @@ PROTOTYPES = {
     "bt_tiling_prepass_run": (_i32, [_vp, _P(ViewStateC)]),
     "bt_tiling_prepass_buffers": (_i32, [_vp, _P(_vp), _P(_vp)]),
     "bt_tiling_prepass_read": (_i32, [_vp, _P(TileCoordinateC), _u32, _P(_u32), _P(IndirectC)]),
+    "bt_selftest": (_i32, [_vp, _P(_u32)]),
     "bt_synth_fbm_r16": (_i32, [_vp, _vp, _u32, _u32, _u64, _u32, _u32, _u32, _u32, _u32]),
 }
 

@@ -8,16 +8,22 @@
 // 2x2 child-mosaic pixels below it (downsample.wgsl:18-20, child_size = c/2).  So nothing needs the
 // reference's write-section copies, per-tile dispatches or phase barriers.
 //
-//   fused_main : one workgroup = 32 centre rows of one finest-LOD tile.  Streams the source raster once,
-//                writes complete, already stitched 1024-byte tile rows of the finest LOD (aprons are pulled:
-//                evaluated with the neighbour tile's own formula, so they are bit-identical to its centre),
-//                and reduces in registers / across lane pairs to the next two LODs, which it *pushes* into
-//                the parent and grand-parent tiles including the aprons of their neighbours.
+//   fused_main : one workgroup = 32 centre rows of one finest-LOD tile (+ the apron rows at the tile's
+//                top / bottom).  The source rows it needs are staged once into LDS with 16-byte loads
+//                (one 1 KiB wave-instruction per source row), every thread owns one pair of texture
+//                columns and walks down the rows: complete, already stitched 1024-byte tile rows of the
+//                finest LOD leave as one coalesced store per wave (aprons are *pulled*: evaluated with the
+//                neighbour tile's own formula, hence bit-identical to its centre); row pairs reduce in
+//                registers and lane pairs via DPP to the next two LODs, which are *pushed* into the parent
+//                and grand-parent tiles including the aprons of their neighbours.
 //   fused_tail : the remaining (tiny) LODs, three at a time, from the atlas: 32x32 mosaic pixels per
 //                workgroup, LDS hand-off between levels, same push.
 //   cube seams : tiles on a cube-face edge get their aprons from the generic stitch kernel afterwards.
 //
-// Arithmetic contract: identical to bt_kernels.hip / oracle (IEEE binary32, -ffp-contract=off).
+// Arithmetic contract: identical to bt_kernels.hip / oracle (IEEE binary32, -ffp-contract=off).  The one
+// liberty: t / 65535.0f is evaluated as q0 = t*r, e = fma(-q0, 65535, t), q = fma(e, r, q0) with
+// r = RN(1/65535) (Markstein's correctly rounded division); equality with `/` for all 65536 inputs is
+// checked on the device by bt_selftest() and on the CPU by tests/test_oracle_preprocess.py.
 #include "bt_internal.hpp"
 
 namespace bt {
@@ -25,7 +31,10 @@ namespace bt {
 namespace {
 
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
-constexpr uint32_t kMainRows = 32;  // centre rows per fused_main workgroup (multiple of 4)
+constexpr uint32_t kMainRows = 16;               // centre rows per fused_main workgroup (multiple of 4)
+constexpr uint32_t kMaxBorder = 8;
+constexpr uint32_t kRowTable = kMainRows + 2 * kMaxBorder;  // texture rows a workgroup can own
+constexpr uint32_t kMaxSlots = 2 * kRowTable;                // staged source rows (worst case: 2 per row)
 
 struct MainItem {  // one finest-LOD tile
     uint32_t side, x, y, atlas_index, raster;
@@ -44,12 +53,23 @@ struct FusedArgs {
     uint32_t item_count;  // fused_main: tiles
     uint32_t groups;      // fused_main: row groups per tile
     uint32_t sides;       // fused_tail: 1 or 6
+    uint32_t lds_pitch;   // fused_main: texels per staged source row (multiple of 8)
+    uint32_t lds_rows;    // fused_main: staged source rows that fit
 };
 
-__device__ __forceinline__ float unorm16_to_float(uint32_t t) { return float(t) / 65535.0f; }
+// t / 65535.0f, correctly rounded, in 3 VALU ops (see header)
+__device__ __forceinline__ float unorm16_to_float(uint32_t t) {
+    const float x = float(t);
+    const float r = 1.0f / 65535.0f;
+    const float q0 = x * r;
+    const float e = __builtin_fmaf(-q0, 65535.0f, x);
+    return __builtin_fmaf(e, r, q0);
+}
+// floor(0.5 + 65535 * clamp(e, 0, 1)): med3 clamps (no NaN reaches here); the u32 conversion truncates,
+// which is floor for the non-negative argument
 __device__ __forceinline__ uint32_t float_to_unorm16(float e) {
-    const float cl = e < 0.0f ? 0.0f : (e > 1.0f ? 1.0f : e);
-    return uint32_t(floorf(0.5f + 65535.0f * cl));
+    const float cl = __builtin_amdgcn_fmed3f(e, 0.0f, 1.0f);
+    return uint32_t(0.5f + 65535.0f * cl);
 }
 __device__ __forceinline__ float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 
@@ -82,73 +102,80 @@ __device__ __forceinline__ uint32_t grid_lookup(const FusedArgs& A, uint32_t sid
     return A.grids[off + uint32_t(x) * uint32_t(n) + uint32_t(y)];
 }
 
-// A tile of some LOD together with its 8 same-face neighbours (region order of stitch.wgsl:57-66:
-// N, E, S, W, NW, NE, SE, SW).  Out-of-face neighbours are treated as absent here; on a cube the
-// face-edge tiles are re-stitched afterwards by the generic kernel.
+// A tile of some LOD together with its 8 same-face neighbours (stitch.wgsl:57-66 regions N, E, S, W, NW,
+// NE, SE, SW).  Out-of-face neighbours count as absent here; on a cube the face-edge tiles are re-stitched
+// afterwards by the generic kernel.  Named members: indexed arrays would be demoted to scratch / LDS.
 struct TileNb {
-    uint32_t self;
-    uint32_t nb[8];
+    uint32_t self, n, e, s, w;
 };
 
 __device__ __forceinline__ TileNb load_tile_nb(const FusedArgs& A, uint32_t side, uint32_t lod, uint32_t x, uint32_t y) {
-    constexpr int kOff[8][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}, {-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
+    const int ix = int(x), iy = int(y);
     TileNb t;
-    t.self = grid_lookup(A, side, lod, int(x), int(y));
-#pragma unroll
-    for (int r = 0; r < 8; r++) t.nb[r] = grid_lookup(A, side, lod, int(x) + kOff[r][0], int(y) + kOff[r][1]);
+    t.self = grid_lookup(A, side, lod, ix, iy);
+    t.n = grid_lookup(A, side, lod, ix, iy - 1);
+    t.e = grid_lookup(A, side, lod, ix + 1, iy);
+    t.s = grid_lookup(A, side, lod, ix, iy + 1);
+    t.w = grid_lookup(A, side, lod, ix - 1, iy);
     return t;
 }
 
-// Write centre pixel (cx, cy) of tile `t` and every apron texel that copies it (stitch.wgsl:53-118 inverted):
+// Write centre pixel (cx, cy) of tile (side, lod, tx, ty) — atlas layer `self_index` — and every apron
+// texel that copies it (stitch.wgsl:53-118 inverted):
 //  - the tile's own apron where the neighbour on that side is absent (repeat_data clamps into the centre),
 //  - the facing apron of each existing neighbour whose b-wide strip contains the pixel.
-__device__ __forceinline__ void push_pixel(uint16_t* __restrict__ atlas, const TileNb& t, uint32_t T, uint32_t b, uint32_t c,
-                                           uint32_t cx, uint32_t cy, uint16_t v) {
+// Neighbours are looked up only for the few pixels within b of a tile edge.
+__device__ __forceinline__ void push_pixel(const FusedArgs& A, uint32_t side, uint32_t lod, uint32_t tx, uint32_t ty,
+                                           uint32_t self_index, uint32_t cx, uint32_t cy, uint16_t v) {
+    const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
     const uint64_t tile_texels = uint64_t(T) * T;
-    uint16_t* self = atlas + uint64_t(t.self) * tile_texels;
+    uint16_t* atlas = A.atlas;
+    uint16_t* self = atlas + uint64_t(self_index) * tile_texels;
     self[uint64_t(b + cy) * T + b + cx] = v;
     const int ex = cx < b ? -1 : (cx >= c - b ? 1 : 0);
     const int ey = cy < b ? -1 : (cy >= c - b ? 1 : 0);
     if (ex == 0 && ey == 0) return;
     const uint32_t o = b + c;
-    // own aprons (absent neighbour): only the outermost centre row / column / corner pixel is replicated
-    const bool first_x = cx == 0, last_x = cx == c - 1, first_y = cy == 0, last_y = cy == c - 1;
-    if (first_x && t.nb[3] == kInvalid)
-        for (uint32_t j = 0; j < b; j++) self[uint64_t(b + cy) * T + j] = v;
-    if (last_x && t.nb[1] == kInvalid)
-        for (uint32_t j = 0; j < b; j++) self[uint64_t(b + cy) * T + o + j] = v;
-    if (first_y && t.nb[0] == kInvalid)
-        for (uint32_t j = 0; j < b; j++) self[uint64_t(j) * T + b + cx] = v;
-    if (last_y && t.nb[2] == kInvalid)
-        for (uint32_t j = 0; j < b; j++) self[uint64_t(o + j) * T + b + cx] = v;
-    if ((first_x || last_x) && (first_y || last_y)) {
-        const uint32_t region = first_y ? (first_x ? 4u : 5u) : (first_x ? 7u : 6u);
-        if (t.nb[region] == kInvalid) {
-            const uint32_t x0 = first_x ? 0u : o, y0 = first_y ? 0u : o;
+    const int ix = int(tx), iy = int(ty);
+    // a neighbour at offset (dx, dy) sees our centre (cx, cy) at texture (b + cx - dx*c, b + cy - dy*c)
+    const uint32_t ax = uint32_t(int(b + cx) - ex * int(c)), ay = uint32_t(int(b + cy) - ey * int(c));
+    if (ex != 0) {
+        const uint32_t n = grid_lookup(A, side, lod, ix + ex, iy);
+        if (n != kInvalid) {
+            atlas[uint64_t(n) * tile_texels + uint64_t(b + cy) * T + ax] = v;
+        } else if (cx == 0 || cx == c - 1) {  // absent: our outermost column is replicated into our own apron
+            const uint32_t x0 = ex < 0 ? 0u : o;
+            for (uint32_t j = 0; j < b; j++) self[uint64_t(b + cy) * T + x0 + j] = v;
+        }
+    }
+    if (ey != 0) {
+        const uint32_t n = grid_lookup(A, side, lod, ix, iy + ey);
+        if (n != kInvalid) {
+            atlas[uint64_t(n) * tile_texels + uint64_t(ay) * T + b + cx] = v;
+        } else if (cy == 0 || cy == c - 1) {
+            const uint32_t y0 = ey < 0 ? 0u : o;
+            for (uint32_t j = 0; j < b; j++) self[uint64_t(y0 + j) * T + b + cx] = v;
+        }
+    }
+    if (ex != 0 && ey != 0) {
+        const uint32_t n = grid_lookup(A, side, lod, ix + ex, iy + ey);
+        if (n != kInvalid) {
+            atlas[uint64_t(n) * tile_texels + uint64_t(ay) * T + ax] = v;
+        } else if ((cx == 0 || cx == c - 1) && (cy == 0 || cy == c - 1)) {  // corner region clamps both axes
+            const uint32_t x0 = ex < 0 ? 0u : o, y0 = ey < 0 ? 0u : o;
             for (uint32_t j = 0; j < b; j++)
                 for (uint32_t i = 0; i < b; i++) self[uint64_t(y0 + j) * T + x0 + i] = v;
         }
-    }
-    // neighbours' aprons: apron texel (px, py) of the neighbour at offset (dx, dy) copies our texel
-    // (px - dx*... ) i.e. our centre (cx, cy) lands at texture (b + cx - dx*c, b + cy - dy*c) of that neighbour
-    if (ex != 0) {
-        const uint32_t n = t.nb[ex < 0 ? 3 : 1];
-        if (n != kInvalid) atlas[uint64_t(n) * tile_texels + uint64_t(b + cy) * T + uint32_t(int(b + cx) - ex * int(c))] = v;
-    }
-    if (ey != 0) {
-        const uint32_t n = t.nb[ey < 0 ? 0 : 2];
-        if (n != kInvalid) atlas[uint64_t(n) * tile_texels + uint64_t(uint32_t(int(b + cy) - ey * int(c))) * T + b + cx] = v;
-    }
-    if (ex != 0 && ey != 0) {
-        const uint32_t region = ey < 0 ? (ex < 0 ? 4u : 5u) : (ex < 0 ? 7u : 6u);
-        const uint32_t n = t.nb[region];
-        if (n != kInvalid)
-            atlas[uint64_t(n) * tile_texels + uint64_t(uint32_t(int(b + cy) - ey * int(c))) * T + uint32_t(int(b + cx) - ex * int(c))] = v;
     }
 }
 
 // downsample.wgsl:25-39 on four texels in OFFSETS order (0,0),(0,1),(1,0),(1,1) of (dx, dy)
 __device__ __forceinline__ uint32_t downsample4(uint32_t t00, uint32_t t01, uint32_t t10, uint32_t t11) {
+    if (t00 != 0 && t01 != 0 && t10 != 0 && t11 != 0) {
+        // all four valid (the common case): ((((0 + a) + b) + c) + d) / 4, and x / 4 == x * 0.25 exactly
+        const float value = ((unorm16_to_float(t00) + unorm16_to_float(t01)) + unorm16_to_float(t10)) + unorm16_to_float(t11);
+        return float_to_unorm16(value * 0.25f);
+    }
     float value = 0.0f, count = 0.0f;
     if (t00 != 0) { value += unorm16_to_float(t00); count += 1.0f; }
     if (t01 != 0) { value += unorm16_to_float(t01); count += 1.0f; }
@@ -159,9 +186,9 @@ __device__ __forceinline__ uint32_t downsample4(uint32_t t00, uint32_t t01, uint
 }
 
 // general (slow) evaluation of the finest-LOD mosaic pixel (tile, r) from the source; used for the
-// b x b corner aprons only.  `home` = atlas texel holding that pixel (for the keep-previous rule).
-__device__ uint32_t split_value_slow(const FusedArgs& A, const RasterDev& r, uint32_t tx, uint32_t rx, uint32_t ty, uint32_t ry,
-                                     uint32_t home_index) {
+// b x b corner aprons only.  `home` = atlas tile holding that pixel (for the keep-previous rule).
+__device__ __forceinline__ uint32_t split_value_slow(const FusedArgs& A, const RasterDev& r, uint32_t tx, uint32_t rx, uint32_t ty,
+                                                  uint32_t ry, uint32_t home_index) {
     const float scale = float(1u << A.lod);
     const uint32_t c = A.m.center_size, b = A.m.border_size, T = A.m.texture_size;
     const Axis ax = split_axis(rx, c, tx, scale, A.tlx, A.brx, r.width);
@@ -180,18 +207,17 @@ __device__ uint32_t split_value_slow(const FusedArgs& A, const RasterDev& r, uin
 
 struct Texel4 {  // the four source texels a column pair needs from one source row, converted
     float a0, a1, b0, b1;
-    uint32_t zero_mask;  // bit k set if texel k == 0
+    bool za, zb;  // a no-data (zero) texel in pair a / pair b
 };
 
-__device__ __forceinline__ Texel4 load_row(const uint8_t* __restrict__ data, uint64_t pitch, int y, int xa0, int xa1, int xb0, int xb1) {
-    const uint16_t* row = (const uint16_t*)(data + uint64_t(y) * pitch);
-    const uint32_t ta0 = row[xa0], ta1 = row[xa1], tb0 = row[xb0], tb1 = row[xb1];
+__device__ __forceinline__ Texel4 convert4(uint32_t ta0, uint32_t ta1, uint32_t tb0, uint32_t tb1) {
     Texel4 r;
     r.a0 = unorm16_to_float(ta0);
     r.a1 = unorm16_to_float(ta1);
     r.b0 = unorm16_to_float(tb0);
     r.b1 = unorm16_to_float(tb1);
-    r.zero_mask = (ta0 == 0 ? 1u : 0u) | (ta1 == 0 ? 2u : 0u) | (tb0 == 0 ? 4u : 0u) | (tb1 == 0 ? 8u : 0u);
+    r.za = ta0 == 0 || ta1 == 0;
+    r.zb = tb0 == 0 || tb1 == 0;
     return r;
 }
 
@@ -202,10 +228,75 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t total) {
     return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + i;
 }
 
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+struct MainShared {  // fixed part of the dynamic LDS block (size is a multiple of 16 bytes)
+    int y0[kRowTable], y1[kRowTable];
+    float fy[kRowTable];
+    uint32_t ry[kRowTable];
+    uint16_t slot0[kRowTable], slot1[kRowTable];
+    int slot_y[kMaxSlots];
+    uint32_t nb[2][8];  // neighbours (N,E,S,W,NW,NE,SE,SW) of the parent [0] and grand-parent [1] tile
+    int xmin, xmax;
+    uint32_t slots, pad;
+};
+static_assert(sizeof(MainShared) % 16 == 0, "LDS carve must stay 16-byte aligned");
+
+// push_pixel with the tile's neighbour table already in LDS (the fused_main hot loop must not wait on global
+// lookups: its first and last lanes sit on a tile edge in every row)
+__device__ __forceinline__ void push_pixel_lds(const FusedArgs& A, const uint32_t* nb, uint16_t* __restrict__ self, uint32_t cx,
+                                               uint32_t cy, uint16_t v) {
+    const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
+    const uint32_t tile_texels = T * T;
+    self[(b + cy) * T + b + cx] = v;
+    const int ex = cx < b ? -1 : (cx >= c - b ? 1 : 0);
+    const int ey = cy < b ? -1 : (cy >= c - b ? 1 : 0);
+    if (ex == 0 && ey == 0) return;
+    const uint32_t o = b + c;
+    const uint32_t ax = uint32_t(int(b + cx) - ex * int(c)), ay = uint32_t(int(b + cy) - ey * int(c));
+    if (ex != 0) {
+        const uint32_t n = nb[ex < 0 ? 3 : 1];
+        if (n != kInvalid) {
+            A.atlas[uint64_t(n) * tile_texels + (b + cy) * T + ax] = v;
+        } else if (cx == 0 || cx == c - 1) {
+            const uint32_t x0 = ex < 0 ? 0u : o;
+            for (uint32_t j = 0; j < b; j++) self[(b + cy) * T + x0 + j] = v;
+        }
+    }
+    if (ey != 0) {
+        const uint32_t n = nb[ey < 0 ? 0 : 2];
+        if (n != kInvalid) {
+            A.atlas[uint64_t(n) * tile_texels + ay * T + b + cx] = v;
+        } else if (cy == 0 || cy == c - 1) {
+            const uint32_t y0 = ey < 0 ? 0u : o;
+            for (uint32_t j = 0; j < b; j++) self[(y0 + j) * T + b + cx] = v;
+        }
+    }
+    if (ex != 0 && ey != 0) {
+        const uint32_t n = nb[ey < 0 ? (ex < 0 ? 4 : 5) : (ex < 0 ? 7 : 6)];
+        if (n != kInvalid) {
+            A.atlas[uint64_t(n) * tile_texels + ay * T + ax] = v;
+        } else if ((cx == 0 || cx == c - 1) && (cy == 0 || cy == c - 1)) {
+            const uint32_t x0 = ex < 0 ? 0u : o, y0 = ey < 0 ? 0u : o;
+            for (uint32_t j = 0; j < b; j++)
+                for (uint32_t i = 0; i < b; i++) self[(y0 + j) * T + x0 + i] = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void fused_main_kernel(FusedArgs A) {
-    __shared__ int s_y0[kMainRows + 16], s_y1[kMainRows + 16];
-    __shared__ float s_fy[kMainRows + 16];
-    __shared__ uint32_t s_ty[kMainRows + 16], s_ry[kMainRows + 16];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    MainShared& S = *reinterpret_cast<MainShared*>(smem);
+    uint16_t* s_src = reinterpret_cast<uint16_t*>(smem + sizeof(MainShared));
 
     const uint32_t work = xcd_remap(blockIdx.x, gridDim.x);
     const MainItem it = A.items[work / A.groups];
@@ -214,162 +305,239 @@ __global__ __launch_bounds__(256) void fused_main_kernel(FusedArgs A) {
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
     const uint32_t tid = threadIdx.x;
     const float scale = float(1u << A.lod);
-    const uint64_t tile_texels = uint64_t(T) * T;
+    const uint32_t tile_texels = T * T;
 
     const TileNb t5 = load_tile_nb(A, it.side, A.lod, it.x, it.y);
-    TileNb t4{}, t3{};
-    if (A.levels >= 2) t4 = load_tile_nb(A, it.side, A.lod - 1, it.x >> 1, it.y >> 1);
-    if (A.levels >= 3) t3 = load_tile_nb(A, it.side, A.lod - 2, it.x >> 2, it.y >> 2);
+    const uint32_t self4 = A.levels >= 2 ? grid_lookup(A, it.side, A.lod - 1, int(it.x >> 1), int(it.y >> 1)) : kInvalid;
+    const uint32_t self3 = A.levels >= 3 ? grid_lookup(A, it.side, A.lod - 2, int(it.x >> 2), int(it.y >> 2)) : kInvalid;
 
     // texture rows handled by this workgroup: its centre rows plus the apron rows of the tile's first / last group
     const uint32_t cr0 = g * kMainRows, cr1 = min(c, cr0 + kMainRows);
     const uint32_t py_begin = g == 0 ? 0u : b + cr0, py_end = cr1 == c ? T : b + cr1;
-    const uint32_t nrows = py_end - py_begin;
+    const uint32_t nrows = py_end - py_begin;  // even: b, kMainRows and c are even
 
+    if (tid == 0) {
+        S.xmin = 0x7FFFFFFF;
+        S.xmax = -1;
+    }
     if (tid < nrows) {
         const uint32_t py = py_begin + tid;
         uint32_t ty, ry;
         if (py < b) {  // top apron: the north neighbour's last centre rows, or (absent) clamped into the own centre
-            if (t5.nb[0] != kInvalid) { ty = it.y - 1; ry = c - b + py; } else { ty = it.y; ry = 0; }
+            if (t5.n != kInvalid) { ty = it.y - 1; ry = c - b + py; } else { ty = it.y; ry = 0; }
         } else if (py >= o) {
-            if (t5.nb[2] != kInvalid) { ty = it.y + 1; ry = py - o; } else { ty = it.y; ry = c - 1; }
+            if (t5.s != kInvalid) { ty = it.y + 1; ry = py - o; } else { ty = it.y; ry = c - 1; }
         } else {
             ty = it.y;
             ry = py - b;
         }
         const Axis ay = split_axis(ry, c, ty, scale, A.tly, A.bry, raster.height);
-        s_y0[tid] = ay.i0;
-        s_y1[tid] = ay.i1;
-        s_fy[tid] = ay.fr;
-        s_ty[tid] = ty;
-        s_ry[tid] = ry;
+        S.y0[tid] = ay.i0;
+        S.y1[tid] = ay.i1;
+        S.fy[tid] = ay.fr;
+        S.ry[tid] = ry;
+    } else if (tid >= 64 && tid < 80 && A.levels >= 2) {
+        // neighbour tables of the parent / grand-parent tile for the pushes below
+        constexpr int kOff[8][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}, {-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
+        const uint32_t k = tid - 64, lvl = k >> 3, r = k & 7u;
+        const uint32_t shift = lvl + 1;
+        S.nb[lvl][r] = (A.lod >= shift && A.levels >= shift + 1)
+                           ? grid_lookup(A, it.side, A.lod - shift, int(it.x >> shift) + kOff[r][0], int(it.y >> shift) + kOff[r][1])
+                           : kInvalid;
     }
 
     // column pair of this thread: centre pairs first so that lanes (2m, 2m+1) hold the two halves of one
     // pixel of the level two below; the b/2 right and b/2 left apron pairs come last
     const uint32_t half_c = c / 2, half_b = b / 2;
-    enum { kCentre, kRight, kLeft, kIdle } role;
-    uint32_t px0;  // texture column of the pair's first pixel
-    uint32_t txc[2], rxc[2];
-    if (tid < half_c) {
-        role = kCentre;
+    const bool is_centre = tid < half_c;
+    const bool is_right = !is_centre && tid < half_c + half_b;
+    const bool is_left = !is_centre && !is_right && tid < half_c + 2 * half_b;
+    const bool is_idle = !is_centre && !is_right && !is_left;
+    uint32_t px0 = 0;  // texture column of the pair's first pixel
+    uint32_t txa = it.x, txb = it.x, rxa = 0, rxb = 0;
+    if (is_centre) {
         px0 = b + 2 * tid;
-        txc[0] = txc[1] = it.x;
-        rxc[0] = 2 * tid;
-        rxc[1] = 2 * tid + 1;
-    } else if (tid < half_c + half_b) {
-        role = kRight;
+        rxa = 2 * tid;
+        rxb = 2 * tid + 1;
+    } else if (is_right) {
         const uint32_t j = 2 * (tid - half_c);
         px0 = o + j;
-        for (int k = 0; k < 2; k++) {
-            if (t5.nb[1] != kInvalid) { txc[k] = it.x + 1; rxc[k] = j + k; } else { txc[k] = it.x; rxc[k] = c - 1; }
-        }
-    } else if (tid < half_c + 2 * half_b) {
-        role = kLeft;
+        if (t5.e != kInvalid) { txa = txb = it.x + 1; rxa = j; rxb = j + 1; } else { rxa = rxb = c - 1; }
+    } else if (is_left) {
         const uint32_t j = 2 * (tid - half_c - half_b);
         px0 = j;
-        for (int k = 0; k < 2; k++) {
-            if (t5.nb[3] != kInvalid) { txc[k] = it.x - 1; rxc[k] = c - b + j + k; } else { txc[k] = it.x; rxc[k] = 0; }
-        }
-    } else {
-        role = kIdle;
-        px0 = 0;
-        txc[0] = txc[1] = it.x;
-        rxc[0] = rxc[1] = 0;
+        if (t5.w != kInvalid) { txa = txb = it.x - 1; rxa = c - b + j; rxb = c - b + j + 1; } else { rxa = rxb = 0; }
     }
-    const Axis axa = split_axis(rxc[0], c, txc[0], scale, A.tlx, A.brx, raster.width);
-    const Axis axb = split_axis(rxc[1], c, txc[1], scale, A.tlx, A.brx, raster.width);
-    const float fxa = axa.fr, fxb = axb.fr;
+    const Axis axa = split_axis(rxa, c, txa, scale, A.tlx, A.brx, raster.width);
+    const Axis axb = split_axis(rxb, c, txb, scale, A.tlx, A.brx, raster.width);
+    const float fxa = axa.fr, fxb = axb.fr, gxa = 1.0f - fxa, gxb = 1.0f - fxb;
     // atlas tile holding each column's pixels (keep-previous rule reads it when the source has no data)
-    const uint32_t home_col = role == kRight && t5.nb[1] != kInvalid ? t5.nb[1]
-                              : role == kLeft && t5.nb[3] != kInvalid ? t5.nb[3] : t5.self;
+    const uint32_t home_col = is_right && t5.e != kInvalid ? t5.e : (is_left && t5.w != kInvalid ? t5.w : t5.self);
 
     __syncthreads();
 
+    // source window: columns [xa, xa + pitch) with xa 8-texel aligned, one LDS slot per distinct source row
+    {
+        const int lo = wave_min(is_idle ? 0x7FFFFFFF : min(axa.i0, axb.i0));
+        const int hi = wave_max(is_idle ? -1 : max(axa.i1, axb.i1));
+        if ((tid & 63u) == 0) {
+            atomicMin(&S.xmin, lo);
+            atomicMax(&S.xmax, hi);
+        }
+    }
+    if (tid == 0) {
+        uint32_t slots = 0;
+        int last_y = -1;
+        for (uint32_t j = 0; j < nrows; j++) {
+            const int y0 = S.y0[j], y1 = S.y1[j];
+            // rows are non-decreasing, so a row is either one of the last two staged or new
+            uint32_t s0;
+            if (slots >= 1 && y0 == last_y) s0 = slots - 1;
+            else if (slots >= 2 && y0 == S.slot_y[slots - 2]) s0 = slots - 2;
+            else { S.slot_y[slots] = y0; s0 = slots++; last_y = y0; }
+            uint32_t s1;
+            if (y1 == y0) s1 = s0;
+            else if (y1 == last_y) s1 = slots - 1;
+            else { S.slot_y[slots] = y1; s1 = slots++; last_y = y1; }
+            S.slot0[j] = uint16_t(s0);
+            S.slot1[j] = uint16_t(s1);
+        }
+        S.slots = slots;
+    }
+    __syncthreads();
+
+    const int xa = S.xmin & ~7;
+    const uint32_t P = A.lds_pitch;
+    const uint32_t slots = S.slots;
+    // staged == false (window larger than the LDS budget the host sized): read the source directly
+    const bool staged = slots <= A.lds_rows && uint32_t(S.xmax - xa + 1) <= P;
     const uint8_t* data = (const uint8_t*)raster.data;
+    if (staged) {
+        const uint32_t chunks_per_row = P / 8u;
+        const uint32_t row_texels = uint32_t(raster.pitch / 2u);  // addressable texels per source row
+        const bool wide = ((reinterpret_cast<uintptr_t>(data) | raster.pitch) & 15u) == 0;
+        for (uint32_t ch = tid; ch < slots * chunks_per_row; ch += 256u) {
+            const uint32_t slot = ch / chunks_per_row, k = ch % chunks_per_row;
+            const uint32_t x = uint32_t(xa) + 8u * k;
+            const uint8_t* src = data + uint64_t(S.slot_y[slot]) * raster.pitch + uint64_t(x) * 2u;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (wide && x + 8u <= row_texels) {
+                v = *reinterpret_cast<const uint4*>(src);
+            } else if (x < raster.width) {
+                uint16_t t[8];
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) t[i] = (x + i < raster.width) ? ((const uint16_t*)src)[i] : uint16_t(0);
+                v = make_uint4(t[0] | (uint32_t(t[1]) << 16), t[2] | (uint32_t(t[3]) << 16), t[4] | (uint32_t(t[5]) << 16),
+                               t[6] | (uint32_t(t[7]) << 16));
+            }
+            *reinterpret_cast<uint4*>(s_src + size_t(slot) * P + 8u * k) = v;
+        }
+    }
+    __syncthreads();
+
+    // LDS offsets of this thread's four source columns
+    const uint32_t la0 = uint32_t(axa.i0 - xa), la1 = uint32_t(axa.i1 - xa), lb0 = uint32_t(axb.i0 - xa), lb1 = uint32_t(axb.i1 - xa);
+    auto fetch_row = [&](uint32_t slot, int y) -> Texel4 {
+        if (staged) {
+            const uint16_t* row = s_src + slot * P;
+            return convert4(row[la0], row[la1], row[lb0], row[lb1]);
+        }
+        const uint16_t* row = (const uint16_t*)(data + uint64_t(y) * raster.pitch);
+        return convert4(row[axa.i0], row[axa.i1], row[axb.i0], row[axb.i1]);
+    };
+    // one finest-LOD pixel pair from its top / bottom source rows
+    auto shade = [&](const Texel4& top, const Texel4& bot, float fy, uint32_t& va, uint32_t& vb) {
+        const float gy = 1.0f - fy;
+        va = float_to_unorm16((top.a0 * gxa + top.a1 * fxa) * gy + (bot.a0 * gxa + bot.a1 * fxa) * fy);
+        vb = float_to_unorm16((top.b0 * gxb + top.b1 * fxb) * gy + (bot.b0 * gxb + bot.b1 * fxb) * fy);
+    };
+
     uint16_t* tile5 = A.atlas + uint64_t(t5.self) * tile_texels;
+    uint32_t* tile5_u32 = reinterpret_cast<uint32_t*>(tile5);
+    uint16_t* tile4 = A.atlas + uint64_t(self4 == kInvalid ? 0u : self4) * tile_texels;
+    uint16_t* tile3 = A.atlas + uint64_t(self3 == kInvalid ? 0u : self3) * tile_texels;
+    const uint32_t cx4 = (it.x & 1u) * half_c + tid, cy4_base = (it.y & 1u) * half_c;
+    const uint32_t cx3 = (it.x & 3u) * (c / 4) + (tid >> 1), cy3_base = (it.y & 3u) * (c / 4);
 
     Texel4 prev{};
-    int prev_y = -1;
-    uint32_t even_a = 0, even_b = 0;  // finest values of the even row of the current row pair
-    uint32_t q_even = 0;              // level-1 value of the even row pair of the current quad
+    uint32_t prev_slot = kInvalid;
+    uint32_t q_even = 0;  // level-1 value of the even row pair of the current quad
 
-    for (uint32_t j = 0; j < nrows; j++) {
+    for (uint32_t j = 0; j < nrows; j += 2) {
         const uint32_t py = py_begin + j;
-        const bool apron_row = py < b || py >= o;
-        const int y0 = s_y0[j], y1 = s_y1[j];
-        const float fy = s_fy[j];
-        uint32_t va, vb;
-        if (role == kIdle) {
-            va = vb = 0;
-        } else if (apron_row && role != kCentre) {
+        const bool apron_rows = py < b || py >= o;  // b is even: a row pair never straddles the centre edge
+        uint32_t va0 = 0, vb0 = 0, va1 = 0, vb1 = 0;    // pixels of row j (0) and row j + 1 (1)
+        if (is_idle) {
+            // nothing
+        } else if (apron_rows && !is_centre) {
             // b x b corner: governed by the diagonal neighbour alone (stitch.wgsl:57-66, 105-118)
-            const uint32_t region = py < b ? (role == kLeft ? 4u : 5u) : (role == kLeft ? 7u : 6u);
-            const uint32_t n = t5.nb[region];
-            uint32_t v[2];
-            for (uint32_t k = 0; k < 2; k++) {
+            const bool top = py < b;
+            const uint32_t n = grid_lookup(A, it.side, A.lod, int(it.x) + (is_left ? -1 : 1), int(it.y) + (top ? -1 : 1));
+            uint32_t v[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t pxk = px0 + (k & 1u), pyk = py + (k >> 1);
                 uint32_t tx, rx, ty, ry, home;
                 if (n != kInvalid) {
-                    tx = role == kLeft ? it.x - 1 : it.x + 1;
-                    rx = role == kLeft ? c - b + (px0 + k) : (px0 + k) - o;
-                    ty = py < b ? it.y - 1 : it.y + 1;
-                    ry = py < b ? c - b + py : py - o;
+                    tx = is_left ? it.x - 1 : it.x + 1;
+                    rx = is_left ? c - b + pxk : pxk - o;
+                    ty = top ? it.y - 1 : it.y + 1;
+                    ry = top ? c - b + pyk : pyk - o;
                     home = n;
                 } else {
                     tx = it.x;
-                    rx = role == kLeft ? 0u : c - 1;
+                    rx = is_left ? 0u : c - 1;
                     ty = it.y;
-                    ry = py < b ? 0u : c - 1;
+                    ry = top ? 0u : c - 1;
                     home = t5.self;
                 }
                 v[k] = split_value_slow(A, raster, tx, rx, ty, ry, home);
             }
-            va = v[0];
-            vb = v[1];
+            va0 = v[0];
+            vb0 = v[1];
+            va1 = v[2];
+            vb1 = v[3];
         } else {
-            const Texel4 top = (y0 == prev_y) ? prev : load_row(data, raster.pitch, y0, axa.i0, axa.i1, axb.i0, axb.i1);
-            const Texel4 bot = (y1 == y0) ? top : load_row(data, raster.pitch, y1, axa.i0, axa.i1, axb.i0, axb.i1);
-            prev = bot;
-            prev_y = y1;
-            const uint32_t zero = top.zero_mask | bot.zero_mask;
-            {
-                const float tp = mixf(top.a0, top.a1, fxa), bt_ = mixf(bot.a0, bot.a1, fxa);
-                va = float_to_unorm16(mixf(tp, bt_, fy));
-            }
-            {
-                const float tp = mixf(top.b0, top.b1, fxb), bt_ = mixf(bot.b0, bot.b1, fxb);
-                vb = float_to_unorm16(mixf(tp, bt_, fy));
-            }
-            if (zero) {  // no data in the footprint: the pixel keeps its previous atlas value (split.wgsl:37-42)
-                const uint32_t home = apron_row ? (py < b ? t5.nb[0] : t5.nb[2]) : home_col;
+            const uint32_t a0 = S.slot0[j], a1 = S.slot1[j], b0s = S.slot0[j + 1], b1s = S.slot1[j + 1];
+            const Texel4 r0 = (a0 == prev_slot) ? prev : fetch_row(a0, S.y0[j]);
+            const Texel4 r1 = (a1 == a0) ? r0 : fetch_row(a1, S.y1[j]);
+            const Texel4 r2 = (b0s == a1) ? r1 : ((b0s == a0) ? r0 : fetch_row(b0s, S.y0[j + 1]));
+            const Texel4 r3 = (b1s == b0s) ? r2 : fetch_row(b1s, S.y1[j + 1]);
+            prev = r3;
+            prev_slot = b1s;
+            shade(r0, r1, S.fy[j], va0, vb0);
+            shade(r2, r3, S.fy[j + 1], va1, vb1);
+            const bool z0a = r0.za || r1.za, z0b = r0.zb || r1.zb, z1a = r2.za || r3.za, z1b = r2.zb || r3.zb;
+            if (z0a || z0b || z1a || z1b) {  // no data in a footprint: those pixels keep their previous atlas value (split.wgsl:37-42)
+                const uint32_t home = apron_rows ? (py < b ? t5.n : t5.s) : home_col;
                 const uint32_t hi = home == kInvalid ? t5.self : home;
-                const uint16_t* hrow = A.atlas + uint64_t(hi) * tile_texels + uint64_t(b + s_ry[j]) * T + b;
-                if (zero & 3u) va = hrow[rxc[0]];
-                if (zero & 12u) vb = hrow[rxc[1]];
+                const uint16_t* h0 = A.atlas + uint64_t(hi) * tile_texels + (b + S.ry[j]) * T + b;
+                const uint16_t* h1 = A.atlas + uint64_t(hi) * tile_texels + (b + S.ry[j + 1]) * T + b;
+                if (z0a) va0 = h0[rxa];
+                if (z0b) vb0 = h0[rxb];
+                if (z1a) va1 = h1[rxa];
+                if (z1b) vb1 = h1[rxb];
             }
         }
-        if (role != kIdle) ((uint32_t*)tile5)[(uint64_t(py) * T + px0) / 2] = va | (vb << 16);
+        if (!is_idle) {
+            tile5_u32[(py * T + px0) >> 1] = va0 | (vb0 << 16);
+            tile5_u32[((py + 1) * T + px0) >> 1] = va1 | (vb1 << 16);
+        }
 
-        // ---- next two LODs from the centre pixels: rows pair up, then lanes pair up
-        if (A.levels >= 2 && !apron_row) {
-            const uint32_t cy = py - b;
-            if ((cy & 1u) == 0) {
-                even_a = va;
-                even_b = vb;
-            } else {
-                // level-1 pixel (tid, cy/2) of this tile's quadrant: OFFSETS (0,0),(0,1),(1,0),(1,1)
-                const uint32_t q = downsample4(even_a, va, even_b, vb);
-                if (role == kCentre)
-                    push_pixel(A.atlas, t4, T, b, c, (it.x & 1u) * half_c + tid, (it.y & 1u) * half_c + (cy >> 1), uint16_t(q));
-                if (A.levels >= 3) {
-                    if (((cy >> 1) & 1u) == 0) {
-                        q_even = q;
-                    } else {
-                        const uint32_t other_even = __shfl_xor(q_even, 1), other_odd = __shfl_xor(q, 1);
-                        if (role == kCentre && (tid & 1u) == 0) {
-                            const uint32_t w = downsample4(q_even, q, other_even, other_odd);
-                            push_pixel(A.atlas, t3, T, b, c, (it.x & 3u) * (c / 4) + (tid >> 1), (it.y & 3u) * (c / 4) + (cy >> 2), uint16_t(w));
-                        }
+        // ---- next two LODs from the centre pixels: the row pair gives one level-1 pixel per thread, two row
+        // pairs and a lane pair give one level-2 pixel per even lane
+        if (A.levels >= 2 && !apron_rows) {
+            const uint32_t cy = py - b;  // even
+            const uint32_t q = downsample4(va0, va1, vb0, vb1);  // OFFSETS (0,0),(0,1),(1,0),(1,1) of (dx, dy)
+            if (is_centre) push_pixel_lds(A, S.nb[0], tile4, cx4, cy4_base + (cy >> 1), uint16_t(q));
+            if (A.levels >= 3) {
+                if ((cy & 2u) == 0) {
+                    q_even = q;
+                } else {
+                    const uint32_t other_even = __shfl_xor(q_even, 1), other_odd = __shfl_xor(q, 1);
+                    if (is_centre && (tid & 1u) == 0) {
+                        const uint32_t w = downsample4(q_even, q, other_even, other_odd);
+                        push_pixel_lds(A, S.nb[1], tile3, cx3, cy3_base + (cy >> 2), uint16_t(w));
                     }
                 }
             }
@@ -402,8 +570,8 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
         }
         v1 = downsample4(t[0], t[1], t[2], t[3]);
         const uint32_t x1 = gx >> 1, y1 = gy >> 1;
-        const TileNb tn = load_tile_nb(A, side, A.lod - 1, x1 / c, y1 / c);
-        if (tn.self != kInvalid) push_pixel(A.atlas, tn, T, b, c, x1 % c, y1 % c, uint16_t(v1));
+        const uint32_t self = grid_lookup(A, side, A.lod - 1, int(x1 / c), int(y1 / c));
+        if (self != kInvalid) push_pixel(A, side, A.lod - 1, x1 / c, y1 / c, self, x1 % c, y1 % c, uint16_t(v1));
     }
     if (A.levels < 2) return;
     s_l1[ty][tx] = uint16_t(v1);
@@ -415,8 +583,8 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
     if (act2) {
         v2 = downsample4(s_l1[2 * uy][2 * ux], s_l1[2 * uy + 1][2 * ux], s_l1[2 * uy][2 * ux + 1], s_l1[2 * uy + 1][2 * ux + 1]);
         const uint32_t x2 = blockIdx.x * 8u + ux, y2 = blockIdx.y * 8u + uy;
-        const TileNb tn = load_tile_nb(A, side, A.lod - 2, x2 / c, y2 / c);
-        if (tn.self != kInvalid) push_pixel(A.atlas, tn, T, b, c, x2 % c, y2 % c, uint16_t(v2));
+        const uint32_t self = grid_lookup(A, side, A.lod - 2, int(x2 / c), int(y2 / c));
+        if (self != kInvalid) push_pixel(A, side, A.lod - 2, x2 / c, y2 / c, self, x2 % c, y2 % c, uint16_t(v2));
     }
     if (A.levels < 3) return;
     if (threadIdx.x < 64) s_l2[uy][ux] = uint16_t(v2);
@@ -425,8 +593,17 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
     if (threadIdx.x < 16 && (blockIdx.x * 32u + 8u * wx) < size && (blockIdx.y * 32u + 8u * wy) < size) {
         const uint32_t v3 = downsample4(s_l2[2 * wy][2 * wx], s_l2[2 * wy + 1][2 * wx], s_l2[2 * wy][2 * wx + 1], s_l2[2 * wy + 1][2 * wx + 1]);
         const uint32_t x3 = blockIdx.x * 4u + wx, y3 = blockIdx.y * 4u + wy;
-        const TileNb tn = load_tile_nb(A, side, A.lod - 3, x3 / c, y3 / c);
-        if (tn.self != kInvalid) push_pixel(A.atlas, tn, T, b, c, x3 % c, y3 % c, uint16_t(v3));
+        const uint32_t self = grid_lookup(A, side, A.lod - 3, int(x3 / c), int(y3 / c));
+        if (self != kInvalid) push_pixel(A, side, A.lod - 3, x3 / c, y3 / c, self, x3 % c, y3 % c, uint16_t(v3));
+    }
+}
+
+// exhaustive device check of the fast unorm conversion against correctly rounded division
+__global__ void selftest_kernel(uint32_t* failures) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 65536u) {
+        volatile float d = 65535.0f;
+        if (unorm16_to_float(t) != float(t) / d) atomicAdd(failures, 1u);
     }
 }
 
@@ -582,6 +759,22 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         main_job.args.levels = main_levels;
         main_job.args.item_count = uint32_t(items.size());
         main_job.args.groups = (m.center_size + kMainRows - 1) / kMainRows;
+        {   // LDS window of a workgroup: T consecutive mosaic columns x (kMainRows + 2b) mosaic rows of the source
+            double ratio_x = 0.0, ratio_y = 0.0;
+            const double mosaic = double(1u << lod_hi) * double(m.center_size);
+            for (const Task* t : splits) {
+                const RasterDev& r = p->rasters[t->raster].dev;
+                ratio_x = std::max(ratio_x, double(r.width) / (double(args.brx - args.tlx) * mosaic));
+                ratio_y = std::max(ratio_y, double(r.height) / (double(args.bry - args.tly) * mosaic));
+            }
+            const uint32_t rows = std::min(kMainRows, m.center_size) + 2 * m.border_size;
+            const uint64_t cols_needed = uint64_t(double(m.texture_size - 1) * ratio_x) + 4 + 7;
+            const uint64_t rows_needed = std::min<uint64_t>(2 * rows, uint64_t(double(rows - 1) * ratio_y) + 4);
+            const uint64_t pitch = (cols_needed + 7) / 8 * 8;
+            const uint64_t budget = 65536 - sizeof(MainShared);
+            main_job.args.lds_pitch = uint32_t(std::min<uint64_t>(pitch, 4096));
+            main_job.args.lds_rows = uint32_t(std::min<uint64_t>(rows_needed, budget / (2 * uint64_t(main_job.args.lds_pitch))));
+        }
         Launch lm{};
         lm.kind = kLaunchFusedMain;
         lm.attachment = ai;
@@ -658,7 +851,8 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
     job.args.rasters = p->rasters_dev;
     if (l.kind == kLaunchFusedMain) {
         const uint32_t blocks = job.args.item_count * job.args.groups;
-        fused_main_kernel<<<blocks, 256, 0, p->ctx->stream>>>(job.args);
+        const size_t lds = sizeof(MainShared) + size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
+        fused_main_kernel<<<blocks, 256, lds, p->ctx->stream>>>(job.args);
     } else {
         const uint32_t size = (1u << job.args.lod) * job.args.m.center_size;
         const dim3 grid((size + 31) / 32, (size + 31) / 32, job.args.sides);
@@ -670,3 +864,20 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
 }
 
 }  // namespace bt
+
+extern "C" bt_status bt_selftest(bt_ctx* ctx, uint32_t* failures) {
+    if (!ctx || !failures) return BT_ERR_INVALID_ARGUMENT;
+    BT_HIP(hipSetDevice(ctx->device));
+    uint32_t* dev = nullptr;
+    BT_HIP(hipMalloc((void**)&dev, sizeof(uint32_t)));
+    hipError_t e = hipMemsetAsync(dev, 0, sizeof(uint32_t), ctx->stream);
+    if (e == hipSuccess) {
+        bt::selftest_kernel<<<256, 256, 0, ctx->stream>>>(dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(failures, dev, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(dev);
+    if (e != hipSuccess) return bt::hip_fail(e, "bt_selftest");
+    return BT_OK;
+}

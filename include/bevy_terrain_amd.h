@@ -271,6 +271,11 @@ bt_status bt_tiling_prepass_buffers(const bt_tiling_prepass* t, void** final_til
 bt_status bt_tiling_prepass_read(bt_tiling_prepass* t, bt_tile_coordinate* final_tiles_host, uint32_t cap,
                                  uint32_t* count, bt_indirect* indirect);
 
+/* ---------------------------------------------------------------- diagnostics */
+/* Exhaustive device check that the kernels' 3-operation unorm16 -> f32 conversion equals the correctly
+ * rounded division t / 65535.0f for all 65536 texel values; *failures must come back 0. */
+bt_status bt_selftest(bt_ctx* ctx, uint32_t* failures);
+
 /* ---------------------------------------------------------------- synthetic inputs */
 /* Deterministic integer fBm heightmap in [1, 65535] written straight into HBM (bench / tests: the
  * reference's Gaia and GEBCO source rasters are not in its checkout).  The window

@@ -169,3 +169,10 @@ def test_synth_fbm_matches_integer_model(device):
     exp = M.fbm_u16(w, h, 42, x0=1000, y0=77, base_cell=64)
     assert np.array_equal(ours, exp)
     assert ours.min() >= 1
+
+
+def test_fast_unorm_conversion_is_exact_on_device(device):
+    import ctypes as C
+    failures = C.c_uint32(123)
+    bt._ffi.check(bt._ffi.lib().bt_selftest(device._h, C.byref(failures)))
+    assert failures.value == 0

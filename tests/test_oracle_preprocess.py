@@ -153,3 +153,13 @@ def test_second_dataset_keeps_previous_where_nodata():
     t = a.tile(0, 0)[b:b + c, b:b + c]
     assert np.all(t[:, : c // 2 - 1] == 20000)
     assert np.all(t[:, c // 2 + 1:] == 40000)
+
+
+def test_markstein_unorm_division_is_exact_on_cpu():
+    # the fused kernels evaluate t/65535 as q0=t*r, e=fma(-q0,65535,t), q=fma(e,r,q0); check all inputs
+    t = np.arange(65536, dtype=np.float32)
+    r = np.float32(1.0) / np.float32(65535.0)
+    q0 = (t * r).astype(np.float32)
+    e = (np.float64(t) - np.float64(q0) * 65535.0).astype(np.float32)  # exact: the true fma result is representable
+    q = (np.float64(q0) + np.float64(e) * np.float64(r)).astype(np.float32)
+    assert np.array_equal(q, (t / np.float32(65535.0)).astype(np.float32))
