@@ -24,6 +24,8 @@
 // liberty: t / 65535.0f is evaluated as q0 = t*r, e = fma(-q0, 65535, t), q = fma(e, r, q0) with
 // r = RN(1/65535) (Markstein's correctly rounded division); equality with `/` for all 65536 inputs is
 // checked on the device by bt_selftest() and on the CPU by tests/test_oracle_preprocess.py.
+#include <cstdlib>
+
 #include "bt_internal.hpp"
 
 namespace bt {
@@ -33,8 +35,6 @@ namespace {
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 constexpr uint32_t kMainRows = 16;               // centre rows per fused_main workgroup (multiple of 4)
 constexpr uint32_t kMaxBorder = 8;
-constexpr uint32_t kRowTable = kMainRows + 2 * kMaxBorder;  // texture rows a workgroup can own
-constexpr uint32_t kMaxSlots = 2 * kRowTable;                // staged source rows (worst case: 2 per row)
 
 struct MainItem {  // one finest-LOD tile
     uint32_t side, x, y, atlas_index, raster;
@@ -55,6 +55,7 @@ struct FusedArgs {
     uint32_t sides;       // fused_tail: 1 or 6
     uint32_t lds_pitch;   // fused_main: texels per staged source row (multiple of 8)
     uint32_t lds_rows;    // fused_main: staged source rows that fit
+    uint32_t ablate;      // debug only (env BT_FUSED_ABLATE): 1 no pyramid, 2 no finest stores, 4 no shading, 8 no staging loads, 16 prologue only, 32 no packed fast loop
 };
 
 // t / 65535.0f, correctly rounded, in 3 VALU ops (see header)
@@ -193,8 +194,10 @@ __device__ __forceinline__ uint32_t split_value_slow(const FusedArgs& A, const R
     const uint32_t c = A.m.center_size, b = A.m.border_size, T = A.m.texture_size;
     const Axis ax = split_axis(rx, c, tx, scale, A.tlx, A.brx, r.width);
     const Axis ay = split_axis(ry, c, ty, scale, A.tly, A.bry, r.height);
-    const uint16_t* row0 = (const uint16_t*)((const uint8_t*)r.data + uint64_t(ay.i0) * r.pitch);
-    const uint16_t* row1 = (const uint16_t*)((const uint8_t*)r.data + uint64_t(ay.i1) * r.pitch);
+    typedef const uint8_t __attribute__((address_space(1))) * global_bytes;
+    typedef const uint16_t __attribute__((address_space(1))) * global_u16;
+    const global_u16 row0 = (global_u16)((global_bytes)r.data + uint64_t(ay.i0) * r.pitch);
+    const global_u16 row1 = (global_u16)((global_bytes)r.data + uint64_t(ay.i1) * r.pitch);
     const uint32_t t00 = row0[ax.i0], t10 = row0[ax.i1], t01 = row1[ax.i0], t11 = row1[ax.i1];
     if (t00 == 0 || t10 == 0 || t01 == 0 || t11 == 0) {
         if (home_index == kInvalid) return 0;
@@ -203,22 +206,6 @@ __device__ __forceinline__ uint32_t split_value_slow(const FusedArgs& A, const R
     const float top = mixf(unorm16_to_float(t00), unorm16_to_float(t10), ax.fr);
     const float bot = mixf(unorm16_to_float(t01), unorm16_to_float(t11), ax.fr);
     return float_to_unorm16(mixf(top, bot, ay.fr));
-}
-
-struct Texel4 {  // the four source texels a column pair needs from one source row, converted
-    float a0, a1, b0, b1;
-    bool za, zb;  // a no-data (zero) texel in pair a / pair b
-};
-
-__device__ __forceinline__ Texel4 convert4(uint32_t ta0, uint32_t ta1, uint32_t tb0, uint32_t tb1) {
-    Texel4 r;
-    r.a0 = unorm16_to_float(ta0);
-    r.a1 = unorm16_to_float(ta1);
-    r.b0 = unorm16_to_float(tb0);
-    r.b1 = unorm16_to_float(tb1);
-    r.za = ta0 == 0 || ta1 == 0;
-    r.zb = tb0 == 0 || tb1 == 0;
-    return r;
 }
 
 // blockIdx -> logical work id such that each XCD (blocks b, b+8, b+16, ... run on XCD b % 8) walks a
@@ -239,22 +226,24 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
+struct RowParam {  // one centre row of the workgroup: LDS slots of its two source rows + the y weight
+    int y0, y1;
+    float fy;
+    uint32_t pad;
+};
+
 struct MainShared {  // fixed part of the dynamic LDS block (size is a multiple of 16 bytes)
-    int y0[kRowTable], y1[kRowTable];
-    float fy[kRowTable];
-    uint32_t ry[kRowTable];
-    uint16_t slot0[kRowTable], slot1[kRowTable];
-    int slot_y[kMaxSlots];
+    RowParam rows[kMainRows];
+    RowParam apron[2 * kMaxBorder];  // [0, b): top apron rows, [b, 2b): bottom apron rows (pad = mosaic row ry)
     uint32_t nb[2][8];  // neighbours (N,E,S,W,NW,NE,SE,SW) of the parent [0] and grand-parent [1] tile
     int xmin, xmax;
-    uint32_t slots, pad;
+    uint32_t pad[2];
 };
 static_assert(sizeof(MainShared) % 16 == 0, "LDS carve must stay 16-byte aligned");
 
-// push_pixel with the tile's neighbour table already in LDS (the fused_main hot loop must not wait on global
-// lookups: its first and last lanes sit on a tile edge in every row)
+// push_pixel with the tile's neighbour table already in LDS (edge rows of the parent tiles only)
 __device__ __forceinline__ void push_pixel_lds(const FusedArgs& A, const uint32_t* nb, uint16_t* __restrict__ self, uint32_t cx,
-                                               uint32_t cy, uint16_t v) {
+                                            uint32_t cy, uint16_t v) {
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
     const uint32_t tile_texels = T * T;
     self[(b + cy) * T + b + cx] = v;
@@ -293,6 +282,68 @@ __device__ __forceinline__ void push_pixel_lds(const FusedArgs& A, const uint32_
     }
 }
 
+// Per-thread constants of the x direction of a push (the column of a thread never changes): where the
+// value also goes besides the centre texel when the row is NOT within b of the tile's top / bottom edge.
+struct PushX {
+    uint32_t centre;      // b + cx
+    uint32_t extra_base;  // element offset (without the row term) of the extra apron texel(s), or kInvalid
+    uint32_t extra_count; // 1 = one texel in the x neighbour's apron; b = replicate into the own apron
+    bool other_tile;      // extra texels live in the neighbour tile (extra_tile) instead of the own one
+    uint32_t extra_tile;
+};
+
+__device__ __forceinline__ PushX make_push_x(const FusedArgs& A, const uint32_t* nb, uint32_t cx) {
+    const uint32_t b = A.m.border_size, c = A.m.center_size, o = b + c;
+    PushX p;
+    p.centre = b + cx;
+    p.extra_base = kInvalid;
+    p.extra_count = 0;
+    p.other_tile = false;
+    p.extra_tile = 0;
+    const int ex = cx < b ? -1 : (cx >= c - b ? 1 : 0);
+    if (ex != 0) {
+        const uint32_t n = nb[ex < 0 ? 3 : 1];
+        if (n != kInvalid) {
+            p.extra_base = uint32_t(int(b + cx) - ex * int(c));
+            p.extra_count = 1;
+            p.other_tile = true;
+            p.extra_tile = n;
+        } else if (cx == 0 || cx == c - 1) {
+            p.extra_base = ex < 0 ? 0u : o;
+            p.extra_count = b;
+        }
+    }
+    return p;
+}
+
+// interior-row push: centre texel plus the precomputed x extras (no neighbour lookups, one rare branch)
+__device__ __forceinline__ void push_fast(const FusedArgs& A, const PushX& p, uint16_t* __restrict__ self, uint32_t cy, uint16_t v) {
+    const uint32_t T = A.m.texture_size, b = A.m.border_size;
+    const uint32_t row = (b + cy) * T;
+    self[row + p.centre] = v;
+    if (p.extra_count) {
+        uint16_t* t = p.other_tile ? A.atlas + uint64_t(p.extra_tile) * (T * T) : self;
+        for (uint32_t j = 0; j < p.extra_count; j++) t[row + p.extra_base + j] = v;
+    }
+}
+
+struct Texel4 {  // the four source texels a column pair needs from one source row
+    float a0, a1, b0, b1;  // converted
+    uint32_t za, zb;       // min of the raw pair: 0 <=> a no-data texel in pair a / b
+};
+
+__device__ __forceinline__ Texel4 convert4(uint32_t ta0, uint32_t ta1, uint32_t tb0, uint32_t tb1) {
+    Texel4 r;
+    r.a0 = unorm16_to_float(ta0);
+    r.a1 = unorm16_to_float(ta1);
+    r.b0 = unorm16_to_float(tb0);
+    r.b1 = unorm16_to_float(tb1);
+    r.za = min(ta0, ta1);
+    r.zb = min(tb0, tb1);
+    return r;
+}
+
+template <bool kStaged>
 __global__ __launch_bounds__(256) void fused_main_kernel(FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     MainShared& S = *reinterpret_cast<MainShared*>(smem);
@@ -311,31 +362,27 @@ __global__ __launch_bounds__(256) void fused_main_kernel(FusedArgs A) {
     const uint32_t self4 = A.levels >= 2 ? grid_lookup(A, it.side, A.lod - 1, int(it.x >> 1), int(it.y >> 1)) : kInvalid;
     const uint32_t self3 = A.levels >= 3 ? grid_lookup(A, it.side, A.lod - 2, int(it.x >> 2), int(it.y >> 2)) : kInvalid;
 
-    // texture rows handled by this workgroup: its centre rows plus the apron rows of the tile's first / last group
+    // centre rows of this workgroup (a multiple of 4: c and kMainRows are)
     const uint32_t cr0 = g * kMainRows, cr1 = min(c, cr0 + kMainRows);
-    const uint32_t py_begin = g == 0 ? 0u : b + cr0, py_end = cr1 == c ? T : b + cr1;
-    const uint32_t nrows = py_end - py_begin;  // even: b, kMainRows and c are even
+    const uint32_t nrows = cr1 - cr0;
 
-    if (tid == 0) {
-        S.xmin = 0x7FFFFFFF;
-        S.xmax = -1;
-    }
     if (tid < nrows) {
-        const uint32_t py = py_begin + tid;
+        const Axis ay = split_axis(cr0 + tid, c, it.y, scale, A.tly, A.bry, raster.height);
+        S.rows[tid].y0 = ay.i0;
+        S.rows[tid].y1 = ay.i1;
+        S.rows[tid].fy = ay.fr;
+    } else if (tid >= 32 && tid < 32 + 2 * b) {
+        // apron rows: the north / south neighbour's centre rows, or (neighbour absent) clamped into the own centre
+        const uint32_t r = tid - 32, k = r % b;
+        const bool top = r < b;
+        const uint32_t nrow = top ? t5.n : t5.s;
         uint32_t ty, ry;
-        if (py < b) {  // top apron: the north neighbour's last centre rows, or (absent) clamped into the own centre
-            if (t5.n != kInvalid) { ty = it.y - 1; ry = c - b + py; } else { ty = it.y; ry = 0; }
-        } else if (py >= o) {
-            if (t5.s != kInvalid) { ty = it.y + 1; ry = py - o; } else { ty = it.y; ry = c - 1; }
-        } else {
-            ty = it.y;
-            ry = py - b;
-        }
+        if (nrow != kInvalid) { ty = top ? it.y - 1 : it.y + 1; ry = top ? c - b + k : k; } else { ty = it.y; ry = top ? 0u : c - 1; }
         const Axis ay = split_axis(ry, c, ty, scale, A.tly, A.bry, raster.height);
-        S.y0[tid] = ay.i0;
-        S.y1[tid] = ay.i1;
-        S.fy[tid] = ay.fr;
-        S.ry[tid] = ry;
+        S.apron[r].y0 = ay.i0;
+        S.apron[r].y1 = ay.i1;
+        S.apron[r].fy = ay.fr;
+        S.apron[r].pad = ry;
     } else if (tid >= 64 && tid < 80 && A.levels >= 2) {
         // neighbour tables of the parent / grand-parent tile for the pushes below
         constexpr int kOff[8][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}, {-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
@@ -374,171 +421,284 @@ __global__ __launch_bounds__(256) void fused_main_kernel(FusedArgs A) {
     // atlas tile holding each column's pixels (keep-previous rule reads it when the source has no data)
     const uint32_t home_col = is_right && t5.e != kInvalid ? t5.e : (is_left && t5.w != kInvalid ? t5.w : t5.self);
 
+    // the first left-apron pair reads the leftmost source column, the last right-apron pair the rightmost
+    if (tid == half_c + half_b) S.xmin = min(axa.i0, axb.i0);
+    if (tid == half_c + half_b - 1) S.xmax = max(axa.i1, axb.i1);
     __syncthreads();
 
-    // source window: columns [xa, xa + pitch) with xa 8-texel aligned, one LDS slot per distinct source row
-    {
-        const int lo = wave_min(is_idle ? 0x7FFFFFFF : min(axa.i0, axb.i0));
-        const int hi = wave_max(is_idle ? -1 : max(axa.i1, axb.i1));
-        if ((tid & 63u) == 0) {
-            atomicMin(&S.xmin, lo);
-            atomicMax(&S.xmax, hi);
-        }
-    }
-    if (tid == 0) {
-        uint32_t slots = 0;
-        int last_y = -1;
-        for (uint32_t j = 0; j < nrows; j++) {
-            const int y0 = S.y0[j], y1 = S.y1[j];
-            // rows are non-decreasing, so a row is either one of the last two staged or new
-            uint32_t s0;
-            if (slots >= 1 && y0 == last_y) s0 = slots - 1;
-            else if (slots >= 2 && y0 == S.slot_y[slots - 2]) s0 = slots - 2;
-            else { S.slot_y[slots] = y0; s0 = slots++; last_y = y0; }
-            uint32_t s1;
-            if (y1 == y0) s1 = s0;
-            else if (y1 == last_y) s1 = slots - 1;
-            else { S.slot_y[slots] = y1; s1 = slots++; last_y = y1; }
-            S.slot0[j] = uint16_t(s0);
-            S.slot1[j] = uint16_t(s1);
-        }
-        S.slots = slots;
-    }
-    __syncthreads();
-
-    const int xa = S.xmin & ~7;
+    // source window: columns [xa, xa + pitch) with xa 8-texel aligned; LDS slot of source row y = y - ymin
+    // (the centre rows of a workgroup are consecutive mosaic rows; the host sized the LDS for their range)
+    const int xa = __builtin_amdgcn_readfirstlane(S.xmin) & ~7;
+    const bool own_top = g == 0, own_bottom = cr1 == c;
+    const int ymin = __builtin_amdgcn_readfirstlane(own_top ? min(S.apron[0].y0, S.rows[0].y0) : S.rows[0].y0);
+    const int ymax = __builtin_amdgcn_readfirstlane(own_bottom ? max(S.apron[2 * b - 1].y1, S.rows[nrows - 1].y1) : S.rows[nrows - 1].y1);
     const uint32_t P = A.lds_pitch;
-    const uint32_t slots = S.slots;
-    // staged == false (window larger than the LDS budget the host sized): read the source directly
-    const bool staged = slots <= A.lds_rows && uint32_t(S.xmax - xa + 1) <= P;
-    const uint8_t* data = (const uint8_t*)raster.data;
-    if (staged) {
+    const uint32_t slots = uint32_t(ymax - ymin + 1);
+    // raster.data is loaded from memory, so tell the compiler it is a global (not generic) pointer
+    typedef const uint8_t __attribute__((address_space(1))) * global_bytes;
+    typedef const uint16_t __attribute__((address_space(1))) * global_u16;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const u32x4 __attribute__((address_space(1))) * global_u4;
+    const global_bytes data = (global_bytes)raster.data;
+    typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+    u16x2 zmin = {1, 1};  // running minimum of every staged texel: 0 <=> the window holds a no-data texel
+    if (kStaged && !(A.ablate & 8u)) {
         const uint32_t chunks_per_row = P / 8u;
+        const uint32_t total = slots * chunks_per_row;
         const uint32_t row_texels = uint32_t(raster.pitch / 2u);  // addressable texels per source row
-        const bool wide = ((reinterpret_cast<uintptr_t>(data) | raster.pitch) & 15u) == 0;
-        for (uint32_t ch = tid; ch < slots * chunks_per_row; ch += 256u) {
-            const uint32_t slot = ch / chunks_per_row, k = ch % chunks_per_row;
-            const uint32_t x = uint32_t(xa) + 8u * k;
-            const uint8_t* src = data + uint64_t(S.slot_y[slot]) * raster.pitch + uint64_t(x) * 2u;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (wide && x + 8u <= row_texels) {
-                v = *reinterpret_cast<const uint4*>(src);
-            } else if (x < raster.width) {
-                uint16_t t[8];
+        const bool wide = ((reinterpret_cast<uintptr_t>(raster.data) | raster.pitch) & 15u) == 0;
+        if (wide) {
+            // branch-free batches: every thread issues kBatch independent 16-byte loads (addresses of chunks
+            // past the window are clamped to a valid one and dropped), then writes them to LDS
+            constexpr uint32_t kBatch = 8;
+            for (uint32_t base = 0; base < total; base += 256u * kBatch) {
+                u32x4 v[kBatch];
 #pragma unroll
-                for (uint32_t i = 0; i < 8; i++) t[i] = (x + i < raster.width) ? ((const uint16_t*)src)[i] : uint16_t(0);
-                v = make_uint4(t[0] | (uint32_t(t[1]) << 16), t[2] | (uint32_t(t[3]) << 16), t[4] | (uint32_t(t[5]) << 16),
-                               t[6] | (uint32_t(t[7]) << 16));
+                for (uint32_t i = 0; i < kBatch; i++) {
+                    const uint32_t ch = min(base + tid + 256u * i, total - 1u);
+                    const uint32_t slot = ch / chunks_per_row, k = ch - slot * chunks_per_row;
+                    const uint32_t x = min(uint32_t(xa) + 8u * k, row_texels - 8u);  // x, row_texels: multiples of 8
+                    v[i] = *(global_u4)(data + uint64_t(ymin + int(slot)) * raster.pitch + uint64_t(x) * 2u);
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < kBatch; i++) {
+                    const uint32_t ch = base + tid + 256u * i;
+                    const uint32_t slot = ch / chunks_per_row, k = ch - slot * chunks_per_row;
+                    if (ch < total) *reinterpret_cast<u32x4*>(s_src + slot * P + 8u * k) = v[i];
+                    const u16x2 m01 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, v[i].x), __builtin_bit_cast(u16x2, v[i].y));
+                    const u16x2 m23 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, v[i].z), __builtin_bit_cast(u16x2, v[i].w));
+                    zmin = __builtin_elementwise_min(zmin, __builtin_elementwise_min(m01, m23));
+                }
             }
-            *reinterpret_cast<uint4*>(s_src + size_t(slot) * P + 8u * k) = v;
+        } else {
+            // unaligned raster (odd widths / pitches): texel by texel
+            for (uint32_t i = tid; i < slots * P; i += 256u) {
+                const uint32_t slot = i / P, k = i - slot * P;
+                const uint32_t x = uint32_t(xa) + k;
+                const global_u16 row = (global_u16)(data + uint64_t(ymin + int(slot)) * raster.pitch);
+                const uint16_t t = x < raster.width ? row[x] : uint16_t(1);
+                s_src[i] = t;
+                zmin.x = min(zmin.x, t);
+            }
         }
     }
-    __syncthreads();
-
-    // LDS offsets of this thread's four source columns
-    const uint32_t la0 = uint32_t(axa.i0 - xa), la1 = uint32_t(axa.i1 - xa), lb0 = uint32_t(axb.i0 - xa), lb1 = uint32_t(axb.i1 - xa);
-    auto fetch_row = [&](uint32_t slot, int y) -> Texel4 {
-        if (staged) {
-            const uint16_t* row = s_src + slot * P;
-            return convert4(row[la0], row[la1], row[lb0], row[lb1]);
-        }
-        const uint16_t* row = (const uint16_t*)(data + uint64_t(y) * raster.pitch);
-        return convert4(row[axa.i0], row[axa.i1], row[axb.i0], row[axb.i1]);
-    };
-    // one finest-LOD pixel pair from its top / bottom source rows
-    auto shade = [&](const Texel4& top, const Texel4& bot, float fy, uint32_t& va, uint32_t& vb) {
-        const float gy = 1.0f - fy;
-        va = float_to_unorm16((top.a0 * gxa + top.a1 * fxa) * gy + (bot.a0 * gxa + bot.a1 * fxa) * fy);
-        vb = float_to_unorm16((top.b0 * gxb + top.b1 * fxb) * gy + (bot.b0 * gxb + bot.b1 * fxb) * fy);
-    };
 
     uint16_t* tile5 = A.atlas + uint64_t(t5.self) * tile_texels;
     uint32_t* tile5_u32 = reinterpret_cast<uint32_t*>(tile5);
+
+    // staged source rows visible; has_nodata is workgroup-uniform (texels past the image edge were loaded from
+    // clamped addresses, so they are real texels too)
+    const bool has_nodata = __syncthreads_or((!kStaged) || zmin.x == 0 || zmin.y == 0) != 0;
+
+    if (A.ablate & 16u) return;  // debug: prologue + staging only
+
+    // LDS offsets of this thread's four source columns (idle lanes read column 0 and store nothing)
+    const uint32_t la0 = uint32_t(axa.i0 - xa), la1 = uint32_t(axa.i1 - xa), lb0 = uint32_t(axb.i0 - xa), lb1 = uint32_t(axb.i1 - xa);
+    auto fetch_row = [&](int y) -> Texel4 {
+        if constexpr (kStaged) {
+            const uint16_t* row = s_src + uint32_t(y - ymin) * P;
+            return convert4(row[la0], row[la1], row[lb0], row[lb1]);
+        } else {
+            const global_u16 row = (global_u16)(data + uint64_t(y) * raster.pitch);
+            return convert4(row[axa.i0], row[axa.i1], row[axb.i0], row[axb.i1]);
+        }
+    };
+
+    // ---- apron rows (first / last workgroup of a tile only), one row at a time.  Centre columns use the
+    // staged rows like any centre row; the b x b corners follow the diagonal neighbour alone
+    // (stitch.wgsl:57-66, 105-118) and take the general evaluation.
+    if ((own_top || own_bottom) && !is_idle) {
+        for (uint32_t r = 0; r < 2 * b; r++) {
+            const bool top = r < b;
+            if (top ? !own_top : !own_bottom) continue;
+            const uint32_t k = r % b, py = top ? k : o + k;
+            uint32_t va, vb;
+            if (is_centre) {
+                const int y0 = __builtin_amdgcn_readfirstlane(S.apron[r].y0), y1 = __builtin_amdgcn_readfirstlane(S.apron[r].y1);
+                const float fy = S.apron[r].fy, gy = 1.0f - fy;
+                const Texel4 t0 = fetch_row(y0), t1 = fetch_row(y1);
+                va = float_to_unorm16((t0.a0 * gxa + t0.a1 * fxa) * gy + (t1.a0 * gxa + t1.a1 * fxa) * fy);
+                vb = float_to_unorm16((t0.b0 * gxb + t0.b1 * fxb) * gy + (t1.b0 * gxb + t1.b1 * fxb) * fy);
+                if (min(min(t0.za, t1.za), min(t0.zb, t1.zb)) == 0) {
+                    const uint32_t nrow = top ? t5.n : t5.s;
+                    const uint16_t* h = A.atlas + uint64_t(nrow == kInvalid ? t5.self : nrow) * tile_texels + (b + S.apron[r].pad) * T + b;
+                    if (min(t0.za, t1.za) == 0) va = h[rxa];
+                    if (min(t0.zb, t1.zb) == 0) vb = h[rxb];
+                }
+            } else {
+                const uint32_t n = grid_lookup(A, it.side, A.lod, int(it.x) + (is_left ? -1 : 1), int(it.y) + (top ? -1 : 1));
+                uint32_t v[2];
+#pragma unroll
+                for (uint32_t e = 0; e < 2; e++) {
+                    const uint32_t pxk = px0 + e;
+                    if (n != kInvalid)
+                        v[e] = split_value_slow(A, raster, is_left ? it.x - 1 : it.x + 1, is_left ? c - b + pxk : pxk - o,
+                                                top ? it.y - 1 : it.y + 1, top ? c - b + k : k, n);
+                    else
+                        v[e] = split_value_slow(A, raster, it.x, is_left ? 0u : c - 1, it.y, top ? 0u : c - 1, t5.self);
+                }
+                va = v[0];
+                vb = v[1];
+            }
+            tile5_u32[(py * T + px0) >> 1] = va | (vb << 16);
+        }
+    }
+
     uint16_t* tile4 = A.atlas + uint64_t(self4 == kInvalid ? 0u : self4) * tile_texels;
     uint16_t* tile3 = A.atlas + uint64_t(self3 == kInvalid ? 0u : self3) * tile_texels;
     const uint32_t cx4 = (it.x & 1u) * half_c + tid, cy4_base = (it.y & 1u) * half_c;
     const uint32_t cx3 = (it.x & 3u) * (c / 4) + (tid >> 1), cy3_base = (it.y & 3u) * (c / 4);
+    const bool do4 = A.levels >= 2 && !(A.ablate & 1u), do3 = A.levels >= 3 && !(A.ablate & 1u);
+    PushX px4{}, px3{};
+    if (do4 && is_centre) px4 = make_push_x(A, S.nb[0], cx4);
+    if (do3 && is_centre) px3 = make_push_x(A, S.nb[1], cx3);
 
-    Texel4 prev{};
-    uint32_t prev_slot = kInvalid;
-    uint32_t q_even = 0;  // level-1 value of the even row pair of the current quad
-
-    for (uint32_t j = 0; j < nrows; j += 2) {
-        const uint32_t py = py_begin + j;
-        const bool apron_rows = py < b || py >= o;  // b is even: a row pair never straddles the centre edge
-        uint32_t va0 = 0, vb0 = 0, va1 = 0, vb1 = 0;    // pixels of row j (0) and row j + 1 (1)
-        if (is_idle) {
-            // nothing
-        } else if (apron_rows && !is_centre) {
-            // b x b corner: governed by the diagonal neighbour alone (stitch.wgsl:57-66, 105-118)
-            const bool top = py < b;
-            const uint32_t n = grid_lookup(A, it.side, A.lod, int(it.x) + (is_left ? -1 : 1), int(it.y) + (top ? -1 : 1));
-            uint32_t v[4];
+    if (kStaged && !has_nodata && !(A.ablate & 32u)) {
+        // ---- fast loop: the window has no no-data texel, so every pixel of every LOD is valid (a blend of
+        // non-zero texels is >= 1/65535) and no validity bookkeeping is needed.  Two columns ride in the two
+        // lanes of packed f32 instructions; the horizontal blend of a source row is computed once and
+        // serves both output rows that touch it.  Same operations, same order as the generic loop below.
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 gx = {gxa, gxb}, fx = {fxa, fxb};
+        const f2 kr = {1.0f / 65535.0f, 1.0f / 65535.0f}, kn = {65535.0f, 65535.0f}, khalf = {0.5f, 0.5f};
+        const f2 kzero = {0.0f, 0.0f}, kone = {1.0f, 1.0f}, kquarter = {0.25f, 0.25f};
+        auto conv2 = [&](uint32_t ta, uint32_t tb) -> f2 {  // (ta, tb) / 65535, correctly rounded (see header)
+            const f2 x = {float(ta), float(tb)};
+            const f2 q0 = x * kr;
+            const f2 e = __builtin_elementwise_fma(-q0, kn, x);
+            return __builtin_elementwise_fma(e, kr, q0);
+        };
+        auto hblend = [&](int y) -> f2 {  // (mix(t00, t10, fx) for column a, same for column b) of source row y
+            const uint16_t* row = s_src + uint32_t(y - ymin) * P;
+            const f2 left = conv2(row[la0], row[lb0]), right = conv2(row[la1], row[lb1]);
+            return left * gx + right * fx;
+        };
+        auto quantise = [&](f2 v) -> f2 {  // 0.5 + 65535 * clamp(v, 0, 1); the u32 conversion then floors
+            const f2 cl = __builtin_elementwise_min(__builtin_elementwise_max(v, kzero), kone);
+            return khalf + kn * cl;
+        };
+        f2 hcur = kzero;
+        int hy = -1;
+        for (uint32_t q = 0; q < nrows; q += 4) {
+            uint32_t ua[4], ub[4];
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const uint32_t pxk = px0 + (k & 1u), pyk = py + (k >> 1);
-                uint32_t tx, rx, ty, ry, home;
-                if (n != kInvalid) {
-                    tx = is_left ? it.x - 1 : it.x + 1;
-                    rx = is_left ? c - b + pxk : pxk - o;
-                    ty = top ? it.y - 1 : it.y + 1;
-                    ry = top ? c - b + pyk : pyk - o;
-                    home = n;
-                } else {
-                    tx = it.x;
-                    rx = is_left ? 0u : c - 1;
-                    ty = it.y;
-                    ry = top ? 0u : c - 1;
-                    home = t5.self;
-                }
-                v[k] = split_value_slow(A, raster, tx, rx, ty, ry, home);
+            for (uint32_t i = 0; i < 4; i++) {
+                const int y0 = __builtin_amdgcn_readfirstlane(S.rows[q + i].y0);
+                const int y1 = __builtin_amdgcn_readfirstlane(S.rows[q + i].y1);
+                const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, S.rows[q + i].fy)));
+                const f2 top = (y0 == hy) ? hcur : hblend(y0);
+                const f2 bot = (y1 == y0) ? top : hblend(y1);
+                hcur = bot;
+                hy = y1;
+                const f2 fy2 = {fy, fy}, gy2 = {1.0f - fy, 1.0f - fy};
+                const f2 w = quantise(top * gy2 + bot * fy2);
+                ua[i] = uint32_t(w.x);
+                ub[i] = uint32_t(w.y);
             }
-            va0 = v[0];
-            vb0 = v[1];
-            va1 = v[2];
-            vb1 = v[3];
-        } else {
-            const uint32_t a0 = S.slot0[j], a1 = S.slot1[j], b0s = S.slot0[j + 1], b1s = S.slot1[j + 1];
-            const Texel4 r0 = (a0 == prev_slot) ? prev : fetch_row(a0, S.y0[j]);
-            const Texel4 r1 = (a1 == a0) ? r0 : fetch_row(a1, S.y1[j]);
-            const Texel4 r2 = (b0s == a1) ? r1 : ((b0s == a0) ? r0 : fetch_row(b0s, S.y0[j + 1]));
-            const Texel4 r3 = (b1s == b0s) ? r2 : fetch_row(b1s, S.y1[j + 1]);
-            prev = r3;
-            prev_slot = b1s;
-            shade(r0, r1, S.fy[j], va0, vb0);
-            shade(r2, r3, S.fy[j + 1], va1, vb1);
-            const bool z0a = r0.za || r1.za, z0b = r0.zb || r1.zb, z1a = r2.za || r3.za, z1b = r2.zb || r3.zb;
-            if (z0a || z0b || z1a || z1b) {  // no data in a footprint: those pixels keep their previous atlas value (split.wgsl:37-42)
-                const uint32_t home = apron_rows ? (py < b ? t5.n : t5.s) : home_col;
-                const uint32_t hi = home == kInvalid ? t5.self : home;
-                const uint16_t* h0 = A.atlas + uint64_t(hi) * tile_texels + (b + S.ry[j]) * T + b;
-                const uint16_t* h1 = A.atlas + uint64_t(hi) * tile_texels + (b + S.ry[j + 1]) * T + b;
-                if (z0a) va0 = h0[rxa];
-                if (z0b) vb0 = h0[rxb];
-                if (z1a) va1 = h1[rxa];
-                if (z1b) vb1 = h1[rxb];
+            const uint32_t py = b + cr0 + q;
+            if (!is_idle && !(A.ablate & 2u)) {
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) tile5_u32[((py + i) * T + px0) >> 1] = ua[i] | (ub[i] << 16);
+            }
+            if (do4) {
+                // two level-1 pixels (row pairs 0-1 and 2-3) in the two packed lanes: ((a0 + a1) + b0) + b1, then / 4
+                const f2 s = ((conv2(ua[0], ua[2]) + conv2(ua[1], ua[3])) + conv2(ub[0], ub[2])) + conv2(ub[1], ub[3]);
+                const f2 wq = quantise(s * kquarter);
+                const uint32_t q0 = uint32_t(wq.x), q1 = uint32_t(wq.y);
+                const uint32_t cy = cr0 + q, cy4 = cy4_base + (cy >> 1);
+                const bool edge4 = cy4 < b || cy4 + 2 > c - b;  // uniform: the row pair touches the parent's top / bottom strip
+                if (is_centre) {
+                    if (edge4) {
+                        push_pixel_lds(A, S.nb[0], tile4, cx4, cy4, uint16_t(q0));
+                        push_pixel_lds(A, S.nb[0], tile4, cx4, cy4 + 1, uint16_t(q1));
+                    } else {
+                        push_fast(A, px4, tile4, cy4, uint16_t(q0));
+                        push_fast(A, px4, tile4, cy4 + 1, uint16_t(q1));
+                    }
+                }
+                if (do3) {
+                    const uint32_t other0 = __shfl_xor(q0, 1), other1 = __shfl_xor(q1, 1);
+                    if (is_centre && (tid & 1u) == 0) {
+                        const f2 mine = conv2(q0, q1), theirs = conv2(other0, other1);
+                        const float s3 = ((mine.x + mine.y) + theirs.x) + theirs.y;
+                        const uint32_t w3 = float_to_unorm16(s3 * 0.25f);
+                        const uint32_t cy3 = cy3_base + (cy >> 2);
+                        if (cy3 < b || cy3 >= c - b) push_pixel_lds(A, S.nb[1], tile3, cx3, cy3, uint16_t(w3));
+                        else push_fast(A, px3, tile3, cy3, uint16_t(w3));
+                    }
+                }
             }
         }
-        if (!is_idle) {
-            tile5_u32[(py * T + px0) >> 1] = va0 | (vb0 << 16);
-            tile5_u32[((py + 1) * T + px0) >> 1] = va1 | (vb1 << 16);
+        return;
+    }
+
+    Texel4 cur{};
+    int cur_y = -1;
+    for (uint32_t q = 0; q < nrows; q += 4) {
+        uint32_t va[4], vb[4];
+        uint32_t zany = 1;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            // row parameters are workgroup-uniform: scalarise them so the reuse tests are scalar branches
+            const int y0 = __builtin_amdgcn_readfirstlane(S.rows[q + i].y0);
+            const int y1 = __builtin_amdgcn_readfirstlane(S.rows[q + i].y1);
+            const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, S.rows[q + i].fy)));
+            const Texel4 top = (y0 == cur_y) ? cur : fetch_row(y0);
+            const Texel4 bot = (y1 == y0) ? top : fetch_row(y1);
+            cur = bot;
+            cur_y = y1;
+            const float gy = 1.0f - fy;
+            if (A.ablate & 4u) {
+                va[i] = uint32_t(top.a0 + bot.a0);
+                vb[i] = uint32_t(top.b1 + bot.b1);
+            } else {
+                va[i] = float_to_unorm16((top.a0 * gxa + top.a1 * fxa) * gy + (bot.a0 * gxa + bot.a1 * fxa) * fy);
+                vb[i] = float_to_unorm16((top.b0 * gxb + top.b1 * fxb) * gy + (bot.b0 * gxb + bot.b1 * fxb) * fy);
+            }
+            const uint32_t za = min(top.za, bot.za), zb = min(top.zb, bot.zb);
+            zany = min(zany, min(za, zb));
+            // remember the validity in bit 16 (cleared below): 0x10000 = no data in the footprint
+            va[i] |= za == 0 ? 0x10000u : 0u;
+            vb[i] |= zb == 0 ? 0x10000u : 0u;
+        }
+        if (zany == 0) {  // some footprint had no data: those pixels keep their previous atlas value (split.wgsl:37-42)
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) {
+                const uint16_t* h = A.atlas + uint64_t(home_col) * tile_texels + (b + cr0 + q + i) * T + b;
+                if (va[i] & 0x10000u) va[i] = h[rxa];
+                if (vb[i] & 0x10000u) vb[i] = h[rxb];
+            }
+        }
+        const uint32_t py = b + cr0 + q;
+        if (!is_idle && (!(A.ablate & 2u) || va[0] == 0x12345u)) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) tile5_u32[((py + i) * T + px0) >> 1] = (va[i] & 0xFFFFu) | (vb[i] << 16);
         }
 
-        // ---- next two LODs from the centre pixels: the row pair gives one level-1 pixel per thread, two row
-        // pairs and a lane pair give one level-2 pixel per even lane
-        if (A.levels >= 2 && !apron_rows) {
-            const uint32_t cy = py - b;  // even
-            const uint32_t q = downsample4(va0, va1, vb0, vb1);  // OFFSETS (0,0),(0,1),(1,0),(1,1) of (dx, dy)
-            if (is_centre) push_pixel_lds(A, S.nb[0], tile4, cx4, cy4_base + (cy >> 1), uint16_t(q));
-            if (A.levels >= 3) {
-                if ((cy & 2u) == 0) {
-                    q_even = q;
+        // ---- next two LODs from the centre pixels: two row pairs give two level-1 pixels per thread, which a
+        // lane pair combines into one level-2 pixel
+        if (do4) {
+            const uint32_t cy = cr0 + q;  // multiple of 4
+            const uint32_t q0 = downsample4(va[0] & 0xFFFFu, va[1] & 0xFFFFu, vb[0] & 0xFFFFu, vb[1] & 0xFFFFu);  // OFFSETS order
+            const uint32_t q1 = downsample4(va[2] & 0xFFFFu, va[3] & 0xFFFFu, vb[2] & 0xFFFFu, vb[3] & 0xFFFFu);
+            const uint32_t cy4 = cy4_base + (cy >> 1);
+            const bool edge4 = cy4 < b || cy4 + 2 > c - b;  // uniform: the row pair touches the parent tile's top / bottom strip
+            if (is_centre) {
+                if (edge4) {
+                    push_pixel_lds(A, S.nb[0], tile4, cx4, cy4, uint16_t(q0));
+                    push_pixel_lds(A, S.nb[0], tile4, cx4, cy4 + 1, uint16_t(q1));
                 } else {
-                    const uint32_t other_even = __shfl_xor(q_even, 1), other_odd = __shfl_xor(q, 1);
-                    if (is_centre && (tid & 1u) == 0) {
-                        const uint32_t w = downsample4(q_even, q, other_even, other_odd);
-                        push_pixel_lds(A, S.nb[1], tile3, cx3, cy3_base + (cy >> 2), uint16_t(w));
-                    }
+                    push_fast(A, px4, tile4, cy4, uint16_t(q0));
+                    push_fast(A, px4, tile4, cy4 + 1, uint16_t(q1));
+                }
+            }
+            if (do3) {
+                const uint32_t other0 = __shfl_xor(q0, 1), other1 = __shfl_xor(q1, 1);
+                if (is_centre && (tid & 1u) == 0) {
+                    const uint32_t w = downsample4(q0, q1, other0, other1);
+                    const uint32_t cy3 = cy3_base + (cy >> 2);
+                    if (cy3 < b || cy3 >= c - b) push_pixel_lds(A, S.nb[1], tile3, cx3, cy3, uint16_t(w));
+                    else push_fast(A, px3, tile3, cy3, uint16_t(w));
                 }
             }
         }
@@ -722,6 +882,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
 
         FusedArgs args{};
         args.m = m;
+        if (const char* e = getenv("BT_FUSED_ABLATE")) args.ablate = uint32_t(atoi(e));
         args.atlas = (uint16_t*)at.level0;
         args.rasters = p->rasters_dev;  // (re)allocated by bt_preprocessor_run before the first launch
         args.tlx = splits[0]->tl[0];
@@ -769,11 +930,13 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             }
             const uint32_t rows = std::min(kMainRows, m.center_size) + 2 * m.border_size;
             const uint64_t cols_needed = uint64_t(double(m.texture_size - 1) * ratio_x) + 4 + 7;
-            const uint64_t rows_needed = std::min<uint64_t>(2 * rows, uint64_t(double(rows - 1) * ratio_y) + 4);
+            const uint64_t rows_needed = uint64_t(double(rows - 1) * ratio_y) + 4;  // contiguous source-row range
             const uint64_t pitch = (cols_needed + 7) / 8 * 8;
             const uint64_t budget = 65536 - sizeof(MainShared);
-            main_job.args.lds_pitch = uint32_t(std::min<uint64_t>(pitch, 4096));
-            main_job.args.lds_rows = uint32_t(std::min<uint64_t>(rows_needed, budget / (2 * uint64_t(main_job.args.lds_pitch))));
+            main_job.args.lds_pitch = uint32_t(std::min<uint64_t>(pitch, 1u << 20));
+            // the whole window must fit (the bounds above are conservative); otherwise lds_rows = 0 selects the
+            // kernel variant that reads the source directly
+            main_job.args.lds_rows = rows_needed * pitch * 2 <= budget ? uint32_t(rows_needed) : 0u;
         }
         Launch lm{};
         lm.kind = kLaunchFusedMain;
@@ -851,8 +1014,12 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
     job.args.rasters = p->rasters_dev;
     if (l.kind == kLaunchFusedMain) {
         const uint32_t blocks = job.args.item_count * job.args.groups;
-        const size_t lds = sizeof(MainShared) + size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
-        fused_main_kernel<<<blocks, 256, lds, p->ctx->stream>>>(job.args);
+        if (job.args.lds_rows) {
+            const size_t lds = sizeof(MainShared) + size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
+            fused_main_kernel<true><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
+        } else {
+            fused_main_kernel<false><<<blocks, 256, sizeof(MainShared), p->ctx->stream>>>(job.args);
+        }
     } else {
         const uint32_t size = (1u << job.args.lod) * job.args.m.center_size;
         const dim3 grid((size + 31) / 32, (size + 31) / 32, job.args.sides);
