@@ -116,7 +116,7 @@ def main():
 
     def step(profile=False):
         if job is not None:
-            job.step()
+            job.step(profile)
         else:
             pre.run(atlas, generic=args.generic, keep_queue=True, sync=False, profile=profile)
 

@@ -16,7 +16,7 @@ INVALID_ATLAS_INDEX = 0xFFFFFFFF
 MAX_ATTACHMENTS = 8
 
 BT_OK = 0
-RUN_AUTO, RUN_GENERIC, RUN_KEEP_QUEUE, RUN_PROFILE = 0, 1, 2, 4
+RUN_AUTO, RUN_GENERIC, RUN_KEEP_QUEUE, RUN_PROFILE, RUN_SHARD_LOCAL, RUN_SHARD_FINISH = 0, 1, 2, 4, 8, 16
 
 
 class BtError(RuntimeError):
@@ -61,6 +61,11 @@ class SphericalDatasetC(C.Structure):
 class RunStatsC(C.Structure):
     _fields_ = [("kernel_launches", C.c_uint32), ("tiles", C.c_uint32), ("algorithmic_bytes", C.c_uint64),
                 ("fused_jobs", C.c_uint32), ("generic_jobs", C.c_uint32)]
+
+
+class ShardRangeC(C.Structure):
+    _fields_ = [("attachment_index", C.c_uint32), ("side", C.c_uint32), ("lod", C.c_uint32), ("first_layer", C.c_uint32),
+                ("layers_per_rank", C.c_uint32)]
 
 
 class LaunchProfileC(C.Structure):
@@ -131,6 +136,8 @@ PROTOTYPES = {
     "bt_preprocessor_run": (_i32, [_vp, _vp, _u32]),
     "bt_preprocessor_save": (_i32, [_vp, _vp, C.c_char_p]),
     "bt_preprocessor_last_run_stats": (_i32, [_vp, _P(RunStatsC)]),
+    "bt_preprocessor_set_shard": (_i32, [_vp, _u32, _u32]),
+    "bt_preprocessor_shard_ranges": (_i32, [_vp, _P(ShardRangeC), _u32, _P(_u32)]),
     "bt_preprocessor_profile": (_i32, [_vp, _P(LaunchProfileC), _u32, _P(_u32)]),
     "bt_tiling_prepass_create": (_i32, [_vp, _u32, _P(_vp)]),
     "bt_tiling_prepass_destroy": (None, [_vp]),

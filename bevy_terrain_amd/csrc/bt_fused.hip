@@ -33,7 +33,7 @@ namespace bt {
 namespace {
 
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
-constexpr uint32_t kMainRows = 16;               // centre rows per fused_main workgroup (multiple of 4)
+constexpr uint32_t kMainRows = 32;               // centre rows per fused_main workgroup (multiple of 4)
 constexpr uint32_t kMaxBorder = 8;
 
 struct MainItem {  // one finest-LOD tile
@@ -877,8 +877,34 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             if (t->tl[0] != splits[0]->tl[0] || t->tl[1] != splits[0]->tl[1] || t->br[0] != splits[0]->br[0] || t->br[1] != splits[0]->br[1])
                 return false;
 
+        // ---- sharding (multi-GPU): rank r owns the columns [r * n / world, (r + 1) * n / world) of every LOD the
+        // main kernel produces; those tiles are contiguous atlas layers (x-major allocation order)
+        const uint32_t world = p->shard_world, rank = p->shard_rank;
+        const uint32_t nlods_all = lod_hi - lod_lo + 1, main_levels_all = std::min(3u, nlods_all);
+        bool shard = world > 1 && ((1u << (lod_hi - (main_levels_all - 1))) % world) == 0;
+        std::vector<bt_shard_range> ranges;
+        if (shard) {
+            for (uint32_t side = 0; side < sides && shard; side++)
+                for (uint32_t k = 0; k < main_levels_all && shard; k++) {
+                    const uint32_t lod = lod_hi - k, n = 1u << lod;
+                    const uint32_t off = grid_offsets[side * 32 + lod];
+                    const uint32_t base = grids[off];
+                    for (size_t i = 0; i < size_t(n) * n; i++)
+                        if (base == kInvalid || grids[off + i] != base + i) shard = false;  // not the fresh x-major layout
+                    ranges.push_back({ai, side, lod, base, n / world * n});
+                }
+        }
+        if (world > 1 && !shard) ranges.clear();
+
         std::vector<MainItem> items;
-        for (const Task* t : splits) items.push_back({t->coord.side, t->coord.x, t->coord.y, t->atlas_index, uint32_t(t->raster)});
+        for (const Task* t : splits) {
+            if (shard) {
+                const uint32_t per = (1u << lod_hi) / world;
+                if (t->coord.x / per != rank) continue;
+            }
+            items.push_back({t->coord.side, t->coord.x, t->coord.y, t->atlas_index, uint32_t(t->raster)});
+        }
+        if (shard) p->shard_ranges.insert(p->shard_ranges.end(), ranges.begin(), ranges.end());
 
         FusedArgs args{};
         args.m = m;
@@ -948,6 +974,34 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         jobs.push_back(main_job);
         plan.push_back(lm);
 
+        if (shard && main_levels > 1) {
+            // the parent / grand-parent tiles received their cross-strip aprons in another rank's memory:
+            // after the all-gather every rank re-stitches those LODs from the (now complete) centres
+            const uint32_t first = uint32_t(tasks.size());
+            for (const Task* t : stitches) {
+                if (t->coord.lod == lod_hi || t->coord.lod + main_levels <= lod_hi) continue;
+                TaskDev d{};
+                d.atlas_index = t->atlas_index;
+                d.side = t->coord.side;
+                d.lod = t->coord.lod;
+                d.x = t->coord.x;
+                d.y = t->coord.y;
+                for (int i = 0; i < 8; i++) {
+                    d.rel_index[i] = t->rel[i].atlas_index;
+                    d.rel_side[i] = t->rel[i].coordinate.side;
+                }
+                tasks.push_back(d);
+            }
+            Launch ls{};
+            ls.kind = kLaunchStitch;
+            ls.attachment = ai;
+            ls.first_task = first;
+            ls.task_count = uint32_t(tasks.size()) - first;
+            ls.algorithmic_bytes = uint64_t(ls.task_count) * 2 * (2 * m.border_size * (Tt + cc)) * bpp;
+            ls.phase = 2;
+            if (ls.task_count) plan.push_back(ls);
+        }
+
         // tail launches: three LODs at a time below the last fused one
         uint32_t in_lod = lod_hi - (main_levels - 1);
         while (in_lod > lod_lo) {
@@ -959,6 +1013,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             lt.kind = kLaunchFusedTail;
             lt.attachment = ai;
             lt.aux0 = uint32_t(jobs.size());
+            lt.phase = shard ? 2u : 0u;
             lt.algorithmic_bytes = tiles_at(in_lod) * cc * cc * bpp;
             for (uint32_t k = 1; k <= levels; k++) {
                 lt.algorithmic_bytes += tiles_at(in_lod - k) * Tt * Tt * bpp;
@@ -993,6 +1048,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             ls.first_task = first;
             ls.task_count = uint32_t(tasks.size()) - first;
             ls.algorithmic_bytes = uint64_t(ls.task_count) * 2 * (2 * m.border_size * (Tt + cc)) * bpp;
+            ls.phase = shard ? 2u : 0u;
             if (ls.task_count) plan.push_back(ls);
         }
     }

@@ -135,6 +135,7 @@ struct Launch {
     uint32_t first_task, task_count;  // into the device task array
     uint32_t aux0 = 0, aux1 = 0;
     uint64_t algorithmic_bytes = 0;  // inputs read once + outputs written once
+    uint32_t phase = 0;              // sharded runs: 0 = BT_RUN_SHARD_LOCAL part, 2 = BT_RUN_SHARD_FINISH part
 };
 
 // host-side launchers implemented in bt_kernels.hip
@@ -162,6 +163,8 @@ struct bt_preprocessor {
     bool save_pending[BT_MAX_ATTACHMENTS] = {};
     std::vector<bt::Raster> rasters;
     uint32_t jobs = 0;
+    uint32_t shard_rank = 0, shard_world = 1;
+    std::vector<bt_shard_range> shard_ranges;
     // compiled plan (rebuilt when the queue changes)
     bool compiled = false;
     uint32_t compiled_flags = 0;

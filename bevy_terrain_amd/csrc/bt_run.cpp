@@ -108,6 +108,7 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
     if (!p->compiled || p->compiled_flags != mode) {
         std::vector<TaskDev> tasks;
         p->plan.clear();
+        p->shard_ranges.clear();
         bool fused = false;
         if (!mode) fused = fused_plan(p, a, tasks, p->plan);
         if (!fused) {
@@ -159,7 +160,17 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
     if (profile)
         if (bt_status s = record()) return s;
 
+    const bool sharded = p->shard_world > 1;
+    if (sharded && !(flags & (BT_RUN_SHARD_LOCAL | BT_RUN_SHARD_FINISH))) {
+        set_error("a sharded preprocessor runs with BT_RUN_SHARD_LOCAL and / or BT_RUN_SHARD_FINISH");
+        return BT_ERR_INVALID_ARGUMENT;
+    }
     for (const Launch& l : p->plan) {
+        if (sharded && !(flags & (l.phase == 2 ? BT_RUN_SHARD_FINISH : BT_RUN_SHARD_LOCAL))) {
+            if (profile)
+                if (bt_status s2 = record()) return s2;
+            continue;
+        }
         const Attachment& at = a->attachments[l.attachment];
         bt_status s = BT_OK;
         switch (l.kind) {
@@ -219,5 +230,20 @@ extern "C" bt_status bt_preprocessor_profile(bt_preprocessor* p, bt_launch_profi
     for (hipEvent_t e : p->events) hipEventDestroy(e);
     p->events.clear();
     p->profiled_runs = 0;
+    return BT_OK;
+}
+
+extern "C" bt_status bt_preprocessor_set_shard(bt_preprocessor* p, uint32_t rank, uint32_t world) {
+    if (!p || world == 0 || rank >= world) return BT_ERR_INVALID_ARGUMENT;
+    if (p->shard_rank != rank || p->shard_world != world) p->compiled = false;
+    p->shard_rank = rank;
+    p->shard_world = world;
+    return BT_OK;
+}
+
+extern "C" bt_status bt_preprocessor_shard_ranges(const bt_preprocessor* p, bt_shard_range* out, uint32_t cap, uint32_t* count) {
+    if (!p || !count) return BT_ERR_INVALID_ARGUMENT;
+    *count = uint32_t(p->shard_ranges.size());
+    for (uint32_t i = 0; i < *count && i < cap && out; i++) out[i] = p->shard_ranges[i];
     return BT_OK;
 }

@@ -201,6 +201,8 @@ enum {
     BT_RUN_GENERIC = 1, /* one batched launch per queue phase: split / downsample / stitch */
     BT_RUN_KEEP_QUEUE = 2, /* do not clear the queue (benchmarks re-run the same queue) */
     BT_RUN_PROFILE = 4,    /* record a hipEvent after every launch; read with bt_preprocessor_profile() */
+    BT_RUN_SHARD_LOCAL = 8,   /* sharded run, part 1: this rank's column strip of the finest LODs (no collective) */
+    BT_RUN_SHARD_FINISH = 16, /* sharded run, part 2 (after the all-gathers): cross-strip aprons + the top LODs */
 };
 /* Replaces select_ready_tasks + GpuPreprocessor::prepare + TerrainPreprocessNode::run for the whole
  * queue: enqueues every kernel on the context's stream and returns (asynchronous).  Save tasks are
@@ -218,6 +220,21 @@ typedef struct bt_run_stats {
     uint32_t fused_jobs, generic_jobs;
 } bt_run_stats;
 bt_status bt_preprocessor_last_run_stats(const bt_preprocessor* p, bt_run_stats* out);
+/* Multi-GPU: tiles shard by column strips of the finest LODs (new design, the reference is single-GPU;
+ * SURVEY.md §8e).  Every rank builds the SAME queue (same atlas indices), calls set_shard(rank, world),
+ * runs BT_RUN_SHARD_LOCAL, all-gathers each returned range IN PLACE over its atlas storage
+ * (ncclAllGather with sendbuff = recvbuff + rank * count: layers [first_layer + r * layers_per_rank, ...) hold
+ * rank r's tiles because atlas indices are x-major), then runs BT_RUN_SHARD_FINISH.  Every rank ends with the
+ * full atlas, bit-identical to a single-GPU run.  world == 1 restores the normal behaviour. */
+typedef struct bt_shard_range {
+    uint32_t attachment_index, side, lod;
+    uint32_t first_layer;     /* atlas index of tile (x = 0, y = 0) of this (side, lod) */
+    uint32_t layers_per_rank; /* contiguous layers owned by each rank */
+} bt_shard_range;
+bt_status bt_preprocessor_set_shard(bt_preprocessor* p, uint32_t rank, uint32_t world);
+/* valid after the first run of the current queue; *count = 0 means "not sharded: every rank computed everything" */
+bt_status bt_preprocessor_shard_ranges(const bt_preprocessor* p, bt_shard_range* out, uint32_t cap, uint32_t* count);
+
 /* Per-launch device time of the runs made with BT_RUN_PROFILE since the last call (hipEvents on the
  * context's stream, averaged over those runs).  `kind`: 0 split, 1 downsample, 2 stitch, 3 fused main,
  * 4 fused tail.  `algorithmic_bytes`: that launch's inputs read once + outputs written once.
