@@ -174,8 +174,22 @@ def main():
     }
     if dominant:
         achieved = dominant["algorithmic_bytes"] / (dominant["avg_ms"] / 1e3) / 1e9
+        # HBM bytes per launch from the PMC passes of the same command (rocprofv3 cannot run inside this
+        # process): the newest committed summary under profiles/ that knows this kernel, else null
+        traffic, traffic_source = None, None
+        import glob
+
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+            try:
+                summary = json.load(open(path))
+                traffic = summary[dominant["kind"]]["hbm_traffic_bytes"]["total"]
+                traffic_source = os.path.relpath(path, ROOT)
+                break
+            except (KeyError, ValueError, OSError):
+                continue
         line["roofline"] = {"bound": "hbm", "kernel": dominant["kind"], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                            "traffic_source": traffic_source,
                             "avg_launch_ms": dominant["avg_ms"], "algorithmic_bytes_per_launch": dominant["algorithmic_bytes"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"], oracle, shape = cpu_baseline(device, src_ptr)
