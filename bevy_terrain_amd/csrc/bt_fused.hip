@@ -33,7 +33,7 @@ namespace bt {
 namespace {
 
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
-constexpr uint32_t kMainRows = 32;               // centre rows per fused_main workgroup (multiple of 4)
+constexpr uint32_t kMainRows = 8;                // centre rows per fused_main workgroup (multiple of 4)
 constexpr uint32_t kMaxBorder = 8;
 
 struct MainItem {  // one finest-LOD tile
@@ -55,6 +55,7 @@ struct FusedArgs {
     uint32_t sides;       // fused_tail: 1 or 6
     uint32_t lds_pitch;   // fused_main: texels per staged source row (multiple of 8)
     uint32_t lds_rows;    // fused_main: staged source rows that fit
+    uint32_t* todo;       // fused_main: [0] count, [1] finished workgroups, [2..] chunks (item * chunks_per_tile + k) left to the generic variant
     uint32_t ablate;      // debug only (env BT_FUSED_ABLATE): 1 no pyramid, 2 no finest stores, 4 no shading, 8 no staging loads, 16 prologue only, 32 no packed fast loop
 };
 
@@ -233,7 +234,7 @@ struct RowParam {  // one centre row of the workgroup: LDS slots of its two sour
 };
 
 struct MainShared {  // fixed part of the dynamic LDS block (size is a multiple of 16 bytes)
-    RowParam rows[kMainRows];
+    RowParam rows[2][kMainRows];  // double buffered: chunk k uses rows[k & 1]
     RowParam apron[2 * kMaxBorder];  // [0, b): top apron rows, [b, 2b): bottom apron rows (pad = mosaic row ry)
     uint32_t nb[2][8];  // neighbours (N,E,S,W,NW,NE,SE,SW) of the parent [0] and grand-parent [1] tile
     int xmin, xmax;
@@ -343,35 +344,44 @@ __device__ __forceinline__ Texel4 convert4(uint32_t ta0, uint32_t ta1, uint32_t 
     return r;
 }
 
-template <bool kStaged>
-__global__ __launch_bounds__(256) void fused_main_kernel(FusedArgs A) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// kGeneric == false: the fast variant (packed f32, no validity bookkeeping).  A chunk whose source window holds a
+// no-data texel is not processed but appended to A.todo; the kGeneric == true variant then runs exactly those
+// chunks with per-pixel validity, the keep-previous rule and the valid-average.  (Keeping both loops in one kernel
+// costs ~90 spilled VGPRs at the 4-waves-per-SIMD budget.)  kStaged == false reads the source directly (window too
+// large for LDS) and always takes the generic loop.
+template <bool kStaged, bool kGeneric>
+__device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t item_index, uint32_t k_begin, uint32_t k_end, uint8_t* smem) {
     MainShared& S = *reinterpret_cast<MainShared*>(smem);
     uint16_t* s_src = reinterpret_cast<uint16_t*>(smem + sizeof(MainShared));
 
-    const uint32_t work = xcd_remap(blockIdx.x, gridDim.x);
-    const MainItem it = A.items[work / A.groups];
-    const uint32_t g = work % A.groups;
+    // A workgroup is persistent over a run of row chunks (kMainRows centre rows each) of ONE finest tile:
+    // the column parameters, neighbour tables and push constants are computed once, and while chunk k is
+    // shaded out of LDS the source rows of chunk k + 1 are already in flight into registers.
+    const MainItem it = A.items[item_index];
     const RasterDev raster = A.rasters[it.raster];
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
     const uint32_t tid = threadIdx.x;
     const float scale = float(1u << A.lod);
     const uint32_t tile_texels = T * T;
+    const uint32_t chunks_per_tile = (c + kMainRows - 1) / kMainRows;
 
     const TileNb t5 = load_tile_nb(A, it.side, A.lod, it.x, it.y);
     const uint32_t self4 = A.levels >= 2 ? grid_lookup(A, it.side, A.lod - 1, int(it.x >> 1), int(it.y >> 1)) : kInvalid;
     const uint32_t self3 = A.levels >= 3 ? grid_lookup(A, it.side, A.lod - 2, int(it.x >> 2), int(it.y >> 2)) : kInvalid;
 
-    // centre rows of this workgroup (a multiple of 4: c and kMainRows are)
-    const uint32_t cr0 = g * kMainRows, cr1 = min(c, cr0 + kMainRows);
-    const uint32_t nrows = cr1 - cr0;
-
-    if (tid < nrows) {
-        const Axis ay = split_axis(cr0 + tid, c, it.y, scale, A.tly, A.bry, raster.height);
-        S.rows[tid].y0 = ay.i0;
-        S.rows[tid].y1 = ay.i1;
-        S.rows[tid].fy = ay.fr;
-    } else if (tid >= 32 && tid < 32 + 2 * b) {
+    // row parameters of chunk k -> S.rows[k & 1]
+    auto fill_rows = [&](uint32_t k) {
+        const uint32_t cr = k * kMainRows + tid;
+        if (tid < kMainRows && cr < c) {
+            const Axis ay = split_axis(cr, c, it.y, scale, A.tly, A.bry, raster.height);
+            RowParam& r = S.rows[k & 1u][tid];
+            r.y0 = ay.i0;
+            r.y1 = ay.i1;
+            r.fy = ay.fr;
+        }
+    };
+    fill_rows(k_begin);
+    if (tid >= 32 && tid < 32 + 2 * b) {
         // apron rows: the north / south neighbour's centre rows, or (neighbour absent) clamped into the own centre
         const uint32_t r = tid - 32, k = r % b;
         const bool top = r < b;
@@ -426,124 +436,74 @@ __global__ __launch_bounds__(256) void fused_main_kernel(FusedArgs A) {
     if (tid == half_c + half_b - 1) S.xmax = max(axa.i1, axb.i1);
     __syncthreads();
 
-    // source window: columns [xa, xa + pitch) with xa 8-texel aligned; LDS slot of source row y = y - ymin
-    // (the centre rows of a workgroup are consecutive mosaic rows; the host sized the LDS for their range)
+    // source window of a chunk: columns [xa, xa + pitch) with xa 8-texel aligned (the same for every chunk);
+    // LDS slot of source row y = y - ymin(chunk) (the rows of a chunk are consecutive mosaic rows; the host
+    // sized the LDS for their contiguous range)
     const int xa = __builtin_amdgcn_readfirstlane(S.xmin) & ~7;
-    const bool own_top = g == 0, own_bottom = cr1 == c;
-    const int ymin = __builtin_amdgcn_readfirstlane(own_top ? min(S.apron[0].y0, S.rows[0].y0) : S.rows[0].y0);
-    const int ymax = __builtin_amdgcn_readfirstlane(own_bottom ? max(S.apron[2 * b - 1].y1, S.rows[nrows - 1].y1) : S.rows[nrows - 1].y1);
     const uint32_t P = A.lds_pitch;
-    const uint32_t slots = uint32_t(ymax - ymin + 1);
-    // raster.data is loaded from memory, so tell the compiler it is a global (not generic) pointer
     typedef const uint8_t __attribute__((address_space(1))) * global_bytes;
     typedef const uint16_t __attribute__((address_space(1))) * global_u16;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef const u32x4 __attribute__((address_space(1))) * global_u4;
-    const global_bytes data = (global_bytes)raster.data;
     typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-    u16x2 zmin = {1, 1};  // running minimum of every staged texel: 0 <=> the window holds a no-data texel
-    if (kStaged && !(A.ablate & 8u)) {
-        const uint32_t chunks_per_row = P / 8u;
+    const global_bytes data = (global_bytes)raster.data;  // loaded from memory: tell the compiler it is global
+    const uint32_t chunks_per_row = P / 8u;
+    const uint32_t row_texels = uint32_t(raster.pitch / 2u);  // addressable texels per source row
+    const bool wide = ((reinterpret_cast<uintptr_t>(raster.data) | raster.pitch) & 15u) == 0;
+    constexpr uint32_t kBatch = 4;  // 16-byte loads per thread and chunk (host guarantees slots * pitch / 8 <= 256 * kBatch)
+
+    auto chunk_rows = [&](uint32_t k) -> uint32_t { return min(kMainRows, c - k * kMainRows); };
+    auto window = [&](uint32_t k, int& ymin, uint32_t& slots) {  // workgroup-uniform
+        const RowParam* rows = S.rows[k & 1u];
+        const uint32_t n = chunk_rows(k);
+        int lo = rows[0].y0, hi = rows[n - 1].y1;
+        if (k == 0) lo = min(lo, S.apron[0].y0);
+        if (k == chunks_per_tile - 1) hi = max(hi, S.apron[2 * b - 1].y1);
+        ymin = __builtin_amdgcn_readfirstlane(lo);
+        slots = uint32_t(__builtin_amdgcn_readfirstlane(hi) - ymin + 1);
+    };
+    // issue the loads of chunk k into registers (branch-free: addresses past the window are clamped)
+    auto stage_issue = [&](int ymin, uint32_t slots, u32x4 (&v)[kBatch]) {
         const uint32_t total = slots * chunks_per_row;
-        const uint32_t row_texels = uint32_t(raster.pitch / 2u);  // addressable texels per source row
-        const bool wide = ((reinterpret_cast<uintptr_t>(raster.data) | raster.pitch) & 15u) == 0;
-        if (wide) {
-            // branch-free batches: every thread issues kBatch independent 16-byte loads (addresses of chunks
-            // past the window are clamped to a valid one and dropped), then writes them to LDS
-            constexpr uint32_t kBatch = 8;
-            for (uint32_t base = 0; base < total; base += 256u * kBatch) {
-                u32x4 v[kBatch];
 #pragma unroll
-                for (uint32_t i = 0; i < kBatch; i++) {
-                    const uint32_t ch = min(base + tid + 256u * i, total - 1u);
-                    const uint32_t slot = ch / chunks_per_row, k = ch - slot * chunks_per_row;
-                    const uint32_t x = min(uint32_t(xa) + 8u * k, row_texels - 8u);  // x, row_texels: multiples of 8
-                    v[i] = *(global_u4)(data + uint64_t(ymin + int(slot)) * raster.pitch + uint64_t(x) * 2u);
-                }
-#pragma unroll
-                for (uint32_t i = 0; i < kBatch; i++) {
-                    const uint32_t ch = base + tid + 256u * i;
-                    const uint32_t slot = ch / chunks_per_row, k = ch - slot * chunks_per_row;
-                    if (ch < total) *reinterpret_cast<u32x4*>(s_src + slot * P + 8u * k) = v[i];
-                    const u16x2 m01 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, v[i].x), __builtin_bit_cast(u16x2, v[i].y));
-                    const u16x2 m23 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, v[i].z), __builtin_bit_cast(u16x2, v[i].w));
-                    zmin = __builtin_elementwise_min(zmin, __builtin_elementwise_min(m01, m23));
-                }
-            }
-        } else {
-            // unaligned raster (odd widths / pitches): texel by texel
-            for (uint32_t i = tid; i < slots * P; i += 256u) {
-                const uint32_t slot = i / P, k = i - slot * P;
-                const uint32_t x = uint32_t(xa) + k;
-                const global_u16 row = (global_u16)(data + uint64_t(ymin + int(slot)) * raster.pitch);
-                const uint16_t t = x < raster.width ? row[x] : uint16_t(1);
-                s_src[i] = t;
-                zmin.x = min(zmin.x, t);
-            }
+        for (uint32_t i = 0; i < kBatch; i++) {
+            const uint32_t ch = min(tid + 256u * i, total - 1u);
+            const uint32_t slot = ch / chunks_per_row, kk = ch - slot * chunks_per_row;
+            const uint32_t x = min(uint32_t(xa) + 8u * kk, row_texels - 8u);  // x, row_texels: multiples of 8
+            v[i] = *(global_u4)(data + uint64_t(ymin + int(slot)) * raster.pitch + uint64_t(x) * 2u);
         }
-    }
+    };
+    // registers -> LDS; returns this thread's "saw a no-data texel" bit
+    auto stage_commit = [&](uint32_t slots, const u32x4 (&v)[kBatch]) -> bool {
+        const uint32_t total = slots * chunks_per_row;
+        u16x2 zmin = {1, 1};
+#pragma unroll
+        for (uint32_t i = 0; i < kBatch; i++) {
+            const uint32_t ch = tid + 256u * i;
+            const uint32_t slot = ch / chunks_per_row, kk = ch - slot * chunks_per_row;
+            if (ch < total) *reinterpret_cast<u32x4*>(s_src + slot * P + 8u * kk) = v[i];
+            const u16x2 m01 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, v[i].x), __builtin_bit_cast(u16x2, v[i].y));
+            const u16x2 m23 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, v[i].z), __builtin_bit_cast(u16x2, v[i].w));
+            zmin = __builtin_elementwise_min(zmin, __builtin_elementwise_min(m01, m23));
+        }
+        return zmin.x == 0 || zmin.y == 0;
+    };
+    // unaligned rasters (odd widths / pitches): texel by texel, no prefetch
+    auto stage_narrow = [&](int ymin, uint32_t slots) -> bool {
+        bool z = false;
+        for (uint32_t i = tid; i < slots * P; i += 256u) {
+            const uint32_t slot = i / P, kk = i - slot * P;
+            const uint32_t x = uint32_t(xa) + kk;
+            const global_u16 row = (global_u16)(data + uint64_t(ymin + int(slot)) * raster.pitch);
+            const uint16_t t = x < raster.width ? row[x] : uint16_t(1);
+            s_src[i] = t;
+            z = z || t == 0;
+        }
+        return z;
+    };
 
     uint16_t* tile5 = A.atlas + uint64_t(t5.self) * tile_texels;
     uint32_t* tile5_u32 = reinterpret_cast<uint32_t*>(tile5);
-
-    // staged source rows visible; has_nodata is workgroup-uniform (texels past the image edge were loaded from
-    // clamped addresses, so they are real texels too)
-    const bool has_nodata = __syncthreads_or((!kStaged) || zmin.x == 0 || zmin.y == 0) != 0;
-
-    if (A.ablate & 16u) return;  // debug: prologue + staging only
-
-    // LDS offsets of this thread's four source columns (idle lanes read column 0 and store nothing)
-    const uint32_t la0 = uint32_t(axa.i0 - xa), la1 = uint32_t(axa.i1 - xa), lb0 = uint32_t(axb.i0 - xa), lb1 = uint32_t(axb.i1 - xa);
-    auto fetch_row = [&](int y) -> Texel4 {
-        if constexpr (kStaged) {
-            const uint16_t* row = s_src + uint32_t(y - ymin) * P;
-            return convert4(row[la0], row[la1], row[lb0], row[lb1]);
-        } else {
-            const global_u16 row = (global_u16)(data + uint64_t(y) * raster.pitch);
-            return convert4(row[axa.i0], row[axa.i1], row[axb.i0], row[axb.i1]);
-        }
-    };
-
-    // ---- apron rows (first / last workgroup of a tile only), one row at a time.  Centre columns use the
-    // staged rows like any centre row; the b x b corners follow the diagonal neighbour alone
-    // (stitch.wgsl:57-66, 105-118) and take the general evaluation.
-    if ((own_top || own_bottom) && !is_idle) {
-        for (uint32_t r = 0; r < 2 * b; r++) {
-            const bool top = r < b;
-            if (top ? !own_top : !own_bottom) continue;
-            const uint32_t k = r % b, py = top ? k : o + k;
-            uint32_t va, vb;
-            if (is_centre) {
-                const int y0 = __builtin_amdgcn_readfirstlane(S.apron[r].y0), y1 = __builtin_amdgcn_readfirstlane(S.apron[r].y1);
-                const float fy = S.apron[r].fy, gy = 1.0f - fy;
-                const Texel4 t0 = fetch_row(y0), t1 = fetch_row(y1);
-                va = float_to_unorm16((t0.a0 * gxa + t0.a1 * fxa) * gy + (t1.a0 * gxa + t1.a1 * fxa) * fy);
-                vb = float_to_unorm16((t0.b0 * gxb + t0.b1 * fxb) * gy + (t1.b0 * gxb + t1.b1 * fxb) * fy);
-                if (min(min(t0.za, t1.za), min(t0.zb, t1.zb)) == 0) {
-                    const uint32_t nrow = top ? t5.n : t5.s;
-                    const uint16_t* h = A.atlas + uint64_t(nrow == kInvalid ? t5.self : nrow) * tile_texels + (b + S.apron[r].pad) * T + b;
-                    if (min(t0.za, t1.za) == 0) va = h[rxa];
-                    if (min(t0.zb, t1.zb) == 0) vb = h[rxb];
-                }
-            } else {
-                const uint32_t n = grid_lookup(A, it.side, A.lod, int(it.x) + (is_left ? -1 : 1), int(it.y) + (top ? -1 : 1));
-                uint32_t v[2];
-#pragma unroll
-                for (uint32_t e = 0; e < 2; e++) {
-                    const uint32_t pxk = px0 + e;
-                    if (n != kInvalid)
-                        v[e] = split_value_slow(A, raster, is_left ? it.x - 1 : it.x + 1, is_left ? c - b + pxk : pxk - o,
-                                                top ? it.y - 1 : it.y + 1, top ? c - b + k : k, n);
-                    else
-                        v[e] = split_value_slow(A, raster, it.x, is_left ? 0u : c - 1, it.y, top ? 0u : c - 1, t5.self);
-                }
-                va = v[0];
-                vb = v[1];
-            }
-            tile5_u32[(py * T + px0) >> 1] = va | (vb << 16);
-        }
-    }
-
     uint16_t* tile4 = A.atlas + uint64_t(self4 == kInvalid ? 0u : self4) * tile_texels;
     uint16_t* tile3 = A.atlas + uint64_t(self3 == kInvalid ? 0u : self3) * tile_texels;
     const uint32_t cx4 = (it.x & 1u) * half_c + tid, cy4_base = (it.y & 1u) * half_c;
@@ -552,156 +512,272 @@ __global__ __launch_bounds__(256) void fused_main_kernel(FusedArgs A) {
     PushX px4{}, px3{};
     if (do4 && is_centre) px4 = make_push_x(A, S.nb[0], cx4);
     if (do3 && is_centre) px3 = make_push_x(A, S.nb[1], cx3);
+    // LDS offsets of this thread's four source columns (idle lanes read column 0 and store nothing)
+    const uint32_t la0 = uint32_t(axa.i0 - xa), la1 = uint32_t(axa.i1 - xa), lb0 = uint32_t(axb.i0 - xa), lb1 = uint32_t(axb.i1 - xa);
 
-    if (kStaged && !has_nodata && !(A.ablate & 32u)) {
-        // ---- fast loop: the window has no no-data texel, so every pixel of every LOD is valid (a blend of
-        // non-zero texels is >= 1/65535) and no validity bookkeeping is needed.  Two columns ride in the two
-        // lanes of packed f32 instructions; the horizontal blend of a source row is computed once and
-        // serves both output rows that touch it.  Same operations, same order as the generic loop below.
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        const f2 gx = {gxa, gxb}, fx = {fxa, fxb};
-        const f2 kr = {1.0f / 65535.0f, 1.0f / 65535.0f}, kn = {65535.0f, 65535.0f}, khalf = {0.5f, 0.5f};
-        const f2 kzero = {0.0f, 0.0f}, kone = {1.0f, 1.0f}, kquarter = {0.25f, 0.25f};
-        auto conv2 = [&](uint32_t ta, uint32_t tb) -> f2 {  // (ta, tb) / 65535, correctly rounded (see header)
-            const f2 x = {float(ta), float(tb)};
-            const f2 q0 = x * kr;
-            const f2 e = __builtin_elementwise_fma(-q0, kn, x);
-            return __builtin_elementwise_fma(e, kr, q0);
-        };
-        auto hblend = [&](int y) -> f2 {  // (mix(t00, t10, fx) for column a, same for column b) of source row y
-            const uint16_t* row = s_src + uint32_t(y - ymin) * P;
-            const f2 left = conv2(row[la0], row[lb0]), right = conv2(row[la1], row[lb1]);
-            return left * gx + right * fx;
-        };
-        auto quantise = [&](f2 v) -> f2 {  // 0.5 + 65535 * clamp(v, 0, 1); the u32 conversion then floors
-            const f2 cl = __builtin_elementwise_min(__builtin_elementwise_max(v, kzero), kone);
-            return khalf + kn * cl;
-        };
-        f2 hcur = kzero;
-        int hy = -1;
-        for (uint32_t q = 0; q < nrows; q += 4) {
-            uint32_t ua[4], ub[4];
-#pragma unroll
-            for (uint32_t i = 0; i < 4; i++) {
-                const int y0 = __builtin_amdgcn_readfirstlane(S.rows[q + i].y0);
-                const int y1 = __builtin_amdgcn_readfirstlane(S.rows[q + i].y1);
-                const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, S.rows[q + i].fy)));
-                const f2 top = (y0 == hy) ? hcur : hblend(y0);
-                const f2 bot = (y1 == y0) ? top : hblend(y1);
-                hcur = bot;
-                hy = y1;
-                const f2 fy2 = {fy, fy}, gy2 = {1.0f - fy, 1.0f - fy};
-                const f2 w = quantise(top * gy2 + bot * fy2);
-                ua[i] = uint32_t(w.x);
-                ub[i] = uint32_t(w.y);
-            }
-            const uint32_t py = b + cr0 + q;
-            if (!is_idle && !(A.ablate & 2u)) {
-#pragma unroll
-                for (uint32_t i = 0; i < 4; i++) tile5_u32[((py + i) * T + px0) >> 1] = ua[i] | (ub[i] << 16);
-            }
-            if (do4) {
-                // two level-1 pixels (row pairs 0-1 and 2-3) in the two packed lanes: ((a0 + a1) + b0) + b1, then / 4
-                const f2 s = ((conv2(ua[0], ua[2]) + conv2(ua[1], ua[3])) + conv2(ub[0], ub[2])) + conv2(ub[1], ub[3]);
-                const f2 wq = quantise(s * kquarter);
-                const uint32_t q0 = uint32_t(wq.x), q1 = uint32_t(wq.y);
-                const uint32_t cy = cr0 + q, cy4 = cy4_base + (cy >> 1);
-                const bool edge4 = cy4 < b || cy4 + 2 > c - b;  // uniform: the row pair touches the parent's top / bottom strip
-                if (is_centre) {
-                    if (edge4) {
-                        push_pixel_lds(A, S.nb[0], tile4, cx4, cy4, uint16_t(q0));
-                        push_pixel_lds(A, S.nb[0], tile4, cx4, cy4 + 1, uint16_t(q1));
-                    } else {
-                        push_fast(A, px4, tile4, cy4, uint16_t(q0));
-                        push_fast(A, px4, tile4, cy4 + 1, uint16_t(q1));
-                    }
-                }
-                if (do3) {
-                    const uint32_t other0 = __shfl_xor(q0, 1), other1 = __shfl_xor(q1, 1);
-                    if (is_centre && (tid & 1u) == 0) {
-                        const f2 mine = conv2(q0, q1), theirs = conv2(other0, other1);
-                        const float s3 = ((mine.x + mine.y) + theirs.x) + theirs.y;
-                        const uint32_t w3 = float_to_unorm16(s3 * 0.25f);
-                        const uint32_t cy3 = cy3_base + (cy >> 2);
-                        if (cy3 < b || cy3 >= c - b) push_pixel_lds(A, S.nb[1], tile3, cx3, cy3, uint16_t(w3));
-                        else push_fast(A, px3, tile3, cy3, uint16_t(w3));
-                    }
-                }
-            }
+    // ---- first chunk: stage synchronously
+    int ymin = 0;
+    uint32_t slots = 0;
+    bool nodata = !kStaged;
+    u32x4 pre[kBatch];
+    window(k_begin, ymin, slots);
+    if (kStaged && !(A.ablate & 8u)) {
+        if (wide) {
+            stage_issue(ymin, slots, pre);
+            nodata = stage_commit(slots, pre);
+        } else {
+            nodata = stage_narrow(ymin, slots);
         }
-        return;
     }
+    if (k_begin + 1 < k_end) fill_rows(k_begin + 1);
+    bool has_nodata = __syncthreads_or(nodata) != 0;
 
-    Texel4 cur{};
-    int cur_y = -1;
-    for (uint32_t q = 0; q < nrows; q += 4) {
-        uint32_t va[4], vb[4];
-        uint32_t zany = 1;
-#pragma unroll
-        for (uint32_t i = 0; i < 4; i++) {
-            // row parameters are workgroup-uniform: scalarise them so the reuse tests are scalar branches
-            const int y0 = __builtin_amdgcn_readfirstlane(S.rows[q + i].y0);
-            const int y1 = __builtin_amdgcn_readfirstlane(S.rows[q + i].y1);
-            const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, S.rows[q + i].fy)));
-            const Texel4 top = (y0 == cur_y) ? cur : fetch_row(y0);
-            const Texel4 bot = (y1 == y0) ? top : fetch_row(y1);
-            cur = bot;
-            cur_y = y1;
-            const float gy = 1.0f - fy;
-            if (A.ablate & 4u) {
-                va[i] = uint32_t(top.a0 + bot.a0);
-                vb[i] = uint32_t(top.b1 + bot.b1);
+    for (uint32_t k = k_begin; k < k_end; k++) {
+        const RowParam* rows = S.rows[k & 1u];
+        const uint32_t cr0 = k * kMainRows, nrows = chunk_rows(k);
+        const int cur_ymin = ymin;
+        // prefetch the next chunk's source rows while this one is shaded
+        int next_ymin = 0;
+        uint32_t next_slots = 0;
+        const bool more = k + 1 < k_end;
+        if (more) {
+            window(k + 1, next_ymin, next_slots);
+            if (kStaged && wide && !(A.ablate & 8u)) stage_issue(next_ymin, next_slots, pre);
+        }
+
+        auto fetch_row = [&](int y) -> Texel4 {
+            if constexpr (kStaged) {
+                const uint16_t* row = s_src + uint32_t(y - cur_ymin) * P;
+                return convert4(row[la0], row[la1], row[lb0], row[lb1]);
             } else {
-                va[i] = float_to_unorm16((top.a0 * gxa + top.a1 * fxa) * gy + (bot.a0 * gxa + bot.a1 * fxa) * fy);
-                vb[i] = float_to_unorm16((top.b0 * gxb + top.b1 * fxb) * gy + (bot.b0 * gxb + bot.b1 * fxb) * fy);
+                const global_u16 row = (global_u16)(data + uint64_t(y) * raster.pitch);
+                return convert4(row[axa.i0], row[axa.i1], row[axb.i0], row[axb.i1]);
             }
-            const uint32_t za = min(top.za, bot.za), zb = min(top.zb, bot.zb);
-            zany = min(zany, min(za, zb));
-            // remember the validity in bit 16 (cleared below): 0x10000 = no data in the footprint
-            va[i] |= za == 0 ? 0x10000u : 0u;
-            vb[i] |= zb == 0 ? 0x10000u : 0u;
-        }
-        if (zany == 0) {  // some footprint had no data: those pixels keep their previous atlas value (split.wgsl:37-42)
-#pragma unroll
-            for (uint32_t i = 0; i < 4; i++) {
-                const uint16_t* h = A.atlas + uint64_t(home_col) * tile_texels + (b + cr0 + q + i) * T + b;
-                if (va[i] & 0x10000u) va[i] = h[rxa];
-                if (vb[i] & 0x10000u) vb[i] = h[rxb];
+        };
+
+        // a chunk with no-data goes to the generic variant as a whole
+        const bool skip_chunk = !kGeneric && has_nodata;
+        if (skip_chunk && tid == 0) A.todo[2 + atomicAdd(&A.todo[0], 1u)] = item_index * chunks_per_tile + k;
+
+        // ---- apron rows (first / last chunk of a tile only): the centre columns are rows like any other (the
+        // north / south neighbour's centre rows, or clamped into the own centre); the b x b corners follow the
+        // diagonal neighbour alone (stitch.wgsl:57-66, 105-118) and are written by fused_corner_kernel.
+        if ((k == 0 || k == chunks_per_tile - 1) && is_centre && !skip_chunk) {
+            for (uint32_t r = 0; r < 2 * b; r++) {
+                const bool top = r < b;
+                if (top ? k != 0 : k != chunks_per_tile - 1) continue;
+                const uint32_t kk = r % b, py = top ? kk : o + kk;
+                const int y0 = __builtin_amdgcn_readfirstlane(S.apron[r].y0), y1 = __builtin_amdgcn_readfirstlane(S.apron[r].y1);
+                const float fy = S.apron[r].fy, gy = 1.0f - fy;
+                const Texel4 t0 = fetch_row(y0), t1 = fetch_row(y1);
+                uint32_t va = float_to_unorm16((t0.a0 * gxa + t0.a1 * fxa) * gy + (t1.a0 * gxa + t1.a1 * fxa) * fy);
+                uint32_t vb = float_to_unorm16((t0.b0 * gxb + t0.b1 * fxb) * gy + (t1.b0 * gxb + t1.b1 * fxb) * fy);
+                if (kGeneric && min(min(t0.za, t1.za), min(t0.zb, t1.zb)) == 0) {
+                    const uint32_t nrow = top ? t5.n : t5.s;
+                    const uint16_t* h = A.atlas + uint64_t(nrow == kInvalid ? t5.self : nrow) * tile_texels + (b + S.apron[r].pad) * T + b;
+                    if (min(t0.za, t1.za) == 0) va = h[rxa];
+                    if (min(t0.zb, t1.zb) == 0) vb = h[rxb];
+                }
+                tile5_u32[(py * T + px0) >> 1] = va | (vb << 16);
             }
-        }
-        const uint32_t py = b + cr0 + q;
-        if (!is_idle && (!(A.ablate & 2u) || va[0] == 0x12345u)) {
-#pragma unroll
-            for (uint32_t i = 0; i < 4; i++) tile5_u32[((py + i) * T + px0) >> 1] = (va[i] & 0xFFFFu) | (vb[i] << 16);
         }
 
-        // ---- next two LODs from the centre pixels: two row pairs give two level-1 pixels per thread, which a
-        // lane pair combines into one level-2 pixel
-        if (do4) {
-            const uint32_t cy = cr0 + q;  // multiple of 4
-            const uint32_t q0 = downsample4(va[0] & 0xFFFFu, va[1] & 0xFFFFu, vb[0] & 0xFFFFu, vb[1] & 0xFFFFu);  // OFFSETS order
-            const uint32_t q1 = downsample4(va[2] & 0xFFFFu, va[3] & 0xFFFFu, vb[2] & 0xFFFFu, vb[3] & 0xFFFFu);
-            const uint32_t cy4 = cy4_base + (cy >> 1);
-            const bool edge4 = cy4 < b || cy4 + 2 > c - b;  // uniform: the row pair touches the parent tile's top / bottom strip
-            if (is_centre) {
-                if (edge4) {
-                    push_pixel_lds(A, S.nb[0], tile4, cx4, cy4, uint16_t(q0));
-                    push_pixel_lds(A, S.nb[0], tile4, cx4, cy4 + 1, uint16_t(q1));
-                } else {
-                    push_fast(A, px4, tile4, cy4, uint16_t(q0));
-                    push_fast(A, px4, tile4, cy4 + 1, uint16_t(q1));
+        if (!(A.ablate & 16u) && !skip_chunk) {
+            if constexpr (kStaged && !kGeneric) {
+                // ---- fast loop: the window has no no-data texel, so every pixel of every LOD is valid (a blend of
+                // non-zero texels is >= 1/65535) and no validity bookkeeping is needed.  Two columns ride in the two
+                // lanes of packed f32 instructions; the horizontal blend of a source row is computed once and
+                // serves both output rows that touch it.  Same operations, same order as the generic loop below.
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const f2 gx = {gxa, gxb}, fx = {fxa, fxb};
+                const f2 kr = {1.0f / 65535.0f, 1.0f / 65535.0f}, kn = {65535.0f, 65535.0f}, khalf = {0.5f, 0.5f};
+                const f2 kzero = {0.0f, 0.0f}, kone = {1.0f, 1.0f}, kquarter = {0.25f, 0.25f};
+                auto conv2 = [&](uint32_t ta, uint32_t tb) -> f2 {  // (ta, tb) / 65535, correctly rounded (see header)
+                    const f2 x = {float(ta), float(tb)};
+                    const f2 q0 = x * kr;
+                    const f2 e = __builtin_elementwise_fma(-q0, kn, x);
+                    return __builtin_elementwise_fma(e, kr, q0);
+                };
+                auto hblend = [&](int y) -> f2 {  // (mix(t00, t10, fx) for column a, same for column b) of source row y
+                    const uint16_t* row = s_src + uint32_t(y - cur_ymin) * P;
+                    const f2 left = conv2(row[la0], row[lb0]), right = conv2(row[la1], row[lb1]);
+                    return left * gx + right * fx;
+                };
+                auto quantise = [&](f2 v) -> f2 {  // 0.5 + 65535 * clamp(v, 0, 1); the u32 conversion then floors
+                    const f2 cl = __builtin_elementwise_min(__builtin_elementwise_max(v, kzero), kone);
+                    return khalf + kn * cl;
+                };
+                f2 hcur = kzero;
+                int hy = -1;
+                for (uint32_t q = 0; q < nrows; q += 4) {
+                    uint32_t ua[4], ub[4];
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; i++) {
+                        const int y0 = __builtin_amdgcn_readfirstlane(rows[q + i].y0);
+                        const int y1 = __builtin_amdgcn_readfirstlane(rows[q + i].y1);
+                        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rows[q + i].fy)));
+                        const f2 top = (y0 == hy) ? hcur : hblend(y0);
+                        const f2 bot = (y1 == y0) ? top : hblend(y1);
+                        hcur = bot;
+                        hy = y1;
+                        const f2 fy2 = {fy, fy}, gy2 = {1.0f - fy, 1.0f - fy};
+                        const f2 w = quantise(top * gy2 + bot * fy2);
+                        ua[i] = uint32_t(w.x);
+                        ub[i] = uint32_t(w.y);
+                    }
+                    const uint32_t py = b + cr0 + q;
+                    if (!is_idle && !(A.ablate & 2u)) {
+#pragma unroll
+                        for (uint32_t i = 0; i < 4; i++) tile5_u32[((py + i) * T + px0) >> 1] = ua[i] | (ub[i] << 16);
+                    }
+                    if (do4) {
+                        // two level-1 pixels (row pairs 0-1 and 2-3) in the two packed lanes: ((a0 + a1) + b0) + b1, then / 4
+                        const f2 s = ((conv2(ua[0], ua[2]) + conv2(ua[1], ua[3])) + conv2(ub[0], ub[2])) + conv2(ub[1], ub[3]);
+                        const f2 wq = quantise(s * kquarter);
+                        const uint32_t q0 = uint32_t(wq.x), q1 = uint32_t(wq.y);
+                        const uint32_t cy = cr0 + q, cy4 = cy4_base + (cy >> 1);
+                        const bool edge4 = cy4 < b || cy4 + 2 > c - b;  // uniform: the row pair touches the parent's top / bottom strip
+                        if (is_centre) {
+                            if (edge4) {
+                                push_pixel_lds(A, S.nb[0], tile4, cx4, cy4, uint16_t(q0));
+                                push_pixel_lds(A, S.nb[0], tile4, cx4, cy4 + 1, uint16_t(q1));
+                            } else {
+                                push_fast(A, px4, tile4, cy4, uint16_t(q0));
+                                push_fast(A, px4, tile4, cy4 + 1, uint16_t(q1));
+                            }
+                        }
+                        if (do3) {
+                            const uint32_t other0 = __shfl_xor(q0, 1), other1 = __shfl_xor(q1, 1);
+                            if (is_centre && (tid & 1u) == 0) {
+                                const f2 mine = conv2(q0, q1), theirs = conv2(other0, other1);
+                                const float s3 = ((mine.x + mine.y) + theirs.x) + theirs.y;
+                                const uint32_t w3 = float_to_unorm16(s3 * 0.25f);
+                                const uint32_t cy3 = cy3_base + (cy >> 2);
+                                if (cy3 < b || cy3 >= c - b) push_pixel_lds(A, S.nb[1], tile3, cx3, cy3, uint16_t(w3));
+                                else push_fast(A, px3, tile3, cy3, uint16_t(w3));
+                            }
+                        }
+                    }
                 }
-            }
-            if (do3) {
-                const uint32_t other0 = __shfl_xor(q0, 1), other1 = __shfl_xor(q1, 1);
-                if (is_centre && (tid & 1u) == 0) {
-                    const uint32_t w = downsample4(q0, q1, other0, other1);
-                    const uint32_t cy3 = cy3_base + (cy >> 2);
-                    if (cy3 < b || cy3 >= c - b) push_pixel_lds(A, S.nb[1], tile3, cx3, cy3, uint16_t(w));
-                    else push_fast(A, px3, tile3, cy3, uint16_t(w));
+            } else {
+                // ---- generic loop: tracks per-pixel validity (no-data texels), keep-previous rule, valid-average
+                Texel4 cur{};
+                int cur_y = -1;
+                for (uint32_t q = 0; q < nrows; q += 4) {
+                    uint32_t va[4], vb[4];
+                    uint32_t zany = 1;
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; i++) {
+                        const int y0 = __builtin_amdgcn_readfirstlane(rows[q + i].y0);
+                        const int y1 = __builtin_amdgcn_readfirstlane(rows[q + i].y1);
+                        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rows[q + i].fy)));
+                        const Texel4 top = (y0 == cur_y) ? cur : fetch_row(y0);
+                        const Texel4 bot = (y1 == y0) ? top : fetch_row(y1);
+                        cur = bot;
+                        cur_y = y1;
+                        const float gy = 1.0f - fy;
+                        va[i] = float_to_unorm16((top.a0 * gxa + top.a1 * fxa) * gy + (bot.a0 * gxa + bot.a1 * fxa) * fy);
+                        vb[i] = float_to_unorm16((top.b0 * gxb + top.b1 * fxb) * gy + (bot.b0 * gxb + bot.b1 * fxb) * fy);
+                        const uint32_t za = min(top.za, bot.za), zb = min(top.zb, bot.zb);
+                        zany = min(zany, min(za, zb));
+                        // remember the validity in bit 16 (cleared below): 0x10000 = no data in the footprint
+                        va[i] |= za == 0 ? 0x10000u : 0u;
+                        vb[i] |= zb == 0 ? 0x10000u : 0u;
+                    }
+                    if (zany == 0) {  // some footprint had no data: those pixels keep their previous atlas value (split.wgsl:37-42)
+#pragma unroll
+                        for (uint32_t i = 0; i < 4; i++) {
+                            const uint16_t* h = A.atlas + uint64_t(home_col) * tile_texels + (b + cr0 + q + i) * T + b;
+                            if (va[i] & 0x10000u) va[i] = h[rxa];
+                            if (vb[i] & 0x10000u) vb[i] = h[rxb];
+                        }
+                    }
+                    const uint32_t py = b + cr0 + q;
+                    if (!is_idle) {
+#pragma unroll
+                        for (uint32_t i = 0; i < 4; i++) tile5_u32[((py + i) * T + px0) >> 1] = (va[i] & 0xFFFFu) | (vb[i] << 16);
+                    }
+                    if (do4) {
+                        const uint32_t cy = cr0 + q;  // multiple of 4
+                        const uint32_t q0 = downsample4(va[0] & 0xFFFFu, va[1] & 0xFFFFu, vb[0] & 0xFFFFu, vb[1] & 0xFFFFu);  // OFFSETS order
+                        const uint32_t q1 = downsample4(va[2] & 0xFFFFu, va[3] & 0xFFFFu, vb[2] & 0xFFFFu, vb[3] & 0xFFFFu);
+                        const uint32_t cy4 = cy4_base + (cy >> 1);
+                        if (is_centre) {
+                            push_pixel_lds(A, S.nb[0], tile4, cx4, cy4, uint16_t(q0));
+                            push_pixel_lds(A, S.nb[0], tile4, cx4, cy4 + 1, uint16_t(q1));
+                        }
+                        if (do3) {
+                            const uint32_t other0 = __shfl_xor(q0, 1), other1 = __shfl_xor(q1, 1);
+                            if (is_centre && (tid & 1u) == 0) {
+                                const uint32_t w = downsample4(q0, q1, other0, other1);
+                                push_pixel_lds(A, S.nb[1], tile3, cx3, cy3_base + (cy >> 2), uint16_t(w));
+                            }
+                        }
+                    }
                 }
             }
         }
+
+        if (!more) break;
+        __syncthreads();  // everyone is done with this chunk's LDS rows and row table
+        nodata = !kStaged;
+        if (kStaged && !(A.ablate & 8u)) nodata = wide ? stage_commit(next_slots, pre) : stage_narrow(next_ymin, next_slots);
+        if (k + 2 < k_end) fill_rows(k + 2);
+        ymin = next_ymin;
+        slots = next_slots;
+        has_nodata = __syncthreads_or(nodata) != 0;
+    }
+}
+
+// fast / non-staged variants: workgroup = (tile, part of its chunks), XCD-contiguous order
+template <bool kStaged, bool kGeneric>
+__global__ __launch_bounds__(256, 4) void fused_main_kernel(FusedArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t work = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t chunks_per_tile = (A.m.center_size + kMainRows - 1) / kMainRows;
+    const uint32_t part = work % A.groups;
+    const uint32_t k_begin = part * chunks_per_tile / A.groups, k_end = (part + 1) * chunks_per_tile / A.groups;
+    if (k_begin >= k_end) return;  // more parts than chunks (tiny tiles)
+    fused_main_chunks<kStaged, kGeneric>(A, work / A.groups, k_begin, k_end, smem);
+}
+
+// generic variant over the chunks the fast variant left in A.todo; the last workgroup resets the list
+__global__ __launch_bounds__(256, 4) void fused_todo_kernel(FusedArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t chunks_per_tile = (A.m.center_size + kMainRows - 1) / kMainRows;
+    const uint32_t count = A.todo[0];
+    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+        const uint32_t entry = A.todo[2 + e];
+        fused_main_chunks<true, true>(A, entry / chunks_per_tile, entry % chunks_per_tile, entry % chunks_per_tile + 1, smem);
+        __syncthreads();  // LDS is reused by the next entry
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&A.todo[1], 1u) == gridDim.x - 1) {
+            A.todo[0] = 0;
+            A.todo[1] = 0;
+        }
+    }
+}
+
+// the b x b apron corners of the finest tiles: governed by the diagonal neighbour alone (stitch.wgsl:57-66,
+// 105-118) — its centre corner if it exists, else the own centre corner — evaluated with the general formula
+__global__ __launch_bounds__(64) void fused_corner_kernel(FusedArgs A) {
+    const MainItem it = A.items[blockIdx.x];
+    const RasterDev raster = A.rasters[it.raster];
+    const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
+    const uint32_t self = grid_lookup(A, it.side, A.lod, int(it.x), int(it.y));
+    for (uint32_t t = threadIdx.x; t < 4 * b * b; t += blockDim.x) {
+        const uint32_t corner = t / (b * b), i = (t % (b * b)) % b, j = (t % (b * b)) / b;
+        const bool left = corner == 0 || corner == 3, top = corner < 2;  // 0 NW, 1 NE, 2 SE, 3 SW
+        const uint32_t px = left ? i : o + i, py = top ? j : o + j;
+        const uint32_t n = grid_lookup(A, it.side, A.lod, int(it.x) + (left ? -1 : 1), int(it.y) + (top ? -1 : 1));
+        uint32_t v;
+        if (n != kInvalid)
+            v = split_value_slow(A, raster, left ? it.x - 1 : it.x + 1, left ? c - b + i : i, top ? it.y - 1 : it.y + 1, top ? c - b + j : j, n);
+        else
+            v = split_value_slow(A, raster, it.x, left ? 0u : c - 1, it.y, top ? 0u : c - 1, self);
+        A.atlas[uint64_t(self) * T * T + py * T + px] = uint16_t(v);
     }
 }
 
@@ -916,6 +992,13 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         args.brx = splits[0]->br[0];
         args.bry = splits[0]->br[1];
         args.sides = sides;
+        {
+            const uint32_t chunks = (m.center_size + kMainRows - 1) / kMainRows;
+            std::vector<uint32_t> todo(2 + splits.size() * size_t(chunks), 0u);
+            const uint32_t* dev = nullptr;
+            if (upload_vector(p, todo, &dev)) return false;
+            args.todo = const_cast<uint32_t*>(dev);
+        }
         if (upload_vector(p, items, &args.items) || upload_vector(p, grids, &args.grids) || upload_vector(p, grid_offsets, &args.grid_offsets))
             return false;
 
@@ -945,7 +1028,12 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         main_job.args.lod = lod_hi;
         main_job.args.levels = main_levels;
         main_job.args.item_count = uint32_t(items.size());
-        main_job.args.groups = (m.center_size + kMainRows - 1) / kMainRows;
+        {
+            const uint32_t chunks = (m.center_size + kMainRows - 1) / kMainRows;
+            uint32_t parts = 1;
+            while (parts < chunks && uint64_t(items.size()) * parts < 1024) parts *= 2;
+            main_job.args.groups = std::min(parts, chunks);
+        }
         {   // LDS window of a workgroup: T consecutive mosaic columns x (kMainRows + 2b) mosaic rows of the source
             double ratio_x = 0.0, ratio_y = 0.0;
             const double mosaic = double(1u << lod_hi) * double(m.center_size);
@@ -962,7 +1050,8 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             main_job.args.lds_pitch = uint32_t(std::min<uint64_t>(pitch, 1u << 20));
             // the whole window must fit (the bounds above are conservative); otherwise lds_rows = 0 selects the
             // kernel variant that reads the source directly
-            main_job.args.lds_rows = rows_needed * pitch * 2 <= budget ? uint32_t(rows_needed) : 0u;
+            // the staging loop holds one batch of 8 x 16-byte loads per thread: the window must fit that too
+            main_job.args.lds_rows = (rows_needed * pitch * 2 <= budget && rows_needed * (pitch / 8) <= 256 * 4) ? uint32_t(rows_needed) : 0u;
         }
         Launch lm{};
         lm.kind = kLaunchFusedMain;
@@ -1070,11 +1159,13 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
     job.args.rasters = p->rasters_dev;
     if (l.kind == kLaunchFusedMain) {
         const uint32_t blocks = job.args.item_count * job.args.groups;
+        fused_corner_kernel<<<job.args.item_count, 64, 0, p->ctx->stream>>>(job.args);
         if (job.args.lds_rows) {
             const size_t lds = sizeof(MainShared) + size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
-            fused_main_kernel<true><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
+            fused_main_kernel<true, false><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
+            fused_todo_kernel<<<std::min(blocks, 1024u), 256, lds, p->ctx->stream>>>(job.args);
         } else {
-            fused_main_kernel<false><<<blocks, 256, sizeof(MainShared), p->ctx->stream>>>(job.args);
+            fused_main_kernel<false, true><<<blocks, 256, sizeof(MainShared), p->ctx->stream>>>(job.args);
         }
     } else {
         const uint32_t size = (1u << job.args.lod) * job.args.m.center_size;
