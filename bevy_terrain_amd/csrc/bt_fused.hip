@@ -235,6 +235,9 @@ struct RowParam {  // one centre row of the workgroup: LDS slots of its two sour
 
 struct MainShared {  // fixed part of the dynamic LDS block (size is a multiple of 16 bytes)
     RowParam rows[2][kMainRows];  // double buffered: chunk k uses rows[k & 1]
+    float fy[2][kMainRows];       // the y weights again, packed for two 16-byte uniform reads
+    uint32_t consecutive[2];      // chunk's rows use source rows y, y+1, ..., y+kMainRows (one step per row)
+    uint32_t pad2[2];
     RowParam apron[2 * kMaxBorder];  // [0, b): top apron rows, [b, 2b): bottom apron rows (pad = mosaic row ry)
     uint32_t nb[2][8];  // neighbours (N,E,S,W,NW,NE,SE,SW) of the parent [0] and grand-parent [1] tile
     int xmin, xmax;
@@ -349,7 +352,7 @@ __device__ __forceinline__ Texel4 convert4(uint32_t ta0, uint32_t ta1, uint32_t 
 // chunks with per-pixel validity, the keep-previous rule and the valid-average.  (Keeping both loops in one kernel
 // costs ~90 spilled VGPRs at the 4-waves-per-SIMD budget.)  kStaged == false reads the source directly (window too
 // large for LDS) and always takes the generic loop.
-template <bool kStaged, bool kGeneric>
+template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP>
 __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t item_index, uint32_t k_begin, uint32_t k_end, uint8_t* smem) {
     MainShared& S = *reinterpret_cast<MainShared*>(smem);
     uint16_t* s_src = reinterpret_cast<uint16_t*>(smem + sizeof(MainShared));
@@ -359,7 +362,9 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     // shaded out of LDS the source rows of chunk k + 1 are already in flight into registers.
     const MainItem it = A.items[item_index];
     const RasterDev raster = A.rasters[it.raster];
-    const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
+    // kT / kP: texture size and LDS pitch as compile-time constants (0 = runtime) so that row offsets become
+    // instruction immediates in the static fast path
+    const uint32_t T = kT ? kT : A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
     const uint32_t tid = threadIdx.x;
     const float scale = float(1u << A.lod);
     const uint32_t tile_texels = T * T;
@@ -378,6 +383,12 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             r.y0 = ay.i0;
             r.y1 = ay.i1;
             r.fy = ay.fr;
+            S.fy[k & 1u][tid] = ay.fr;
+            // y0 of row i == y0 of row 0 + i and y1 == y0 + 1 for every row of a full chunk
+            const int first = __shfl(ay.i0, 0);
+            const bool ok = ay.i0 == first + int(tid) && ay.i1 == ay.i0 + 1;
+            const unsigned long long all = __ballot(ok);
+            if (tid == 0) S.consecutive[k & 1u] = (all & ((1ull << kMainRows) - 1)) == ((1ull << kMainRows) - 1) && k * kMainRows + kMainRows <= c;
         }
     };
     fill_rows(k_begin);
@@ -440,7 +451,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     // LDS slot of source row y = y - ymin(chunk) (the rows of a chunk are consecutive mosaic rows; the host
     // sized the LDS for their contiguous range)
     const int xa = __builtin_amdgcn_readfirstlane(S.xmin) & ~7;
-    const uint32_t P = A.lds_pitch;
+    const uint32_t P = kP ? kP : A.lds_pitch;
     typedef const uint8_t __attribute__((address_space(1))) * global_bytes;
     typedef const uint16_t __attribute__((address_space(1))) * global_u16;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -584,10 +595,6 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
 
         if (!(A.ablate & 16u) && !skip_chunk) {
             if constexpr (kStaged && !kGeneric) {
-                // ---- fast loop: the window has no no-data texel, so every pixel of every LOD is valid (a blend of
-                // non-zero texels is >= 1/65535) and no validity bookkeeping is needed.  Two columns ride in the two
-                // lanes of packed f32 instructions; the horizontal blend of a source row is computed once and
-                // serves both output rows that touch it.  Same operations, same order as the generic loop below.
                 typedef float f2 __attribute__((ext_vector_type(2)));
                 const f2 gx = {gxa, gxb}, fx = {fxa, fxb};
                 const f2 kr = {1.0f / 65535.0f, 1.0f / 65535.0f}, kn = {65535.0f, 65535.0f}, khalf = {0.5f, 0.5f};
@@ -598,14 +605,102 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                     const f2 e = __builtin_elementwise_fma(-q0, kn, x);
                     return __builtin_elementwise_fma(e, kr, q0);
                 };
+                auto quantise = [&](f2 v) -> f2 {  // 0.5 + 65535 * clamp(v, 0, 1); the u32 conversion then floors
+                    const f2 cl = __builtin_elementwise_min(__builtin_elementwise_max(v, kzero), kone);
+                    return khalf + kn * cl;
+                };
+                const uint32_t cy4_first = cy4_base + (cr0 >> 1), cy3_first = cy3_base + (cr0 >> 2);
+                const bool interior4 = cy4_first >= b && cy4_first + kMainRows / 2 <= c - b;
+                const bool interior3 = cy3_first >= b && cy3_first + kMainRows / 4 <= c - b;
+                if (kMainRows == 8 && __builtin_amdgcn_readfirstlane(S.consecutive[k & 1u]) && (!do4 || interior4) && (!do3 || interior3)) {
+                    // ---- static fast path: the 8 rows use 9 consecutive source rows and stay clear of the parents'
+                    // top / bottom strips: straight-line code, row offsets are immediates, no per-row decisions
+                    const uint16_t* base = s_src + uint32_t(__builtin_amdgcn_readfirstlane(rows[0].y0) - cur_ymin) * P;
+                    const uint16_t *pa0 = base + la0, *pa1 = base + la1, *pb0 = base + lb0, *pb1 = base + lb1;
+                    // software pipelined: the four texels of row r + 1 are requested before row r is converted, so the
+                    // LDS latency hides behind the packed arithmetic of the previous row
+                    f2 h[kMainRows + 1];
+                    uint32_t t0 = pa0[0], t1 = pb0[0], t2 = pa1[0], t3 = pb1[0];
+#pragma unroll
+                    for (uint32_t r = 0; r <= kMainRows; r++) {
+                        uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+                        if (r < kMainRows) {
+                            n0 = pa0[(r + 1) * P];
+                            n1 = pb0[(r + 1) * P];
+                            n2 = pa1[(r + 1) * P];
+                            n3 = pb1[(r + 1) * P];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        h[r] = conv2(t0, t1) * gx + conv2(t2, t3) * fx;
+                        __builtin_amdgcn_sched_barrier(0);
+                        t0 = n0;
+                        t1 = n1;
+                        t2 = n2;
+                        t3 = n3;
+                    }
+                    uint32_t ua[kMainRows], ub[kMainRows];
+                    const float* fyt = S.fy[k & 1u];
+#pragma unroll
+                    for (uint32_t i = 0; i < kMainRows; i++) {
+                        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fyt[i])));
+                        const f2 fy2 = {fy, fy}, gy2 = {1.0f - fy, 1.0f - fy};
+                        const f2 w = quantise(h[i] * gy2 + h[i + 1] * fy2);
+                        ua[i] = uint32_t(w.x);
+                        ub[i] = uint32_t(w.y);
+                    }
+                    if (!is_idle && !(A.ablate & 2u)) {
+                        uint32_t* dst = tile5_u32 + (((b + cr0) * T + px0) >> 1);
+#pragma unroll
+                        for (uint32_t i = 0; i < kMainRows; i++) dst[i * (T / 2)] = ua[i] | (ub[i] << 16);
+                    }
+                    if (do4) {
+                        // four level-1 pixels per thread (row pairs 0-1 .. 6-7), two per packed op: ((a0 + a1) + b0) + b1, / 4
+                        uint32_t q[4];
+#pragma unroll
+                        for (uint32_t j = 0; j < 2; j++) {
+                            const uint32_t r = 4 * j;
+                            const f2 sum = ((conv2(ua[r], ua[r + 2]) + conv2(ua[r + 1], ua[r + 3])) + conv2(ub[r], ub[r + 2])) + conv2(ub[r + 1], ub[r + 3]);
+                            const f2 wq = quantise(sum * kquarter);
+                            q[2 * j] = uint32_t(wq.x);
+                            q[2 * j + 1] = uint32_t(wq.y);
+                        }
+                        if (is_centre) {
+                            uint16_t* dst = tile4 + (b + cy4_first) * T + px4.centre;
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; j++) dst[j * T] = uint16_t(q[j]);
+                            if (px4.extra_count) {  // first / last columns of the parent's quadrant: the x neighbour's apron or the own one
+                                uint16_t* t = (px4.other_tile ? A.atlas + uint64_t(px4.extra_tile) * tile_texels : tile4) + (b + cy4_first) * T + px4.extra_base;
+                                for (uint32_t e = 0; e < px4.extra_count; e++)
+#pragma unroll
+                                    for (uint32_t j = 0; j < 4; j++) t[j * T + e] = uint16_t(q[j]);
+                            }
+                        }
+                        if (do3) {
+                            // the lane pair (2m, 2m+1) owns two level-2 pixels (quads 0 and 1): the even lane finishes
+                            // quad 0, the odd lane quad 1, each receiving the partner's half of its quad
+                            const bool even = (tid & 1u) == 0;
+                            const uint32_t send0 = even ? q[2] : q[0], send1 = even ? q[3] : q[1];
+                            const uint32_t recv0 = __shfl_xor(send0, 1), recv1 = __shfl_xor(send1, 1);
+                            const uint32_t l0 = even ? q[0] : recv0, l1 = even ? q[1] : recv1;  // x even column (dx = 0)
+                            const uint32_t r0 = even ? recv0 : q[2], r1 = even ? recv1 : q[3];  // x odd column (dx = 1)
+                            const f2 left = conv2(l0, l1), right = conv2(r0, r1);
+                            const float s3 = ((left.x + left.y) + right.x) + right.y;
+                            const uint32_t w3 = float_to_unorm16(s3 * 0.25f);
+                            if (is_centre) {
+                                const uint32_t row3 = (b + cy3_first + (even ? 0u : 1u)) * T;
+                                tile3[row3 + px3.centre] = uint16_t(w3);
+                                if (px3.extra_count) {
+                                    uint16_t* t = (px3.other_tile ? A.atlas + uint64_t(px3.extra_tile) * tile_texels : tile3) + row3 + px3.extra_base;
+                                    for (uint32_t e = 0; e < px3.extra_count; e++) t[e] = uint16_t(w3);
+                                }
+                            }
+                        }
+                    }
+                } else {
                 auto hblend = [&](int y) -> f2 {  // (mix(t00, t10, fx) for column a, same for column b) of source row y
                     const uint16_t* row = s_src + uint32_t(y - cur_ymin) * P;
                     const f2 left = conv2(row[la0], row[lb0]), right = conv2(row[la1], row[lb1]);
                     return left * gx + right * fx;
-                };
-                auto quantise = [&](f2 v) -> f2 {  // 0.5 + 65535 * clamp(v, 0, 1); the u32 conversion then floors
-                    const f2 cl = __builtin_elementwise_min(__builtin_elementwise_max(v, kzero), kone);
-                    return khalf + kn * cl;
                 };
                 f2 hcur = kzero;
                 int hy = -1;
@@ -658,6 +753,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             }
                         }
                     }
+                }
                 }
             } else {
                 // ---- generic loop: tracks per-pixel validity (no-data texels), keep-previous rule, valid-average
@@ -730,15 +826,15 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
 }
 
 // fast / non-staged variants: workgroup = (tile, part of its chunks), XCD-contiguous order
-template <bool kStaged, bool kGeneric>
-__global__ __launch_bounds__(256, 4) void fused_main_kernel(FusedArgs A) {
+template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_main_kernel(FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t work = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t chunks_per_tile = (A.m.center_size + kMainRows - 1) / kMainRows;
     const uint32_t part = work % A.groups;
     const uint32_t k_begin = part * chunks_per_tile / A.groups, k_end = (part + 1) * chunks_per_tile / A.groups;
     if (k_begin >= k_end) return;  // more parts than chunks (tiny tiles)
-    fused_main_chunks<kStaged, kGeneric>(A, work / A.groups, k_begin, k_end, smem);
+    fused_main_chunks<kStaged, kGeneric, kT, kP>(A, work / A.groups, k_begin, k_end, smem);
 }
 
 // generic variant over the chunks the fast variant left in A.todo; the last workgroup resets the list
@@ -748,7 +844,7 @@ __global__ __launch_bounds__(256, 4) void fused_todo_kernel(FusedArgs A) {
     const uint32_t count = A.todo[0];
     for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
         const uint32_t entry = A.todo[2 + e];
-        fused_main_chunks<true, true>(A, entry / chunks_per_tile, entry % chunks_per_tile, entry % chunks_per_tile + 1, smem);
+        fused_main_chunks<true, true, 0, 0>(A, entry / chunks_per_tile, entry % chunks_per_tile, entry % chunks_per_tile + 1, smem);
         __syncthreads();  // LDS is reused by the next entry
     }
     if (threadIdx.x == 0) {
@@ -1030,9 +1126,16 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         main_job.args.item_count = uint32_t(items.size());
         {
             const uint32_t chunks = (m.center_size + kMainRows - 1) / kMainRows;
+            // 4 workgroups of 4 waves per CU (128 VGPRs each) = 1024 resident: pick the number of parts per tile so
+            // that the grid is a whole number of 1024-workgroup rounds where possible
             uint32_t parts = 1;
-            while (parts < chunks && uint64_t(items.size()) * parts < 1024) parts *= 2;
-            main_job.args.groups = std::min(parts, chunks);
+            if (const char* e = getenv("BT_FUSED_PARTS")) parts = uint32_t(atoi(e));
+            else {
+                while (parts < chunks && uint64_t(items.size()) * parts < 1024) parts++;
+                for (uint32_t cand = parts; cand <= std::min(chunks, parts + 8); cand++)
+                    if ((uint64_t(items.size()) * cand) % 1024 == 0) { parts = cand; break; }
+            }
+            main_job.args.groups = std::max(1u, std::min(parts, chunks));
         }
         {   // LDS window of a workgroup: T consecutive mosaic columns x (kMainRows + 2b) mosaic rows of the source
             double ratio_x = 0.0, ratio_y = 0.0;
@@ -1162,10 +1265,13 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
         fused_corner_kernel<<<job.args.item_count, 64, 0, p->ctx->stream>>>(job.args);
         if (job.args.lds_rows) {
             const size_t lds = sizeof(MainShared) + size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
-            fused_main_kernel<true, false><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
+            if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528)
+                fused_main_kernel<true, false, 512, 528><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
+            else
+                fused_main_kernel<true, false, 0, 0><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
             fused_todo_kernel<<<std::min(blocks, 1024u), 256, lds, p->ctx->stream>>>(job.args);
         } else {
-            fused_main_kernel<false, true><<<blocks, 256, sizeof(MainShared), p->ctx->stream>>>(job.args);
+            fused_main_kernel<false, true, 0, 0><<<blocks, 256, sizeof(MainShared), p->ctx->stream>>>(job.args);
         }
     } else {
         const uint32_t size = (1u << job.args.lod) * job.args.m.center_size;
