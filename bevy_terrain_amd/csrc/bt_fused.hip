@@ -878,54 +878,75 @@ __global__ __launch_bounds__(64) void fused_corner_kernel(FusedArgs A) {
 }
 
 // ---- fused_tail: up to three LODs below `A.lod`, read from the atlas ---------------------------------
-// Workgroup = 32 x 32 pixels of the LOD-`lod` mosaic (16 x 16 threads, 2 x 2 pixels each).
+// Workgroup = 64 x 64 pixels of the LOD-`lod` mosaic, 16 x 16 threads, 4 x 4 input pixels per thread: a thread
+// owns 2 x 2 pixels of lod-1 and one pixel of lod-2 in registers; 2 x 2 neighbouring threads (lanes l, l+1,
+// l+16, l+17 of one wave) combine into one pixel of lod-3 with three shuffles.  No LDS, no barrier, one tile
+// lookup per thread and LOD (c % 4 == 0: a 4 x 4 block never straddles a tile).
 __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
-    __shared__ uint16_t s_l1[16][16];
-    __shared__ uint16_t s_l2[8][8];
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
-    const uint64_t tile_texels = uint64_t(T) * T;
+    const uint32_t tile_texels = T * T;
     const uint32_t side = blockIdx.z;
-    const uint32_t size = (1u << A.lod) * c;  // mosaic extent of the input LOD
+    const uint32_t size = (1u << A.lod) * c;  // mosaic extent of the input LOD (a multiple of 4)
     const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
-    const uint32_t gx = blockIdx.x * 32u + 2u * tx, gy = blockIdx.y * 32u + 2u * ty;  // first input pixel
+    const uint32_t gx = blockIdx.x * 64u + 4u * tx, gy = blockIdx.y * 64u + 4u * ty;  // first input pixel
+    const bool active = gx < size && gy < size;
 
-    // level 1 (lod - 1): one pixel per thread
-    uint32_t v1 = 0;
-    const bool in1 = gx < size && gy < size;
-    if (in1) {
-        uint32_t t[4];
+    uint32_t t[4][4];  // [row][col]
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {  // (dx, dy) = (0,0),(0,1),(1,0),(1,1)
-            const uint32_t x = gx + (k >> 1), y = gy + (k & 1u);
-            const uint32_t idx = grid_lookup(A, side, A.lod, int(x / c), int(y / c));
-            t[k] = idx == kInvalid ? 0u : A.atlas[uint64_t(idx) * tile_texels + uint64_t(b + y % c) * T + b + x % c];
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) t[r][k] = 0;
+    // all tile lookups up front (independent of the data): one round of memory latency instead of four
+    uint32_t idx = kInvalid, self1 = kInvalid, self2 = kInvalid, self3 = kInvalid;
+    if (active) {
+        idx = grid_lookup(A, side, A.lod, int(gx / c), int(gy / c));
+        self1 = grid_lookup(A, side, A.lod - 1, int((gx >> 1) / c), int((gy >> 1) / c));
+        if (A.levels >= 2) self2 = grid_lookup(A, side, A.lod - 2, int((gx >> 2) / c), int((gy >> 2) / c));
+        if (A.levels >= 3) self3 = grid_lookup(A, side, A.lod - 3, int((gx >> 3) / c), int((gy >> 3) / c));
+    }
+    if (active) {
+        if (idx != kInvalid) {  // an absent tile reads as no data
+            const uint16_t* p = A.atlas + uint64_t(idx) * tile_texels + (b + gy % c) * T + b + gx % c;  // 4-byte aligned (b even)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t lo = *reinterpret_cast<const uint32_t*>(p + r * T), hi = *reinterpret_cast<const uint32_t*>(p + r * T + 2);
+                t[r][0] = lo & 0xFFFFu;
+                t[r][1] = lo >> 16;
+                t[r][2] = hi & 0xFFFFu;
+                t[r][3] = hi >> 16;
+            }
         }
-        v1 = downsample4(t[0], t[1], t[2], t[3]);
+    }
+    // lod-1: 2 x 2 pixels, each from a 2 x 2 block in OFFSETS order (0,0),(0,1),(1,0),(1,1) of (dx, dy)
+    uint32_t q[2][2];  // [row][col]
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) q[r][k] = downsample4(t[2 * r][2 * k], t[2 * r + 1][2 * k], t[2 * r][2 * k + 1], t[2 * r + 1][2 * k + 1]);
+    if (active) {
         const uint32_t x1 = gx >> 1, y1 = gy >> 1;
-        const uint32_t self = grid_lookup(A, side, A.lod - 1, int(x1 / c), int(y1 / c));
-        if (self != kInvalid) push_pixel(A, side, A.lod - 1, x1 / c, y1 / c, self, x1 % c, y1 % c, uint16_t(v1));
+        const uint32_t self = self1;
+        if (self != kInvalid) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int k = 0; k < 2; k++) push_pixel(A, side, A.lod - 1, x1 / c, y1 / c, self, x1 % c + k, y1 % c + r, uint16_t(q[r][k]));
+        }
     }
     if (A.levels < 2) return;
-    s_l1[ty][tx] = uint16_t(v1);
-    __syncthreads();
-    // level 2: 8 x 8 per workgroup
-    uint32_t v2 = 0;
-    const uint32_t ux = threadIdx.x & 7u, uy = (threadIdx.x >> 3) & 7u;
-    const bool act2 = threadIdx.x < 64 && (blockIdx.x * 32u + 4u * ux) < size && (blockIdx.y * 32u + 4u * uy) < size;
-    if (act2) {
-        v2 = downsample4(s_l1[2 * uy][2 * ux], s_l1[2 * uy + 1][2 * ux], s_l1[2 * uy][2 * ux + 1], s_l1[2 * uy + 1][2 * ux + 1]);
-        const uint32_t x2 = blockIdx.x * 8u + ux, y2 = blockIdx.y * 8u + uy;
-        const uint32_t self = grid_lookup(A, side, A.lod - 2, int(x2 / c), int(y2 / c));
+    const uint32_t v2 = downsample4(q[0][0], q[1][0], q[0][1], q[1][1]);
+    if (active) {
+        const uint32_t x2 = gx >> 2, y2 = gy >> 2;
+        const uint32_t self = self2;
         if (self != kInvalid) push_pixel(A, side, A.lod - 2, x2 / c, y2 / c, self, x2 % c, y2 % c, uint16_t(v2));
     }
     if (A.levels < 3) return;
-    if (threadIdx.x < 64) s_l2[uy][ux] = uint16_t(v2);
-    __syncthreads();
-    const uint32_t wx = threadIdx.x & 3u, wy = (threadIdx.x >> 2) & 3u;
-    if (threadIdx.x < 16 && (blockIdx.x * 32u + 8u * wx) < size && (blockIdx.y * 32u + 8u * wy) < size) {
-        const uint32_t v3 = downsample4(s_l2[2 * wy][2 * wx], s_l2[2 * wy + 1][2 * wx], s_l2[2 * wy][2 * wx + 1], s_l2[2 * wy + 1][2 * wx + 1]);
-        const uint32_t x3 = blockIdx.x * 4u + wx, y3 = blockIdx.y * 4u + wy;
-        const uint32_t self = grid_lookup(A, side, A.lod - 3, int(x3 / c), int(y3 / c));
+    // lod-3: threads (tx, ty) with both even own the pixel; partners are lanes +1 (dx), +16 (dy), +17
+    const uint32_t right = __shfl_down(v2, 1), below = __shfl_down(v2, 16), diag = __shfl_down(v2, 17);
+    if (active && ((tx | ty) & 1u) == 0) {
+        const uint32_t v3 = downsample4(v2, below, right, diag);
+        const uint32_t x3 = gx >> 3, y3 = gy >> 3;
+        const uint32_t self = self3;
         if (self != kInvalid) push_pixel(A, side, A.lod - 3, x3 / c, y3 / c, self, x3 % c, y3 % c, uint16_t(v3));
     }
 }
@@ -1275,7 +1296,7 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
         }
     } else {
         const uint32_t size = (1u << job.args.lod) * job.args.m.center_size;
-        const dim3 grid((size + 31) / 32, (size + 31) / 32, job.args.sides);
+        const dim3 grid((size + 63) / 64, (size + 63) / 64, job.args.sides);
         fused_tail_kernel<<<grid, 256, 0, p->ctx->stream>>>(job.args);
     }
     hipError_t e = hipGetLastError();
