@@ -234,10 +234,9 @@ struct RowParam {  // one centre row of the workgroup: LDS slots of its two sour
 };
 
 struct MainShared {  // fixed part of the dynamic LDS block (size is a multiple of 16 bytes)
-    RowParam rows[2][kMainRows];  // double buffered: chunk k uses rows[k & 1]
-    float fy[2][kMainRows];       // the y weights again, packed for two 16-byte uniform reads
-    uint32_t consecutive[2];      // chunk's rows use source rows y, y+1, ..., y+kMainRows (one step per row)
-    uint32_t pad2[2];
+    RowParam rows[3][kMainRows];  // chunk k uses rows[k % 3]: k+2 is filled while k is shaded and k+1 staged
+    float fy[3][kMainRows];       // the y weights again, packed for two 16-byte uniform reads
+    uint32_t consecutive[4];      // [k % 3]: chunk's rows use source rows y, y+1, ..., y+kMainRows (one step per row)
     RowParam apron[2 * kMaxBorder];  // [0, b): top apron rows, [b, 2b): bottom apron rows (pad = mosaic row ry)
     uint32_t nb[2][8];  // neighbours (N,E,S,W,NW,NE,SE,SW) of the parent [0] and grand-parent [1] tile
     int xmin, xmax;
@@ -355,7 +354,8 @@ __device__ __forceinline__ Texel4 convert4(uint32_t ta0, uint32_t ta1, uint32_t 
 template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP>
 __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t item_index, uint32_t k_begin, uint32_t k_end, uint8_t* smem) {
     MainShared& S = *reinterpret_cast<MainShared*>(smem);
-    uint16_t* s_src = reinterpret_cast<uint16_t*>(smem + sizeof(MainShared));
+    uint16_t* s_buf = reinterpret_cast<uint16_t*>(smem + sizeof(MainShared));
+    const uint32_t buf_texels = A.lds_rows * (kP ? kP : A.lds_pitch);  // two staging buffers (chunk parity)
 
     // A workgroup is persistent over a run of row chunks (kMainRows centre rows each) of ONE finest tile:
     // the column parameters, neighbour tables and push constants are computed once, and while chunk k is
@@ -379,16 +379,16 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         const uint32_t cr = k * kMainRows + tid;
         if (tid < kMainRows && cr < c) {
             const Axis ay = split_axis(cr, c, it.y, scale, A.tly, A.bry, raster.height);
-            RowParam& r = S.rows[k & 1u][tid];
+            RowParam& r = S.rows[k % 3u][tid];
             r.y0 = ay.i0;
             r.y1 = ay.i1;
             r.fy = ay.fr;
-            S.fy[k & 1u][tid] = ay.fr;
+            S.fy[k % 3u][tid] = ay.fr;
             // y0 of row i == y0 of row 0 + i and y1 == y0 + 1 for every row of a full chunk
             const int first = __shfl(ay.i0, 0);
             const bool ok = ay.i0 == first + int(tid) && ay.i1 == ay.i0 + 1;
             const unsigned long long all = __ballot(ok);
-            if (tid == 0) S.consecutive[k & 1u] = (all & ((1ull << kMainRows) - 1)) == ((1ull << kMainRows) - 1) && k * kMainRows + kMainRows <= c;
+            if (tid == 0) S.consecutive[k % 3u] = (all & ((1ull << kMainRows) - 1)) == ((1ull << kMainRows) - 1) && k * kMainRows + kMainRows <= c;
         }
     };
     fill_rows(k_begin);
@@ -465,7 +465,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
 
     auto chunk_rows = [&](uint32_t k) -> uint32_t { return min(kMainRows, c - k * kMainRows); };
     auto window = [&](uint32_t k, int& ymin, uint32_t& slots) {  // workgroup-uniform
-        const RowParam* rows = S.rows[k & 1u];
+        const RowParam* rows = S.rows[k % 3u];
         const uint32_t n = chunk_rows(k);
         int lo = rows[0].y0, hi = rows[n - 1].y1;
         if (k == 0) lo = min(lo, S.apron[0].y0);
@@ -485,7 +485,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         }
     };
     // registers -> LDS; returns this thread's "saw a no-data texel" bit
-    auto stage_commit = [&](uint32_t slots, const u32x4 (&v)[kBatch]) -> bool {
+    auto stage_commit = [&](uint16_t* s_src, uint32_t slots, const u32x4 (&v)[kBatch]) -> bool {
         const uint32_t total = slots * chunks_per_row;
         u16x2 zmin = {1, 1};
 #pragma unroll
@@ -500,7 +500,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         return zmin.x == 0 || zmin.y == 0;
     };
     // unaligned rasters (odd widths / pitches): texel by texel, no prefetch
-    auto stage_narrow = [&](int ymin, uint32_t slots) -> bool {
+    auto stage_narrow = [&](uint16_t* s_src, int ymin, uint32_t slots) -> bool {
         bool z = false;
         for (uint32_t i = tid; i < slots * P; i += 256u) {
             const uint32_t slot = i / P, kk = i - slot * P;
@@ -520,9 +520,6 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     const uint32_t cx4 = (it.x & 1u) * half_c + tid, cy4_base = (it.y & 1u) * half_c;
     const uint32_t cx3 = (it.x & 3u) * (c / 4) + (tid >> 1), cy3_base = (it.y & 3u) * (c / 4);
     const bool do4 = A.levels >= 2 && !(A.ablate & 1u), do3 = A.levels >= 3 && !(A.ablate & 1u);
-    PushX px4{}, px3{};
-    if (do4 && is_centre) px4 = make_push_x(A, S.nb[0], cx4);
-    if (do3 && is_centre) px3 = make_push_x(A, S.nb[1], cx3);
     // LDS offsets of this thread's four source columns (idle lanes read column 0 and store nothing)
     const uint32_t la0 = uint32_t(axa.i0 - xa), la1 = uint32_t(axa.i1 - xa), lb0 = uint32_t(axb.i0 - xa), lb1 = uint32_t(axb.i1 - xa);
 
@@ -535,17 +532,19 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     if (kStaged && !(A.ablate & 8u)) {
         if (wide) {
             stage_issue(ymin, slots, pre);
-            nodata = stage_commit(slots, pre);
+            nodata = stage_commit(s_buf + (k_begin & 1u) * buf_texels, slots, pre);
         } else {
-            nodata = stage_narrow(ymin, slots);
+            nodata = stage_narrow(s_buf + (k_begin & 1u) * buf_texels, ymin, slots);
         }
     }
     if (k_begin + 1 < k_end) fill_rows(k_begin + 1);
+    if (k_begin + 2 < k_end) fill_rows(k_begin + 2);
     bool has_nodata = __syncthreads_or(nodata) != 0;
 
     for (uint32_t k = k_begin; k < k_end; k++) {
-        const RowParam* rows = S.rows[k & 1u];
+        const RowParam* rows = S.rows[k % 3u];
         const uint32_t cr0 = k * kMainRows, nrows = chunk_rows(k);
+        uint16_t* s_src = s_buf + (k & 1u) * buf_texels;  // this chunk's staged rows; the other half receives chunk k + 1
         const int cur_ymin = ymin;
         // prefetch the next chunk's source rows while this one is shaded
         int next_ymin = 0;
@@ -598,79 +597,85 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                 typedef float f2 __attribute__((ext_vector_type(2)));
                 const f2 gx = {gxa, gxb}, fx = {fxa, fxb};
                 const f2 kr = {1.0f / 65535.0f, 1.0f / 65535.0f}, kn = {65535.0f, 65535.0f}, khalf = {0.5f, 0.5f};
-                const f2 kzero = {0.0f, 0.0f}, kone = {1.0f, 1.0f}, kquarter = {0.25f, 0.25f};
+                const f2 kzero = {0.0f, 0.0f}, kquarter = {0.25f, 0.25f};
                 auto conv2 = [&](uint32_t ta, uint32_t tb) -> f2 {  // (ta, tb) / 65535, correctly rounded (see header)
                     const f2 x = {float(ta), float(tb)};
                     const f2 q0 = x * kr;
                     const f2 e = __builtin_elementwise_fma(-q0, kn, x);
                     return __builtin_elementwise_fma(e, kr, q0);
                 };
-                auto quantise = [&](f2 v) -> f2 {  // 0.5 + 65535 * clamp(v, 0, 1); the u32 conversion then floors
-                    const f2 cl = __builtin_elementwise_min(__builtin_elementwise_max(v, kzero), kone);
-                    return khalf + kn * cl;
-                };
+                // 0.5 + 65535 * clamp(v, 0, 1); the u32 conversion then floors.  In this loop every input lies in
+                // (0, 1] and the weights in [0, 1], so v is in (0, 1 + a few ulp]: the clamp can only act on an excess
+                // of ~1e-7, and floor(0.5 + 65535 * (1 + 1e-7)) = 65535 = floor(0.5 + 65535 * 1) — it is a no-op on the
+                // result and is left out (tests: saturated rasters, all-65535 blocks).
+                auto quantise = [&](f2 v) -> f2 { return khalf + kn * v; };
                 const uint32_t cy4_first = cy4_base + (cr0 >> 1), cy3_first = cy3_base + (cr0 >> 2);
                 const bool interior4 = cy4_first >= b && cy4_first + kMainRows / 2 <= c - b;
                 const bool interior3 = cy3_first >= b && cy3_first + kMainRows / 4 <= c - b;
-                if (kMainRows == 8 && __builtin_amdgcn_readfirstlane(S.consecutive[k & 1u]) && (!do4 || interior4) && (!do3 || interior3)) {
+                if (kMainRows == 8 && __builtin_amdgcn_readfirstlane(S.consecutive[k % 3u]) && (!do4 || interior4) && (!do3 || interior3)) {
                     // ---- static fast path: the 8 rows use 9 consecutive source rows and stay clear of the parents'
-                    // top / bottom strips: straight-line code, row offsets are immediates, no per-row decisions
+                    // top / bottom strips: straight-line code, row offsets are immediates, no per-row decisions.
+                    // Rolling over the source rows (two live horizontal blends) in two quads of output rows; the
+                    // four texels of the next source row are requested before the current row is converted, so the
+                    // LDS latency hides behind the packed arithmetic.
                     const uint16_t* base = s_src + uint32_t(__builtin_amdgcn_readfirstlane(rows[0].y0) - cur_ymin) * P;
                     const uint16_t *pa0 = base + la0, *pa1 = base + la1, *pb0 = base + lb0, *pb1 = base + lb1;
-                    // software pipelined: the four texels of row r + 1 are requested before row r is converted, so the
-                    // LDS latency hides behind the packed arithmetic of the previous row
-                    f2 h[kMainRows + 1];
+                    const float* fyt = S.fy[k % 3u];
                     uint32_t t0 = pa0[0], t1 = pb0[0], t2 = pa1[0], t3 = pb1[0];
+                    uint32_t n0 = pa0[P], n1 = pb0[P], n2 = pa1[P], n3 = pb1[P];
+                    f2 hprev = conv2(t0, t1) * gx + conv2(t2, t3) * fx;
+                    uint32_t q[4];
+                    uint32_t* dst5 = tile5_u32 + (((b + cr0) * T + px0) >> 1);
 #pragma unroll
-                    for (uint32_t r = 0; r <= kMainRows; r++) {
-                        uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-                        if (r < kMainRows) {
-                            n0 = pa0[(r + 1) * P];
-                            n1 = pb0[(r + 1) * P];
-                            n2 = pa1[(r + 1) * P];
-                            n3 = pb1[(r + 1) * P];
+                    for (uint32_t quad = 0; quad < 2; quad++) {
+                        uint32_t ua[4], ub[4];
+#pragma unroll
+                        for (uint32_t i = 0; i < 4; i++) {
+                            const uint32_t r = 4 * quad + i;  // output row; needs source rows r and r + 1
+                            t0 = n0;
+                            t1 = n1;
+                            t2 = n2;
+                            t3 = n3;
+                            if (r + 2 <= kMainRows) {
+                                n0 = pa0[(r + 2) * P];
+                                n1 = pb0[(r + 2) * P];
+                                n2 = pa1[(r + 2) * P];
+                                n3 = pb1[(r + 2) * P];
+                            }
+                            const f2 hnew = conv2(t0, t1) * gx + conv2(t2, t3) * fx;
+                            const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fyt[r])));
+                            const f2 fy2 = {fy, fy}, gy2 = {1.0f - fy, 1.0f - fy};
+                            const f2 w = quantise(hprev * gy2 + hnew * fy2);
+                            hprev = hnew;
+                            ua[i] = uint32_t(w.x);
+                            ub[i] = uint32_t(w.y);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
-                        h[r] = conv2(t0, t1) * gx + conv2(t2, t3) * fx;
-                        __builtin_amdgcn_sched_barrier(0);
-                        t0 = n0;
-                        t1 = n1;
-                        t2 = n2;
-                        t3 = n3;
-                    }
-                    uint32_t ua[kMainRows], ub[kMainRows];
-                    const float* fyt = S.fy[k & 1u];
+                        if (!is_idle && !(A.ablate & 2u)) {
 #pragma unroll
-                    for (uint32_t i = 0; i < kMainRows; i++) {
-                        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fyt[i])));
-                        const f2 fy2 = {fy, fy}, gy2 = {1.0f - fy, 1.0f - fy};
-                        const f2 w = quantise(h[i] * gy2 + h[i + 1] * fy2);
-                        ua[i] = uint32_t(w.x);
-                        ub[i] = uint32_t(w.y);
-                    }
-                    if (!is_idle && !(A.ablate & 2u)) {
-                        uint32_t* dst = tile5_u32 + (((b + cr0) * T + px0) >> 1);
-#pragma unroll
-                        for (uint32_t i = 0; i < kMainRows; i++) dst[i * (T / 2)] = ua[i] | (ub[i] << 16);
+                            for (uint32_t i = 0; i < 4; i++) dst5[(4 * quad + i) * (T / 2)] = ua[i] | (ub[i] << 16);
+                        }
+                        if (do4) {
+                            // two level-1 pixels (row pairs 0-1, 2-3 of the quad), one per packed lane: ((a0 + a1) + b0) + b1, / 4
+                            const f2 sum = ((conv2(ua[0], ua[2]) + conv2(ua[1], ua[3])) + conv2(ub[0], ub[2])) + conv2(ub[1], ub[3]);
+                            const f2 wq = quantise(sum * kquarter);
+                            q[2 * quad] = uint32_t(wq.x);
+                            q[2 * quad + 1] = uint32_t(wq.y);
+                        }
                     }
                     if (do4) {
-                        // four level-1 pixels per thread (row pairs 0-1 .. 6-7), two per packed op: ((a0 + a1) + b0) + b1, / 4
-                        uint32_t q[4];
-#pragma unroll
-                        for (uint32_t j = 0; j < 2; j++) {
-                            const uint32_t r = 4 * j;
-                            const f2 sum = ((conv2(ua[r], ua[r + 2]) + conv2(ua[r + 1], ua[r + 3])) + conv2(ub[r], ub[r + 2])) + conv2(ub[r + 1], ub[r + 3]);
-                            const f2 wq = quantise(sum * kquarter);
-                            q[2 * j] = uint32_t(wq.x);
-                            q[2 * j + 1] = uint32_t(wq.y);
-                        }
+                        // the parent's x edge: first / last b columns of the parent tile also feed an apron (its x
+                        // neighbour's, or the own one when that neighbour is absent); only a few lanes of a tile take this
+                        const bool xedge4 = is_centre && (cx4 < b || cx4 >= c - b);
                         if (is_centre) {
-                            uint16_t* dst = tile4 + (b + cy4_first) * T + px4.centre;
+                            uint16_t* dst = tile4 + (b + cy4_first) * T + b + cx4;
 #pragma unroll
                             for (uint32_t j = 0; j < 4; j++) dst[j * T] = uint16_t(q[j]);
-                            if (px4.extra_count) {  // first / last columns of the parent's quadrant: the x neighbour's apron or the own one
-                                uint16_t* t = (px4.other_tile ? A.atlas + uint64_t(px4.extra_tile) * tile_texels : tile4) + (b + cy4_first) * T + px4.extra_base;
-                                for (uint32_t e = 0; e < px4.extra_count; e++)
+                        }
+                        if (xedge4) {
+                            const PushX px = make_push_x(A, S.nb[0], cx4);
+                            if (px.extra_count) {
+                                uint16_t* t = (px.other_tile ? A.atlas + uint64_t(px.extra_tile) * tile_texels : tile4) + (b + cy4_first) * T + px.extra_base;
+                                for (uint32_t e = 0; e < px.extra_count; e++)
 #pragma unroll
                                     for (uint32_t j = 0; j < 4; j++) t[j * T + e] = uint16_t(q[j]);
                             }
@@ -685,13 +690,14 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             const uint32_t r0 = even ? recv0 : q[2], r1 = even ? recv1 : q[3];  // x odd column (dx = 1)
                             const f2 left = conv2(l0, l1), right = conv2(r0, r1);
                             const float s3 = ((left.x + left.y) + right.x) + right.y;
-                            const uint32_t w3 = float_to_unorm16(s3 * 0.25f);
-                            if (is_centre) {
-                                const uint32_t row3 = (b + cy3_first + (even ? 0u : 1u)) * T;
-                                tile3[row3 + px3.centre] = uint16_t(w3);
-                                if (px3.extra_count) {
-                                    uint16_t* t = (px3.other_tile ? A.atlas + uint64_t(px3.extra_tile) * tile_texels : tile3) + row3 + px3.extra_base;
-                                    for (uint32_t e = 0; e < px3.extra_count; e++) t[e] = uint16_t(w3);
+                            const uint32_t w3 = uint32_t(0.5f + 65535.0f * (s3 * 0.25f));  // clamp is a no-op here, see quantise
+                            const uint32_t row3 = (b + cy3_first + (even ? 0u : 1u)) * T;
+                            if (is_centre) tile3[row3 + b + cx3] = uint16_t(w3);
+                            if (is_centre && (cx3 < b || cx3 >= c - b)) {
+                                const PushX px = make_push_x(A, S.nb[1], cx3);
+                                if (px.extra_count) {
+                                    uint16_t* t = (px.other_tile ? A.atlas + uint64_t(px.extra_tile) * tile_texels : tile3) + row3 + px.extra_base;
+                                    for (uint32_t e = 0; e < px.extra_count; e++) t[e] = uint16_t(w3);
                                 }
                             }
                         }
@@ -737,6 +743,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                 push_pixel_lds(A, S.nb[0], tile4, cx4, cy4, uint16_t(q0));
                                 push_pixel_lds(A, S.nb[0], tile4, cx4, cy4 + 1, uint16_t(q1));
                             } else {
+                                const PushX px4 = make_push_x(A, S.nb[0], cx4);
                                 push_fast(A, px4, tile4, cy4, uint16_t(q0));
                                 push_fast(A, px4, tile4, cy4 + 1, uint16_t(q1));
                             }
@@ -749,7 +756,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                 const uint32_t w3 = float_to_unorm16(s3 * 0.25f);
                                 const uint32_t cy3 = cy3_base + (cy >> 2);
                                 if (cy3 < b || cy3 >= c - b) push_pixel_lds(A, S.nb[1], tile3, cx3, cy3, uint16_t(w3));
-                                else push_fast(A, px3, tile3, cy3, uint16_t(w3));
+                                else push_fast(A, make_push_x(A, S.nb[1], cx3), tile3, cy3, uint16_t(w3));
                             }
                         }
                     }
@@ -815,13 +822,17 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         }
 
         if (!more) break;
-        __syncthreads();  // everyone is done with this chunk's LDS rows and row table
+        // chunk k + 1 goes into the other staging buffer (nobody reads it any more: its last readers passed the
+        // previous barrier), the row table of chunk k + 3 replaces the one of chunk k after the barrier
         nodata = !kStaged;
-        if (kStaged && !(A.ablate & 8u)) nodata = wide ? stage_commit(next_slots, pre) : stage_narrow(next_ymin, next_slots);
-        if (k + 2 < k_end) fill_rows(k + 2);
+        if (kStaged && !(A.ablate & 8u)) {
+            uint16_t* s_next = s_buf + ((k + 1) & 1u) * buf_texels;
+            nodata = wide ? stage_commit(s_next, next_slots, pre) : stage_narrow(s_next, next_ymin, next_slots);
+        }
         ymin = next_ymin;
         slots = next_slots;
         has_nodata = __syncthreads_or(nodata) != 0;
+        if (k + 3 < k_end) fill_rows(k + 3);  // rows[k % 3] is free now; visible to everyone after the next barrier
     }
 }
 
@@ -1175,7 +1186,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             // the whole window must fit (the bounds above are conservative); otherwise lds_rows = 0 selects the
             // kernel variant that reads the source directly
             // the staging loop holds one batch of 8 x 16-byte loads per thread: the window must fit that too
-            main_job.args.lds_rows = (rows_needed * pitch * 2 <= budget && rows_needed * (pitch / 8) <= 256 * 4) ? uint32_t(rows_needed) : 0u;
+            main_job.args.lds_rows = (2 * rows_needed * pitch * 2 <= budget && rows_needed * (pitch / 8) <= 256 * 4) ? uint32_t(rows_needed) : 0u;
         }
         Launch lm{};
         lm.kind = kLaunchFusedMain;
@@ -1285,7 +1296,7 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
         const uint32_t blocks = job.args.item_count * job.args.groups;
         fused_corner_kernel<<<job.args.item_count, 64, 0, p->ctx->stream>>>(job.args);
         if (job.args.lds_rows) {
-            const size_t lds = sizeof(MainShared) + size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
+            const size_t lds = sizeof(MainShared) + 2 * size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
             if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528)
                 fused_main_kernel<true, false, 512, 528><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
             else

@@ -176,3 +176,15 @@ def test_fast_unorm_conversion_is_exact_on_device(device):
     failures = C.c_uint32(123)
     bt._ffi.check(bt._ffi.lib().bt_selftest(device._h, C.byref(failures)))
     assert failures.value == 0
+
+
+@pytest.mark.parametrize("generic", [True, False])
+def test_saturated_and_flat_rasters(device, generic):
+    # blends of all-65535 texels round to 1 + ulp before the clamp: the fused fast loop drops the clamp, so pin it
+    src = np.full((1100, 1100), 65535, np.uint16)
+    src[300:500, :] = 65534
+    src[:, 700:] = 1
+    src[900:, 900:] = K.random_raster(O.FORMAT_R16, 200, 200, seed=77)
+    atlas, _ = K.product_planar(device, src, 4, 512, 2, O.FORMAT_R16, atlas_size=128, generic=generic)
+    oracle = K.oracle_planar(src, 4, 512, 2, O.FORMAT_R16, atlas_size=128)
+    assert K.assert_atlas_equal(atlas, oracle) == 85

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Times the tiling prepass (one persistent launch per frame) on scripted camera paths; prints one JSON line.
+Not the headline benchmark (bench.py) — refinement is latency-bound: 10^2..10^4 tiles x 16 B per frame."""
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import bevy_terrain_amd as bt
+
+
+def main():
+    device = bt.Device(0)
+    out = {}
+    for name, model, positions in (
+        ("planar_side1000", bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 250.0),
+         [(700.0 * (1 - 0.9 * t) * math.cos(19 * t), 900.0 - 770.0 * t, 700.0 * (1 - 0.9 * t) * math.sin(19 * t)) for t in np.linspace(0, 1, 64)]),
+        ("sphere_earth", bt.TerrainModel.sphere((0.0, 0.0, 0.0), 6371000.0, -12000.0, 9000.0),
+         [tuple(np.array([0.3 + math.cos(9 * t) * (1 - t), 0.9, 0.2 + math.sin(9 * t) * (1 - t)]) /
+                np.linalg.norm([0.3 + math.cos(9 * t) * (1 - t), 0.9, 0.2 + math.sin(9 * t) * (1 - t)]) * (6371000.0 + 4.0e6 * (1 - t) + 2.0e3))
+          for t in np.linspace(0, 1, 64)]),
+    ):
+        cfg = bt.TerrainViewConfig()
+        prepass = bt.TilingPrepass(device, cfg.geometry_tile_count)
+        views = [bt.make_view_state(model, cfg, p) for p in positions]
+        for v in views[:4]:
+            prepass.run(v)
+        device.synchronize()
+        counts, ms = [], []
+        for v in views:
+            device.timer_begin()
+            prepass.run(v)
+            ms.append(device.timer_end())
+            tiles, _ = prepass.read()
+            counts.append(len(tiles))
+        out[name] = {"frames": len(views), "us_per_frame_avg": 1e3 * float(np.mean(ms)), "us_per_frame_max": 1e3 * float(np.max(ms)),
+                     "final_tiles_avg": float(np.mean(counts)), "final_tiles_max": int(np.max(counts)),
+                     "launches_per_frame": 1, "reference_dispatches_per_frame": 2 * cfg.refinement_count + 3}
+    print(json.dumps({"tiling_prepass": out}))
+
+
+if __name__ == "__main__":
+    main()
