@@ -134,3 +134,36 @@ def test_unshardable_job_runs_everything_on_every_rank():
     assert shard_ranges(pre) == []
     device.synchronize()
     assert K.assert_atlas_equal(atlas, K.oracle_planar(src, 3, 32, 2, O.FORMAT_R16, atlas_size=64)) == 21
+
+
+@pytest.mark.gpu
+def test_nccl_single_rank_group_runs_the_sharded_step():
+    """The 8-GPU run belongs to the driver; on the 1-GPU box at least the exact code path of bench.py --gpus N
+    (device bytes -> torch tensor, in-place all_gather_into_tensor on the kernels' stream, LOCAL / FINISH runs)
+    must work with a world of one RCCL rank."""
+    import torch
+    import torch.distributed as dist
+
+    import bevy_terrain_amd as bt
+    from bevy_terrain_amd.shard import ShardedPreprocess, all_gather_ranges
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        device = bt.Device(0)
+        src = K.random_raster(O.FORMAT_R16, 1100, 1100, seed=33)
+        cfg = bt.TerrainConfig(lod_count=4, atlas_size=128, path="t", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+        cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=128, border_size=2))
+        atlas = bt.TileAtlas.new(cfg, device)
+        job = ShardedPreprocess(bt.Preprocessor.new(), atlas, bt.AssetServer().insert("s", src), "s", range(0, 4), 0, 1)
+        job.step()
+        job.step(profile=True)
+        # an explicit in-place gather over the atlas bytes (world 1: send == recv)
+        with torch.cuda.stream(device.torch_stream):
+            all_gather_ranges(job.storage, job.tile_bytes, [dict(first_layer=0, layers_per_rank=64)], 0, 1, dist)
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert K.assert_atlas_equal(atlas, K.oracle_planar(src, 4, 128, 2, O.FORMAT_R16, atlas_size=128)) == 85
+    finally:
+        dist.destroy_process_group()
