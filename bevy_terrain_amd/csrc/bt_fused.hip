@@ -55,7 +55,8 @@ struct FusedArgs {
     uint32_t sides;       // fused_tail: 1 or 6
     uint32_t lds_pitch;   // fused_main: texels per staged source row (multiple of 8)
     uint32_t lds_rows;    // fused_main: staged source rows that fit
-    uint32_t* todo;       // fused_main: [0] count, [1] finished workgroups, [2..] chunks (item * chunks_per_tile + k) left to the generic variant
+    uint32_t* todo;       // fused_main: [0] count, [2..] chunks (item * chunks_per_tile + k) left to the generic variant
+    uint32_t* todo_next;  // the list of the NEXT run (the two alternate): fused_todo zeroes its count, so no reset protocol
     uint32_t ablate;      // debug only (env BT_FUSED_ABLATE): 1 no pyramid, 2 no finest stores, 4 no shading, 8 no staging loads, 16 prologue only, 32 no packed fast loop
 };
 
@@ -848,8 +849,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     fused_main_chunks<kStaged, kGeneric, kT, kP>(A, work / A.groups, k_begin, k_end, smem);
 }
 
-// generic variant over the chunks the fast variant left in A.todo; the last workgroup resets the list
-__global__ __launch_bounds__(256, 4) void fused_todo_kernel(FusedArgs A) {
+// generic variant over the chunks the fast variant left in A.todo; also clears the list the next run appends to
+__global__ __launch_bounds__(256, 2) void fused_todo_kernel(FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t chunks_per_tile = (A.m.center_size + kMainRows - 1) / kMainRows;
     const uint32_t count = A.todo[0];
@@ -858,13 +859,7 @@ __global__ __launch_bounds__(256, 4) void fused_todo_kernel(FusedArgs A) {
         fused_main_chunks<true, true, 0, 0>(A, entry / chunks_per_tile, entry % chunks_per_tile, entry % chunks_per_tile + 1, smem);
         __syncthreads();  // LDS is reused by the next entry
     }
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&A.todo[1], 1u) == gridDim.x - 1) {
-            A.todo[0] = 0;
-            A.todo[1] = 0;
-        }
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.todo_next[0] = 0;
 }
 
 // the b x b apron corners of the finest tiles: governed by the diagonal neighbour alone (stitch.wgsl:57-66,
@@ -978,6 +973,7 @@ __global__ void selftest_kernel(uint32_t* failures) {
 struct FusedJobDev {  // device buffers of one fused job, kept alive in the preprocessor
     FusedArgs args;
     uint32_t attachment;
+    uint32_t main_runs = 0;  // parity selects the todo list
 };
 
 static std::vector<FusedJobDev>& jobs_of(bt_preprocessor* p);
@@ -1122,10 +1118,12 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         args.sides = sides;
         {
             const uint32_t chunks = (m.center_size + kMainRows - 1) / kMainRows;
-            std::vector<uint32_t> todo(2 + splits.size() * size_t(chunks), 0u);
+            const size_t list = 2 + splits.size() * size_t(chunks);  // two lists, used by alternate runs
+            std::vector<uint32_t> todo(2 * list, 0u);
             const uint32_t* dev = nullptr;
             if (upload_vector(p, todo, &dev)) return false;
             args.todo = const_cast<uint32_t*>(dev);
+            args.todo_next = args.todo + list;
         }
         if (upload_vector(p, items, &args.items) || upload_vector(p, grids, &args.grids) || upload_vector(p, grid_offsets, &args.grid_offsets))
             return false;
@@ -1284,12 +1282,13 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
     FusedJobDev job;
     {
         std::lock_guard<std::mutex> lock(g_jobs_mutex);
-        const std::vector<FusedJobDev>& jobs = jobs_of(p);
+        std::vector<FusedJobDev>& jobs = jobs_of(p);
         if (l.aux0 >= jobs.size()) {
             set_error("fused launch without a plan");
             return BT_ERR_INVALID_ARGUMENT;
         }
         job = jobs[l.aux0];
+        if (l.kind == kLaunchFusedMain && (jobs[l.aux0].main_runs++ & 1u)) std::swap(job.args.todo, job.args.todo_next);
     }
     job.args.rasters = p->rasters_dev;
     if (l.kind == kLaunchFusedMain) {

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collect the judged profile artefacts of one round on the GPU box:
+#   tools/profile_round.sh r01       (run through gpurun from the repo root)
+# writes gpurun_out/<tag>/...; tools/pmc_summary.py then condenses them into profiles/<tag>_*.
+# Counters are collected in their own passes (one --pmc group per run, kernel trace only).
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p "$O"
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --no-cpu-baseline"
+
+python $R/bench.py --steps 30 --warmup 5 --verify > $O/bench_n1_verified.json 2> $O/bench.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $B --steps 30 --warmup 5 > $O/bench_under_rocprofv3.json 2> $O/stats.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o bench -- $B --steps 3 --warmup 1 > /dev/null 2> $O/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o bench -- $B --steps 3 --warmup 1 > /dev/null 2> $O/pmc_write.log
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS \
+    --kernel-trace --output-format csv -d $O/pmc_sq -o bench -- $B --steps 3 --warmup 1 > /dev/null 2> $O/pmc_sq.log
+find $O -name '*.csv' | sort
