@@ -572,7 +572,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
 
         // ---- apron rows (first / last chunk of a tile only): the centre columns are rows like any other (the
         // north / south neighbour's centre rows, or clamped into the own centre); the b x b corners follow the
-        // diagonal neighbour alone (stitch.wgsl:57-66, 105-118) and are written by fused_corner_kernel.
+        // diagonal neighbour alone (stitch.wgsl:57-66, 105-118) and are written by corner_pixels (fused_todo / fused_corner).
         if ((k == 0 || k == chunks_per_tile - 1) && is_centre && !skip_chunk) {
             for (uint32_t r = 0; r < 2 * b; r++) {
                 const bool top = r < b;
@@ -849,27 +849,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     fused_main_chunks<kStaged, kGeneric, kT, kP>(A, work / A.groups, k_begin, k_end, smem);
 }
 
-// generic variant over the chunks the fast variant left in A.todo; also clears the list the next run appends to
-__global__ __launch_bounds__(256, 2) void fused_todo_kernel(FusedArgs A) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t chunks_per_tile = (A.m.center_size + kMainRows - 1) / kMainRows;
-    const uint32_t count = A.todo[0];
-    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
-        const uint32_t entry = A.todo[2 + e];
-        fused_main_chunks<true, true, 0, 0>(A, entry / chunks_per_tile, entry % chunks_per_tile, entry % chunks_per_tile + 1, smem);
-        __syncthreads();  // LDS is reused by the next entry
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) A.todo_next[0] = 0;
-}
-
 // the b x b apron corners of the finest tiles: governed by the diagonal neighbour alone (stitch.wgsl:57-66,
 // 105-118) — its centre corner if it exists, else the own centre corner — evaluated with the general formula
-__global__ __launch_bounds__(64) void fused_corner_kernel(FusedArgs A) {
-    const MainItem it = A.items[blockIdx.x];
+__device__ __forceinline__ void corner_pixels(const FusedArgs& A, uint32_t item_index, uint32_t tid, uint32_t threads) {
+    const MainItem it = A.items[item_index];
     const RasterDev raster = A.rasters[it.raster];
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
     const uint32_t self = grid_lookup(A, it.side, A.lod, int(it.x), int(it.y));
-    for (uint32_t t = threadIdx.x; t < 4 * b * b; t += blockDim.x) {
+    for (uint32_t t = tid; t < 4 * b * b; t += threads) {
         const uint32_t corner = t / (b * b), i = (t % (b * b)) % b, j = (t % (b * b)) / b;
         const bool left = corner == 0 || corner == 3, top = corner < 2;  // 0 NW, 1 NE, 2 SE, 3 SW
         const uint32_t px = left ? i : o + i, py = top ? j : o + j;
@@ -881,6 +868,23 @@ __global__ __launch_bounds__(64) void fused_corner_kernel(FusedArgs A) {
             v = split_value_slow(A, raster, it.x, left ? 0u : c - 1, it.y, top ? 0u : c - 1, self);
         A.atlas[uint64_t(self) * T * T + py * T + px] = uint16_t(v);
     }
+}
+
+__global__ __launch_bounds__(64) void fused_corner_kernel(FusedArgs A) { corner_pixels(A, blockIdx.x, threadIdx.x, blockDim.x); }
+
+// generic variant over the chunks the fast variant left in A.todo; also clears the list the next run appends to
+__global__ __launch_bounds__(256, 2) void fused_todo_kernel(FusedArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t chunks_per_tile = (A.m.center_size + kMainRows - 1) / kMainRows;
+    const uint32_t count = A.todo[0];
+    if (threadIdx.x < 64)  // the apron corners ride along: same stream position, no launch of their own
+        for (uint32_t i = blockIdx.x; i < A.item_count; i += gridDim.x) corner_pixels(A, i, threadIdx.x, 64);
+    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+        const uint32_t entry = A.todo[2 + e];
+        fused_main_chunks<true, true, 0, 0>(A, entry / chunks_per_tile, entry % chunks_per_tile, entry % chunks_per_tile + 1, smem);
+        __syncthreads();  // LDS is reused by the next entry
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.todo_next[0] = 0;
 }
 
 // ---- fused_tail: up to three LODs below `A.lod`, read from the atlas ---------------------------------
@@ -1293,7 +1297,6 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
     job.args.rasters = p->rasters_dev;
     if (l.kind == kLaunchFusedMain) {
         const uint32_t blocks = job.args.item_count * job.args.groups;
-        fused_corner_kernel<<<job.args.item_count, 64, 0, p->ctx->stream>>>(job.args);
         if (job.args.lds_rows) {
             const size_t lds = sizeof(MainShared) + 2 * size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
             if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528)
@@ -1302,6 +1305,7 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
                 fused_main_kernel<true, false, 0, 0><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
             fused_todo_kernel<<<std::min(blocks, 1024u), 256, lds, p->ctx->stream>>>(job.args);
         } else {
+            fused_corner_kernel<<<job.args.item_count, 64, 0, p->ctx->stream>>>(job.args);
             fused_main_kernel<false, true, 0, 0><<<blocks, 256, sizeof(MainShared), p->ctx->stream>>>(job.args);
         }
     } else {
