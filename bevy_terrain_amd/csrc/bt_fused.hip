@@ -494,8 +494,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             const uint32_t ch = tid + 256u * i;
             const uint32_t slot = ch / chunks_per_row, kk = ch - slot * chunks_per_row;
             if (ch < total) *reinterpret_cast<u32x4*>(s_src + slot * P + 8u * kk) = v[i];
-            const u16x2 m01 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, v[i].x), __builtin_bit_cast(u16x2, v[i].y));
-            const u16x2 m23 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, v[i].z), __builtin_bit_cast(u16x2, v[i].w));
+            // scalar copies first: a bit_cast applied directly to a vector element reads element 0 (seen in the ISA)
+            const uint32_t w0 = v[i].x, w1 = v[i].y, w2 = v[i].z, w3 = v[i].w;
+            const u16x2 m01 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, w0), __builtin_bit_cast(u16x2, w1));
+            const u16x2 m23 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, w2), __builtin_bit_cast(u16x2, w3));
             zmin = __builtin_elementwise_min(zmin, __builtin_elementwise_min(m01, m23));
         }
         return zmin.x == 0 || zmin.y == 0;

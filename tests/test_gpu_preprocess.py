@@ -188,3 +188,14 @@ def test_saturated_and_flat_rasters(device, generic):
     atlas, _ = K.product_planar(device, src, 4, 512, 2, O.FORMAT_R16, atlas_size=128, generic=generic)
     oracle = K.oracle_planar(src, 4, 512, 2, O.FORMAT_R16, atlas_size=128)
     assert K.assert_atlas_equal(atlas, oracle) == 85
+
+
+@pytest.mark.parametrize("lane", range(8))
+def test_single_nodata_texel_is_seen_at_every_position_of_a_staging_load(device, lane):
+    # one isolated no-data texel: the fast path must hand exactly its chunk to the validity-aware variant,
+    # whichever of the 8 texels of a 16-byte staging load it is
+    src = K.random_raster(O.FORMAT_R16, 600, 640, seed=5)
+    src[301, 320 + lane] = 0
+    atlas, pre = K.product_planar(device, src, 3, 128, 2, O.FORMAT_R16)
+    assert pre.stats()["fused_jobs"] == 1
+    assert K.assert_atlas_equal(atlas, K.oracle_planar(src, 3, 128, 2, O.FORMAT_R16)) == 21
