@@ -234,10 +234,14 @@ struct RowParam {  // one centre row of the workgroup: LDS slots of its two sour
     uint32_t pad;
 };
 
+constexpr uint32_t kMaxChunks = 64;  // chunks one workgroup may run through (T <= 512: a whole tile)
 struct MainShared {  // fixed part of the dynamic LDS block (size is a multiple of 16 bytes)
-    RowParam rows[3][kMainRows];  // chunk k uses rows[k % 3]: k+2 is filled while k is shaded and k+1 staged
-    float fy[3][kMainRows];       // the y weights again, packed for two 16-byte uniform reads
-    uint32_t consecutive[4];      // [k % 3]: chunk's rows use source rows y, y+1, ..., y+kMainRows (one step per row)
+    // row tables of ALL chunks of the workgroup's run, written once in the prologue; index = (k - k_begin) * kMainRows + row
+    int row_y0[kMaxChunks * kMainRows];    // first source row; bit 31: the second source row is the same one (clamped)
+    float row_fy[kMaxChunks * kMainRows];  // y weight (8 consecutive ones = two 16-byte uniform reads)
+    int win_ymin[kMaxChunks];              // source window of a chunk: first row ...
+    uint32_t win_slots[kMaxChunks];        // ... and row count; bit 31: the chunk's rows use source rows y, y+1, ..., y+kMainRows
+    uint32_t nodata[2][4];                 // [chunk parity][wave]: the staged window holds a no-data texel
     RowParam apron[2 * kMaxBorder];  // [0, b): top apron rows, [b, 2b): bottom apron rows (pad = mosaic row ry)
     uint32_t nb[2][8];  // neighbours (N,E,S,W,NW,NE,SE,SW) of the parent [0] and grand-parent [1] tile
     int xmin, xmax;
@@ -375,24 +379,15 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     const uint32_t self4 = A.levels >= 2 ? grid_lookup(A, it.side, A.lod - 1, int(it.x >> 1), int(it.y >> 1)) : kInvalid;
     const uint32_t self3 = A.levels >= 3 ? grid_lookup(A, it.side, A.lod - 2, int(it.x >> 2), int(it.y >> 2)) : kInvalid;
 
-    // row parameters of chunk k -> S.rows[k & 1]
-    auto fill_rows = [&](uint32_t k) {
-        const uint32_t cr = k * kMainRows + tid;
-        if (tid < kMainRows && cr < c) {
+    // row parameters of every chunk of the run, once
+    for (uint32_t i = tid; i < (k_end - k_begin) * kMainRows; i += 256u) {
+        const uint32_t cr = k_begin * kMainRows + i;
+        if (cr < c) {
             const Axis ay = split_axis(cr, c, it.y, scale, A.tly, A.bry, raster.height);
-            RowParam& r = S.rows[k % 3u][tid];
-            r.y0 = ay.i0;
-            r.y1 = ay.i1;
-            r.fy = ay.fr;
-            S.fy[k % 3u][tid] = ay.fr;
-            // y0 of row i == y0 of row 0 + i and y1 == y0 + 1 for every row of a full chunk
-            const int first = __shfl(ay.i0, 0);
-            const bool ok = ay.i0 == first + int(tid) && ay.i1 == ay.i0 + 1;
-            const unsigned long long all = __ballot(ok);
-            if (tid == 0) S.consecutive[k % 3u] = (all & ((1ull << kMainRows) - 1)) == ((1ull << kMainRows) - 1) && k * kMainRows + kMainRows <= c;
+            S.row_y0[i] = ay.i0 | (ay.i1 == ay.i0 ? int(0x80000000u) : 0);
+            S.row_fy[i] = ay.fr;
         }
-    };
-    fill_rows(k_begin);
+    }
     if (tid >= 32 && tid < 32 + 2 * b) {
         // apron rows: the north / south neighbour's centre rows, or (neighbour absent) clamped into the own centre
         const uint32_t r = tid - 32, k = r % b;
@@ -447,6 +442,20 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     if (tid == half_c + half_b) S.xmin = min(axa.i0, axb.i0);
     if (tid == half_c + half_b - 1) S.xmax = max(axa.i1, axb.i1);
     __syncthreads();
+    if (tid < k_end - k_begin) {
+        // per chunk: the source window (first row, row count) and whether its rows step through the source one by one
+        const uint32_t k = k_begin + tid, n = min(kMainRows, c - k * kMainRows);
+        const int* y0 = S.row_y0 + tid * kMainRows;
+        const int first = y0[0] & 0x7fffffff;
+        bool consecutive = n == kMainRows;
+        for (uint32_t i = 0; i < n; i++) consecutive = consecutive && y0[i] == first + int(i);  // also: second row = first + 1
+        int lo = first, hi = (y0[n - 1] & 0x7fffffff) + (y0[n - 1] < 0 ? 0 : 1);
+        if (k == 0) lo = min(lo, S.apron[0].y0);
+        if (k == chunks_per_tile - 1) hi = max(hi, S.apron[2 * b - 1].y1);
+        S.win_ymin[tid] = lo;
+        S.win_slots[tid] = uint32_t(hi - lo + 1) | (consecutive ? 0x80000000u : 0u);
+    }
+    __syncthreads();
 
     // source window of a chunk: columns [xa, xa + pitch) with xa 8-texel aligned (the same for every chunk);
     // LDS slot of source row y = y - ymin(chunk) (the rows of a chunk are consecutive mosaic rows; the host
@@ -466,34 +475,37 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
 
     auto chunk_rows = [&](uint32_t k) -> uint32_t { return min(kMainRows, c - k * kMainRows); };
     auto window = [&](uint32_t k, int& ymin, uint32_t& slots) {  // workgroup-uniform
-        const RowParam* rows = S.rows[k % 3u];
-        const uint32_t n = chunk_rows(k);
-        int lo = rows[0].y0, hi = rows[n - 1].y1;
-        if (k == 0) lo = min(lo, S.apron[0].y0);
-        if (k == chunks_per_tile - 1) hi = max(hi, S.apron[2 * b - 1].y1);
-        ymin = __builtin_amdgcn_readfirstlane(lo);
-        slots = uint32_t(__builtin_amdgcn_readfirstlane(hi) - ymin + 1);
+        ymin = __builtin_amdgcn_readfirstlane(S.win_ymin[k - k_begin]);
+        slots = uint32_t(__builtin_amdgcn_readfirstlane(S.win_slots[k - k_begin])) & 0x7fffffffu;
     };
-    // issue the loads of chunk k into registers (branch-free: addresses past the window are clamped)
-    auto stage_issue = [&](int ymin, uint32_t slots, u32x4 (&v)[kBatch]) {
-        const uint32_t total = slots * chunks_per_row;
+    // This thread's kBatch 16-byte pieces of a staged window never change: piece i is column group kk_i of window
+    // row slot_i.  Source byte offset from the window's first row and LDS byte offset, computed once per tile;
+    // a chunk then adds only its uniform base address (saddr + 32-bit voffset loads, no per-chunk address math).
+    uint32_t src_off[kBatch], lds_off[kBatch];
 #pragma unroll
-        for (uint32_t i = 0; i < kBatch; i++) {
-            const uint32_t ch = min(tid + 256u * i, total - 1u);
-            const uint32_t slot = ch / chunks_per_row, kk = ch - slot * chunks_per_row;
-            const uint32_t x = min(uint32_t(xa) + 8u * kk, row_texels - 8u);  // x, row_texels: multiples of 8
-            v[i] = *(global_u4)(data + uint64_t(ymin + int(slot)) * raster.pitch + uint64_t(x) * 2u);
-        }
+    for (uint32_t i = 0; i < kBatch; i++) {
+        const uint32_t ch = tid + 256u * i;
+        const uint32_t slot = ch / chunks_per_row, kk = ch - slot * chunks_per_row;
+        const uint32_t x = min(uint32_t(xa) + 8u * kk, row_texels - 8u);  // x, row_texels: multiples of 8
+        src_off[i] = slot * uint32_t(raster.pitch) + x * 2u;  // host: lds_rows * pitch < 2^31
+        lds_off[i] = (slot * P + 8u * kk) * 2u;
+    }
+    const uint32_t safe_off = src_off[0] - (tid / chunks_per_row) * uint32_t(raster.pitch);  // same columns, window row 0
+    // issue the loads of a chunk into registers (branch-free: pieces past the window re-read a piece of its first row)
+    auto stage_issue = [&](int ymin, uint32_t slots, u32x4 (&v)[kBatch]) {
+        const global_bytes base = data + uint64_t(uint32_t(ymin)) * raster.pitch;  // uniform
+        const uint32_t bound = slots * P * 2u;
+#pragma unroll
+        for (uint32_t i = 0; i < kBatch; i++) v[i] = *(global_u4)(base + (lds_off[i] < bound ? src_off[i] : safe_off));
     };
     // registers -> LDS; returns this thread's "saw a no-data texel" bit
     auto stage_commit = [&](uint16_t* s_src, uint32_t slots, const u32x4 (&v)[kBatch]) -> bool {
-        const uint32_t total = slots * chunks_per_row;
+        const uint32_t bound = slots * P * 2u;
+        uint8_t* s_bytes = reinterpret_cast<uint8_t*>(s_src);
         u16x2 zmin = {1, 1};
 #pragma unroll
         for (uint32_t i = 0; i < kBatch; i++) {
-            const uint32_t ch = tid + 256u * i;
-            const uint32_t slot = ch / chunks_per_row, kk = ch - slot * chunks_per_row;
-            if (ch < total) *reinterpret_cast<u32x4*>(s_src + slot * P + 8u * kk) = v[i];
+            if (lds_off[i] < bound) *reinterpret_cast<u32x4*>(s_bytes + lds_off[i]) = v[i];
             // scalar copies first: a bit_cast applied directly to a vector element reads element 0 (seen in the ISA)
             const uint32_t w0 = v[i].x, w1 = v[i].y, w2 = v[i].z, w3 = v[i].w;
             const u16x2 m01 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, w0), __builtin_bit_cast(u16x2, w1));
@@ -540,12 +552,20 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             nodata = stage_narrow(s_buf + (k_begin & 1u) * buf_texels, ymin, slots);
         }
     }
-    if (k_begin + 1 < k_end) fill_rows(k_begin + 1);
-    if (k_begin + 2 < k_end) fill_rows(k_begin + 2);
-    bool has_nodata = __syncthreads_or(nodata) != 0;
+    // block-wide OR of the threads' bits around ONE barrier: a wave writes its ballot into the slot of the chunk's
+    // parity, everybody reads the four slots after the barrier (the slot is rewritten two barriers later)
+    auto any_nodata = [&](bool mine, uint32_t parity) -> bool {
+        const unsigned long long wave_bits = __ballot(mine);
+        if ((tid & 63u) == 0) S.nodata[parity][tid >> 6] = wave_bits != 0ull;
+        __syncthreads();
+        const uint32_t* f = S.nodata[parity];
+        return __builtin_amdgcn_readfirstlane(int(f[0] | f[1] | f[2] | f[3])) != 0;
+    };
+    bool has_nodata = any_nodata(nodata, k_begin & 1u);
 
     for (uint32_t k = k_begin; k < k_end; k++) {
-        const RowParam* rows = S.rows[k % 3u];
+        const int* row_y0 = S.row_y0 + (k - k_begin) * kMainRows;
+        const float* row_fy = S.row_fy + (k - k_begin) * kMainRows;
         const uint32_t cr0 = k * kMainRows, nrows = chunk_rows(k);
         uint16_t* s_src = s_buf + (k & 1u) * buf_texels;  // this chunk's staged rows; the other half receives chunk k + 1
         const int cur_ymin = ymin;
@@ -615,15 +635,15 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                 const uint32_t cy4_first = cy4_base + (cr0 >> 1), cy3_first = cy3_base + (cr0 >> 2);
                 const bool interior4 = cy4_first >= b && cy4_first + kMainRows / 2 <= c - b;
                 const bool interior3 = cy3_first >= b && cy3_first + kMainRows / 4 <= c - b;
-                if (kMainRows == 8 && __builtin_amdgcn_readfirstlane(S.consecutive[k % 3u]) && (!do4 || interior4) && (!do3 || interior3)) {
+                if (kMainRows == 8 && __builtin_amdgcn_readfirstlane(int(S.win_slots[k - k_begin])) < 0 && (!do4 || interior4) && (!do3 || interior3)) {
                     // ---- static fast path: the 8 rows use 9 consecutive source rows and stay clear of the parents'
                     // top / bottom strips: straight-line code, row offsets are immediates, no per-row decisions.
                     // Rolling over the source rows (two live horizontal blends) in two quads of output rows; the
                     // four texels of the next source row are requested before the current row is converted, so the
                     // LDS latency hides behind the packed arithmetic.
-                    const uint16_t* base = s_src + uint32_t(__builtin_amdgcn_readfirstlane(rows[0].y0) - cur_ymin) * P;
+                    const uint16_t* base = s_src + uint32_t(__builtin_amdgcn_readfirstlane(row_y0[0]) - cur_ymin) * P;  // consecutive: bit 31 clear
                     const uint16_t *pa0 = base + la0, *pa1 = base + la1, *pb0 = base + lb0, *pb1 = base + lb1;
-                    const float* fyt = S.fy[k % 3u];
+                    const float* fyt = row_fy;
                     uint32_t t0 = pa0[0], t1 = pb0[0], t2 = pa1[0], t3 = pb1[0];
                     uint32_t n0 = pa0[P], n1 = pb0[P], n2 = pa1[P], n3 = pb1[P];
                     f2 hprev = conv2(t0, t1) * gx + conv2(t2, t3) * fx;
@@ -717,9 +737,9 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                     uint32_t ua[4], ub[4];
 #pragma unroll
                     for (uint32_t i = 0; i < 4; i++) {
-                        const int y0 = __builtin_amdgcn_readfirstlane(rows[q + i].y0);
-                        const int y1 = __builtin_amdgcn_readfirstlane(rows[q + i].y1);
-                        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rows[q + i].fy)));
+                        const int yy = __builtin_amdgcn_readfirstlane(row_y0[q + i]);
+                        const int y0 = yy & 0x7fffffff, y1 = y0 + (yy < 0 ? 0 : 1);
+                        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row_fy[q + i])));
                         const f2 top = (y0 == hy) ? hcur : hblend(y0);
                         const f2 bot = (y1 == y0) ? top : hblend(y1);
                         hcur = bot;
@@ -774,9 +794,9 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                     uint32_t zany = 1;
 #pragma unroll
                     for (uint32_t i = 0; i < 4; i++) {
-                        const int y0 = __builtin_amdgcn_readfirstlane(rows[q + i].y0);
-                        const int y1 = __builtin_amdgcn_readfirstlane(rows[q + i].y1);
-                        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rows[q + i].fy)));
+                        const int yy = __builtin_amdgcn_readfirstlane(row_y0[q + i]);
+                        const int y0 = yy & 0x7fffffff, y1 = y0 + (yy < 0 ? 0 : 1);
+                        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row_fy[q + i])));
                         const Texel4 top = (y0 == cur_y) ? cur : fetch_row(y0);
                         const Texel4 bot = (y1 == y0) ? top : fetch_row(y1);
                         cur = bot;
@@ -834,8 +854,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         }
         ymin = next_ymin;
         slots = next_slots;
-        has_nodata = __syncthreads_or(nodata) != 0;
-        if (k + 3 < k_end) fill_rows(k + 3);  // rows[k % 3] is free now; visible to everyone after the next barrier
+        has_nodata = any_nodata(nodata, (k + 1) & 1u);
     }
 }
 
@@ -1171,13 +1190,16 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                 for (uint32_t cand = parts; cand <= std::min(chunks, parts + 8); cand++)
                     if ((uint64_t(items.size()) * cand) % 1024 == 0) { parts = cand; break; }
             }
+            parts = std::max(parts, (chunks + kMaxChunks - 1) / kMaxChunks);  // row tables of a workgroup hold kMaxChunks chunks
             main_job.args.groups = std::max(1u, std::min(parts, chunks));
         }
         {   // LDS window of a workgroup: T consecutive mosaic columns x (kMainRows + 2b) mosaic rows of the source
             double ratio_x = 0.0, ratio_y = 0.0;
+            uint64_t max_pitch = 0;
             const double mosaic = double(1u << lod_hi) * double(m.center_size);
             for (const Task* t : splits) {
                 const RasterDev& r = p->rasters[t->raster].dev;
+                max_pitch = std::max<uint64_t>(max_pitch, r.pitch);
                 ratio_x = std::max(ratio_x, double(r.width) / (double(args.brx - args.tlx) * mosaic));
                 ratio_y = std::max(ratio_y, double(r.height) / (double(args.bry - args.tly) * mosaic));
             }
@@ -1190,7 +1212,9 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             // the whole window must fit (the bounds above are conservative); otherwise lds_rows = 0 selects the
             // kernel variant that reads the source directly
             // the staging loop holds one batch of 8 x 16-byte loads per thread: the window must fit that too
-            main_job.args.lds_rows = (2 * rows_needed * pitch * 2 <= budget && rows_needed * (pitch / 8) <= 256 * 4) ? uint32_t(rows_needed) : 0u;
+            // and its byte offsets from the first row are kept in 32 bits
+            main_job.args.lds_rows = (2 * rows_needed * pitch * 2 <= budget && rows_needed * (pitch / 8) <= 256 * 4 &&
+                                      (rows_needed + 1) * max_pitch < (1ull << 31)) ? uint32_t(rows_needed) : 0u;
         }
         Launch lm{};
         lm.kind = kLaunchFusedMain;
