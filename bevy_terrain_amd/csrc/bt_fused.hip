@@ -705,14 +705,18 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         }
                         if (do3) {
                             // the lane pair (2m, 2m+1) owns two level-2 pixels (quads 0 and 1): the even lane finishes
-                            // quad 0, the odd lane quad 1, each receiving the partner's half of its quad
+                            // quad 0, the odd lane quad 1.  Sum order ((x0y0 + x0y1) + x1y0) + x1y1: the even lane holds the
+                            // x0 column, the odd lane x1.  Every lane converts its own four values; the even lane sends its
+                            // quad-1 column sum, the odd lane its two quad-0 values (DPP swap inside the lane pair, no LDS).
                             const bool even = (tid & 1u) == 0;
-                            const uint32_t send0 = even ? q[2] : q[0], send1 = even ? q[3] : q[1];
-                            const uint32_t recv0 = __shfl_xor(send0, 1), recv1 = __shfl_xor(send1, 1);
-                            const uint32_t l0 = even ? q[0] : recv0, l1 = even ? q[1] : recv1;  // x even column (dx = 0)
-                            const uint32_t r0 = even ? recv0 : q[2], r1 = even ? recv1 : q[3];  // x odd column (dx = 1)
-                            const f2 left = conv2(l0, l1), right = conv2(r0, r1);
-                            const float s3 = ((left.x + left.y) + right.x) + right.y;
+                            const f2 c02 = conv2(q[0], q[2]), c13 = conv2(q[1], q[3]);
+                            const f2 colsum = c02 + c13;  // {quad 0, quad 1} column sums of this lane
+                            auto swap_pair = [](float v) -> float {  // quad_perm [1, 0, 3, 2]
+                                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+                            };
+                            const float recv1 = swap_pair(even ? colsum.y : c02.x), recv2 = swap_pair(c13.x);
+                            const float sa = even ? colsum.x : recv1, sb = even ? recv1 : c02.y, sc = even ? recv2 : c13.y;
+                            const float s3 = (sa + sb) + sc;
                             const uint32_t w3 = uint32_t(0.5f + 65535.0f * (s3 * 0.25f));  // clamp is a no-op here, see quantise
                             const uint32_t row3 = (b + cy3_first + (even ? 0u : 1u)) * T;
                             if (is_centre) tile3[row3 + b + cx3] = uint16_t(w3);

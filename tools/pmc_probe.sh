@@ -1,0 +1,27 @@
+#!/bin/bash
+# ad-hoc SQ counter passes over the bench (gpurun): results in gpurun_out/probe/
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/probe
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1"
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" \
+           "SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY" \
+           "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INST_CYCLES_SALU" \
+           "SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_INT32 SQ_THREAD_CYCLES_VALU SQ_IFETCH SQ_INSTS_BRANCH"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -o b -- $B > /dev/null 2> $O/p$i.log
+done
+python - <<PY
+import csv, glob, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$O/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        k = "main" if "fused_main" in k else "tail" if "fused_tail" in k else "todo" if "fused_todo" in k else None
+        if k: acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k in ("main",):
+    for n, v in sorted(acc[k].items()):
+        print(k, n, round(sum(v) / len(v)))
+PY

@@ -44,7 +44,7 @@ void run(const char* name, float* out, int blocks_per_cu) {
 }
 int main() {
     float* out; hipMalloc(&out, 256 * 8 * 256 * 4);
-    for (int w : {1, 2, 4}) {
+    for (int w : {1, 2, 4, 6, 8}) {
         run<0>("scalar fma, independent x8", out, w);
         run<1>("scalar fma, dependent", out, w);
         run<2>("packed fma, independent x4", out, w);
