@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--spinup-ms", type=float, default=150.0,
+                    help="untimed spin-up before the W warm-up steps: the GPU needs ~100 ms of load to reach its sustained clock")
     ap.add_argument("--generic", action="store_true", help="force the reference-shaped batched kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="byte-compare all tiles with the oracle run of cpu_baseline")
@@ -127,6 +129,11 @@ def main():
 
     # the context launches on device.torch_stream; the events are recorded on that same stream
     stream = device.torch_stream
+    spin_end = time.perf_counter() + args.spinup_ms / 1e3
+    while time.perf_counter() < spin_end:  # same on every rank: each step ends in the same collectives
+        for _ in range(16):
+            step()
+        fence()
     for _ in range(args.warmup):
         step()
     fence()

@@ -11,10 +11,10 @@ mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline"
 
-python $R/bench.py --steps 30 --warmup 5 --verify > $O/bench_n1_verified.json 2> $O/bench.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $B --steps 30 --warmup 5 > $O/bench_under_rocprofv3.json 2> $O/stats.log
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o bench -- $B --steps 3 --warmup 1 > /dev/null 2> $O/pmc_fetch.log
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o bench -- $B --steps 3 --warmup 1 > /dev/null 2> $O/pmc_write.log
+python $R/bench.py --verify > $O/bench_n1_verified.json 2> $O/bench.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $B > $O/bench_under_rocprofv3.json 2> $O/stats.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o bench -- $B --steps 3 --warmup 1 --spinup-ms 0 > /dev/null 2> $O/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o bench -- $B --steps 3 --warmup 1 --spinup-ms 0 > /dev/null 2> $O/pmc_write.log
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS \
-    --kernel-trace --output-format csv -d $O/pmc_sq -o bench -- $B --steps 3 --warmup 1 > /dev/null 2> $O/pmc_sq.log
+    --kernel-trace --output-format csv -d $O/pmc_sq -o bench -- $B --steps 3 --warmup 1 --spinup-ms 0 > /dev/null 2> $O/pmc_sq.log
 find $O -name '*.csv' | sort
