@@ -57,6 +57,7 @@ struct FusedArgs {
     uint32_t lds_rows;    // fused_main: staged source rows that fit
     uint32_t* todo;       // fused_main: [0] count, [2..] chunks (item * chunks_per_tile + k) left to the generic variant
     uint32_t* todo_next;  // the list of the NEXT run (the two alternate): fused_todo zeroes its count, so no reset protocol
+    uint32_t apron_lods;  // fused_tail: LODs lod, lod+1, ... (this many) get their top / bottom apron rows from extra workgroups
     uint32_t ablate;      // debug only (env BT_FUSED_ABLATE): 1 no pyramid, 2 no finest stores, 4 no shading, 8 no staging loads, 16 prologue only, 32 no packed fast loop
 };
 
@@ -82,7 +83,8 @@ struct Axis {
 };
 
 // split.wgsl:25-32 for centre coordinate r (0..c-1) of tile index `tile` (see bt_kernels.hip split_axis)
-__device__ __forceinline__ Axis split_axis(uint32_t r, uint32_t c, uint32_t tile, float scale, float lo, float hi, uint32_t dim) {
+// (also evaluated on the host, bit for bit the same IEEE operations, to size the LDS window exactly)
+__host__ __device__ __forceinline__ Axis split_axis(uint32_t r, uint32_t c, uint32_t tile, float scale, float lo, float hi, uint32_t dim) {
     const float tc = float(r) / float(c);
     const float s = (float(tile) + tc) / scale;
     const float u = (s - lo) / (hi - lo);
@@ -92,8 +94,9 @@ __device__ __forceinline__ Axis split_axis(uint32_t r, uint32_t c, uint32_t tile
     a.fr = q - fl;
     const int i = int(fl);
     const int last = int(dim) - 1;
-    a.i0 = min(max(i, 0), last);
-    a.i1 = min(max(i + 1, 0), last);
+    const int j = i + 1;
+    a.i0 = i < 0 ? 0 : (i > last ? last : i);
+    a.i1 = j < 0 ? 0 : (j > last ? last : j);
     return a;
 }
 
@@ -243,97 +246,10 @@ struct MainShared {  // fixed part of the dynamic LDS block (size is a multiple 
     uint32_t win_slots[kMaxChunks];        // ... and row count; bit 31: the chunk's rows use source rows y, y+1, ..., y+kMainRows
     uint32_t nodata[2][4];                 // [chunk parity][wave]: the staged window holds a no-data texel
     RowParam apron[2 * kMaxBorder];  // [0, b): top apron rows, [b, 2b): bottom apron rows (pad = mosaic row ry)
-    uint32_t nb[2][8];  // neighbours (N,E,S,W,NW,NE,SE,SW) of the parent [0] and grand-parent [1] tile
     int xmin, xmax;
     uint32_t pad[2];
 };
 static_assert(sizeof(MainShared) % 16 == 0, "LDS carve must stay 16-byte aligned");
-
-// push_pixel with the tile's neighbour table already in LDS (edge rows of the parent tiles only)
-__device__ __forceinline__ void push_pixel_lds(const FusedArgs& A, const uint32_t* nb, uint16_t* __restrict__ self, uint32_t cx,
-                                            uint32_t cy, uint16_t v) {
-    const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
-    const uint32_t tile_texels = T * T;
-    self[(b + cy) * T + b + cx] = v;
-    const int ex = cx < b ? -1 : (cx >= c - b ? 1 : 0);
-    const int ey = cy < b ? -1 : (cy >= c - b ? 1 : 0);
-    if (ex == 0 && ey == 0) return;
-    const uint32_t o = b + c;
-    const uint32_t ax = uint32_t(int(b + cx) - ex * int(c)), ay = uint32_t(int(b + cy) - ey * int(c));
-    if (ex != 0) {
-        const uint32_t n = nb[ex < 0 ? 3 : 1];
-        if (n != kInvalid) {
-            A.atlas[uint64_t(n) * tile_texels + (b + cy) * T + ax] = v;
-        } else if (cx == 0 || cx == c - 1) {
-            const uint32_t x0 = ex < 0 ? 0u : o;
-            for (uint32_t j = 0; j < b; j++) self[(b + cy) * T + x0 + j] = v;
-        }
-    }
-    if (ey != 0) {
-        const uint32_t n = nb[ey < 0 ? 0 : 2];
-        if (n != kInvalid) {
-            A.atlas[uint64_t(n) * tile_texels + ay * T + b + cx] = v;
-        } else if (cy == 0 || cy == c - 1) {
-            const uint32_t y0 = ey < 0 ? 0u : o;
-            for (uint32_t j = 0; j < b; j++) self[(y0 + j) * T + b + cx] = v;
-        }
-    }
-    if (ex != 0 && ey != 0) {
-        const uint32_t n = nb[ey < 0 ? (ex < 0 ? 4 : 5) : (ex < 0 ? 7 : 6)];
-        if (n != kInvalid) {
-            A.atlas[uint64_t(n) * tile_texels + ay * T + ax] = v;
-        } else if ((cx == 0 || cx == c - 1) && (cy == 0 || cy == c - 1)) {
-            const uint32_t x0 = ex < 0 ? 0u : o, y0 = ey < 0 ? 0u : o;
-            for (uint32_t j = 0; j < b; j++)
-                for (uint32_t i = 0; i < b; i++) self[(y0 + j) * T + x0 + i] = v;
-        }
-    }
-}
-
-// Per-thread constants of the x direction of a push (the column of a thread never changes): where the
-// value also goes besides the centre texel when the row is NOT within b of the tile's top / bottom edge.
-struct PushX {
-    uint32_t centre;      // b + cx
-    uint32_t extra_base;  // element offset (without the row term) of the extra apron texel(s), or kInvalid
-    uint32_t extra_count; // 1 = one texel in the x neighbour's apron; b = replicate into the own apron
-    bool other_tile;      // extra texels live in the neighbour tile (extra_tile) instead of the own one
-    uint32_t extra_tile;
-};
-
-__device__ __forceinline__ PushX make_push_x(const FusedArgs& A, const uint32_t* nb, uint32_t cx) {
-    const uint32_t b = A.m.border_size, c = A.m.center_size, o = b + c;
-    PushX p;
-    p.centre = b + cx;
-    p.extra_base = kInvalid;
-    p.extra_count = 0;
-    p.other_tile = false;
-    p.extra_tile = 0;
-    const int ex = cx < b ? -1 : (cx >= c - b ? 1 : 0);
-    if (ex != 0) {
-        const uint32_t n = nb[ex < 0 ? 3 : 1];
-        if (n != kInvalid) {
-            p.extra_base = uint32_t(int(b + cx) - ex * int(c));
-            p.extra_count = 1;
-            p.other_tile = true;
-            p.extra_tile = n;
-        } else if (cx == 0 || cx == c - 1) {
-            p.extra_base = ex < 0 ? 0u : o;
-            p.extra_count = b;
-        }
-    }
-    return p;
-}
-
-// interior-row push: centre texel plus the precomputed x extras (no neighbour lookups, one rare branch)
-__device__ __forceinline__ void push_fast(const FusedArgs& A, const PushX& p, uint16_t* __restrict__ self, uint32_t cy, uint16_t v) {
-    const uint32_t T = A.m.texture_size, b = A.m.border_size;
-    const uint32_t row = (b + cy) * T;
-    self[row + p.centre] = v;
-    if (p.extra_count) {
-        uint16_t* t = p.other_tile ? A.atlas + uint64_t(p.extra_tile) * (T * T) : self;
-        for (uint32_t j = 0; j < p.extra_count; j++) t[row + p.extra_base + j] = v;
-    }
-}
 
 struct Texel4 {  // the four source texels a column pair needs from one source row
     float a0, a1, b0, b1;  // converted
@@ -400,14 +316,6 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         S.apron[r].y1 = ay.i1;
         S.apron[r].fy = ay.fr;
         S.apron[r].pad = ry;
-    } else if (tid >= 64 && tid < 80 && A.levels >= 2) {
-        // neighbour tables of the parent / grand-parent tile for the pushes below
-        constexpr int kOff[8][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}, {-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
-        const uint32_t k = tid - 64, lvl = k >> 3, r = k & 7u;
-        const uint32_t shift = lvl + 1;
-        S.nb[lvl][r] = (A.lod >= shift && A.levels >= shift + 1)
-                           ? grid_lookup(A, it.side, A.lod - shift, int(it.x >> shift) + kOff[r][0], int(it.y >> shift) + kOff[r][1])
-                           : kInvalid;
     }
 
     // column pair of this thread: centre pairs first so that lanes (2m, 2m+1) hold the two halves of one
@@ -535,6 +443,36 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     const uint32_t cx4 = (it.x & 1u) * half_c + tid, cy4_base = (it.y & 1u) * half_c;
     const uint32_t cx3 = (it.x & 3u) * (c / 4) + (tid >> 1), cy3_base = (it.y & 3u) * (c / 4);
     const bool do4 = A.levels >= 2 && !(A.ablate & 1u), do3 = A.levels >= 3 && !(A.ablate & 1u);
+    // Left / right apron columns of the parent (shift 1) and grand-parent (shift 2) tile: a centre column within b of
+    // the tile's x edge is also the x neighbour's apron column (stitch.wgsl:79-88); with that neighbour absent the
+    // own apron repeats the edge column (stitch.wgsl:105-118) and the edge column's thread writes all b of them.
+    // Per thread and level: element offset of the first extra texel in the row of centre row 0, and how many.
+    auto make_xpush = [&](uint32_t shift, uint32_t self, uint32_t cx, uint32_t& off, uint32_t& count) {
+        off = 0;
+        count = 0;
+        if (!is_centre || self == kInvalid) return;
+        const uint32_t mask = (1u << shift) - 1u;
+        const bool left = (it.x & mask) == 0 && cx < b, right = (it.x & mask) == mask && cx >= c - b;
+        if (!left && !right) return;
+        const uint32_t n = grid_lookup(A, it.side, A.lod - shift, int(it.x >> shift) + (left ? -1 : 1), int(it.y >> shift));
+        const uint32_t j = left ? cx : cx - (c - b);
+        if (n != kInvalid) {
+            off = n * tile_texels + b * T + (left ? o + j : j);
+            count = 1;
+        } else if (left ? cx == 0 : cx == c - 1) {
+            off = self * tile_texels + b * T + (left ? 0u : o);
+            count = b;
+        }
+    };
+    uint32_t x4_off, x4_count, x3_off, x3_count;
+    make_xpush(1, A.levels >= 2 ? self4 : kInvalid, cx4, x4_off, x4_count);
+    make_xpush(2, A.levels >= 3 ? self3 : kInvalid, cx3, x3_off, x3_count);
+    auto xpush4 = [&](uint32_t cy, uint16_t v) {  // cy: centre row in the parent tile
+        for (uint32_t e = 0; e < x4_count; e++) A.atlas[x4_off + cy * T + e] = v;
+    };
+    auto xpush3 = [&](uint32_t cy, uint16_t v) {
+        for (uint32_t e = 0; e < x3_count; e++) A.atlas[x3_off + cy * T + e] = v;
+    };
     // LDS offsets of this thread's four source columns (idle lanes read column 0 and store nothing)
     const uint32_t la0 = uint32_t(axa.i0 - xa), la1 = uint32_t(axa.i1 - xa), lb0 = uint32_t(axb.i0 - xa), lb1 = uint32_t(axb.i1 - xa);
 
@@ -633,11 +571,9 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                 // result and is left out (tests: saturated rasters, all-65535 blocks).
                 auto quantise = [&](f2 v) -> f2 { return khalf + kn * v; };
                 const uint32_t cy4_first = cy4_base + (cr0 >> 1), cy3_first = cy3_base + (cr0 >> 2);
-                const bool interior4 = cy4_first >= b && cy4_first + kMainRows / 2 <= c - b;
-                const bool interior3 = cy3_first >= b && cy3_first + kMainRows / 4 <= c - b;
-                if (kMainRows == 8 && __builtin_amdgcn_readfirstlane(int(S.win_slots[k - k_begin])) < 0 && (!do4 || interior4) && (!do3 || interior3)) {
-                    // ---- static fast path: the 8 rows use 9 consecutive source rows and stay clear of the parents'
-                    // top / bottom strips: straight-line code, row offsets are immediates, no per-row decisions.
+                if (kMainRows == 8 && __builtin_amdgcn_readfirstlane(int(S.win_slots[k - k_begin])) < 0) {
+                    // ---- static fast path: the 8 rows use 9 consecutive source rows: straight-line code, row offsets
+                    // are immediates, no per-row decisions.
                     // Rolling over the source rows (two live horizontal blends) in two quads of output rows; the
                     // four texels of the next source row are requested before the current row is converted, so the
                     // LDS latency hides behind the packed arithmetic.
@@ -686,22 +622,20 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         }
                     }
                     if (do4) {
-                        // the parent's x edge: first / last b columns of the parent tile also feed an apron (its x
-                        // neighbour's, or the own one when that neighbour is absent); only a few lanes of a tile take this
-                        const bool xedge4 = is_centre && (cx4 < b || cx4 >= c - b);
+                        // centre + (edge columns) the x neighbour's apron column; apron rows come from the stitch launch
                         if (is_centre) {
                             uint16_t* dst = tile4 + (b + cy4_first) * T + b + cx4;
 #pragma unroll
                             for (uint32_t j = 0; j < 4; j++) dst[j * T] = uint16_t(q[j]);
                         }
-                        if (xedge4) {
-                            const PushX px = make_push_x(A, S.nb[0], cx4);
-                            if (px.extra_count) {
-                                uint16_t* t = (px.other_tile ? A.atlas + uint64_t(px.extra_tile) * tile_texels : tile4) + (b + cy4_first) * T + px.extra_base;
-                                for (uint32_t e = 0; e < px.extra_count; e++)
+                        if (x4_count) {  // a few lanes of a tile; one texel each unless the x neighbour is absent
+                            uint16_t* t = A.atlas + x4_off + cy4_first * T;
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; j++) t[j * T] = uint16_t(q[j]);
+                            if (x4_count > 1)
+                                for (uint32_t e = 1; e < x4_count; e++)
 #pragma unroll
                                     for (uint32_t j = 0; j < 4; j++) t[j * T + e] = uint16_t(q[j]);
-                            }
                         }
                         if (do3) {
                             // the lane pair (2m, 2m+1) owns two level-2 pixels (quads 0 and 1): the even lane finishes
@@ -720,12 +654,11 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             const uint32_t w3 = uint32_t(0.5f + 65535.0f * (s3 * 0.25f));  // clamp is a no-op here, see quantise
                             const uint32_t row3 = (b + cy3_first + (even ? 0u : 1u)) * T;
                             if (is_centre) tile3[row3 + b + cx3] = uint16_t(w3);
-                            if (is_centre && (cx3 < b || cx3 >= c - b)) {
-                                const PushX px = make_push_x(A, S.nb[1], cx3);
-                                if (px.extra_count) {
-                                    uint16_t* t = (px.other_tile ? A.atlas + uint64_t(px.extra_tile) * tile_texels : tile3) + row3 + px.extra_base;
-                                    for (uint32_t e = 0; e < px.extra_count; e++) t[e] = uint16_t(w3);
-                                }
+                            if (x3_count) {
+                                uint16_t* t = A.atlas + x3_off + (cy3_first + (even ? 0u : 1u)) * T;
+                                t[0] = uint16_t(w3);
+                                if (x3_count > 1)
+                                    for (uint32_t e = 1; e < x3_count; e++) t[e] = uint16_t(w3);
                             }
                         }
                     }
@@ -764,16 +697,14 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         const f2 wq = quantise(s * kquarter);
                         const uint32_t q0 = uint32_t(wq.x), q1 = uint32_t(wq.y);
                         const uint32_t cy = cr0 + q, cy4 = cy4_base + (cy >> 1);
-                        const bool edge4 = cy4 < b || cy4 + 2 > c - b;  // uniform: the row pair touches the parent's top / bottom strip
                         if (is_centre) {
-                            if (edge4) {
-                                push_pixel_lds(A, S.nb[0], tile4, cx4, cy4, uint16_t(q0));
-                                push_pixel_lds(A, S.nb[0], tile4, cx4, cy4 + 1, uint16_t(q1));
-                            } else {
-                                const PushX px4 = make_push_x(A, S.nb[0], cx4);
-                                push_fast(A, px4, tile4, cy4, uint16_t(q0));
-                                push_fast(A, px4, tile4, cy4 + 1, uint16_t(q1));
-                            }
+                            uint16_t* dst = tile4 + (b + cy4) * T + b + cx4;
+                            dst[0] = uint16_t(q0);
+                            dst[T] = uint16_t(q1);
+                        }
+                        if (x4_count) {
+                            xpush4(cy4, uint16_t(q0));
+                            xpush4(cy4 + 1, uint16_t(q1));
                         }
                         if (do3) {
                             const uint32_t other0 = __shfl_xor(q0, 1), other1 = __shfl_xor(q1, 1);
@@ -782,8 +713,8 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                 const float s3 = ((mine.x + mine.y) + theirs.x) + theirs.y;
                                 const uint32_t w3 = float_to_unorm16(s3 * 0.25f);
                                 const uint32_t cy3 = cy3_base + (cy >> 2);
-                                if (cy3 < b || cy3 >= c - b) push_pixel_lds(A, S.nb[1], tile3, cx3, cy3, uint16_t(w3));
-                                else push_fast(A, make_push_x(A, S.nb[1], cx3), tile3, cy3, uint16_t(w3));
+                                tile3[(b + cy3) * T + b + cx3] = uint16_t(w3);
+                                if (x3_count) xpush3(cy3, uint16_t(w3));
                             }
                         }
                     }
@@ -833,14 +764,20 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         const uint32_t q1 = downsample4(va[2] & 0xFFFFu, va[3] & 0xFFFFu, vb[2] & 0xFFFFu, vb[3] & 0xFFFFu);
                         const uint32_t cy4 = cy4_base + (cy >> 1);
                         if (is_centre) {
-                            push_pixel_lds(A, S.nb[0], tile4, cx4, cy4, uint16_t(q0));
-                            push_pixel_lds(A, S.nb[0], tile4, cx4, cy4 + 1, uint16_t(q1));
+                            uint16_t* dst = tile4 + (b + cy4) * T + b + cx4;
+                            dst[0] = uint16_t(q0);
+                            dst[T] = uint16_t(q1);
+                        }
+                        if (x4_count) {
+                            xpush4(cy4, uint16_t(q0));
+                            xpush4(cy4 + 1, uint16_t(q1));
                         }
                         if (do3) {
                             const uint32_t other0 = __shfl_xor(q0, 1), other1 = __shfl_xor(q1, 1);
                             if (is_centre && (tid & 1u) == 0) {
                                 const uint32_t w = downsample4(q0, q1, other0, other1);
-                                push_pixel_lds(A, S.nb[1], tile3, cx3, cy3_base + (cy >> 2), uint16_t(w));
+                                tile3[(b + cy3_base + (cy >> 2)) * T + b + cx3] = uint16_t(w);
+                                if (x3_count) xpush3(cy3_base + (cy >> 2), uint16_t(w));
                             }
                         }
                     }
@@ -917,7 +854,47 @@ __global__ __launch_bounds__(256, 2) void fused_todo_kernel(FusedArgs A) {
 // owns 2 x 2 pixels of lod-1 and one pixel of lod-2 in registers; 2 x 2 neighbouring threads (lanes l, l+1,
 // l+16, l+17 of one wave) combine into one pixel of lod-3 with three shuffles.  No LDS, no barrier, one tile
 // lookup per thread and LOD (c % 4 == 0: a 4 x 4 block never straddles a tile).
+// Top / bottom apron rows (whole rows, corners included) of the tiles of the LODs fused_main produced below the
+// finest one: stitch.wgsl:53-118 for same-side neighbours — neighbour's centre rows, or the own centre clamped
+// when it is absent.  (Cube face edges are re-stitched afterwards by the generic kernel.)  One thread per pixel pair.
+__device__ __forceinline__ void tail_apron_rows(const FusedArgs& A, uint32_t side, uint32_t e) {
+    const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
+    const uint32_t pairs = b * T, blocks_per_tile = (pairs + 255u) / 256u;
+    for (uint32_t k = 0; k < A.apron_lods; k++) {
+        const uint32_t lod = A.lod + k, n = 1u << lod, blocks = n * n * blocks_per_tile;
+        if (e >= blocks) {
+            e -= blocks;
+            continue;
+        }
+        const uint32_t tile = e / blocks_per_tile, i = (e % blocks_per_tile) * 256u + threadIdx.x;
+        if (i >= pairs) return;
+        const uint32_t tx = tile / n, ty = tile % n;
+        const uint32_t self = grid_lookup(A, side, lod, int(tx), int(ty));
+        if (self == kInvalid) return;
+        const uint32_t r = i / (T / 2u), px = 2u * (i % (T / 2u)), py = r < b ? r : c + r;
+        const int rx = px < b ? -1 : (px >= o ? 1 : 0), ry = r < b ? -1 : 1;
+        const uint32_t nb = grid_lookup(A, side, lod, int(tx) + rx, int(ty) + ry);
+        uint32_t v[2];
+#pragma unroll
+        for (uint32_t h = 0; h < 2; h++) {
+            const uint32_t x = px + h;
+            const uint32_t sx = nb != kInvalid ? uint32_t(int(x) - rx * int(c)) : min(max(x, b), o - 1u);
+            const uint32_t sy = nb != kInvalid ? uint32_t(int(py) - ry * int(c)) : min(max(py, b), o - 1u);
+            v[h] = A.atlas[uint64_t(nb != kInvalid ? nb : self) * T * T + sy * T + sx];
+        }
+        *reinterpret_cast<uint32_t*>(A.atlas + uint64_t(self) * T * T + py * T + px) = v[0] | (v[1] << 16);
+        return;
+    }
+}
+
 __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
+    {
+        const uint32_t extent = (1u << A.lod) * A.m.center_size, ny = (extent + 63u) / 64u;
+        if (blockIdx.y >= ny) {  // workgroups past the mosaic: apron rows
+            tail_apron_rows(A, blockIdx.z, (blockIdx.y - ny) * gridDim.x + blockIdx.x);
+            return;
+        }
+    }
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
     const uint32_t tile_texels = T * T;
     const uint32_t side = blockIdx.z;
@@ -1010,6 +987,7 @@ static std::vector<FusedJobDev>& jobs_of(bt_preprocessor* p);
 }  // namespace bt
 
 // storage for fused jobs lives next to the preprocessor; keyed by pointer to avoid widening the struct
+#include <algorithm>
 #include <map>
 #include <mutex>
 namespace bt {
@@ -1209,7 +1187,28 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             }
             const uint32_t rows = std::min(kMainRows, m.center_size) + 2 * m.border_size;
             const uint64_t cols_needed = uint64_t(double(m.texture_size - 1) * ratio_x) + 4 + 7;
-            const uint64_t rows_needed = uint64_t(double(rows - 1) * ratio_y) + 4;  // contiguous source-row range
+            uint64_t rows_needed = uint64_t(double(rows - 1) * ratio_y) + 4;  // contiguous source-row range (safe bound)
+            {   // exact: replay the kernel's own window computation for every tile row and chunk (same f32 operations)
+                const uint32_t c = m.center_size, b = m.border_size, chunks = (c + kMainRows - 1) / kMainRows;
+                const float scale = float(1u << lod_hi);
+                uint64_t exact = 1;
+                std::vector<std::pair<uint32_t, int>> seen;  // (tile row, raster)
+                for (const Task* t : splits) {
+                    const std::pair<uint32_t, int> key(t->coord.y, t->raster);
+                    if (std::find(seen.begin(), seen.end(), key) != seen.end()) continue;
+                    seen.push_back(key);
+                    const uint32_t H = p->rasters[t->raster].dev.height, n = 1u << lod_hi, ty = t->coord.y;
+                    auto axis = [&](uint32_t tile, uint32_t r) { return split_axis(r, c, tile, scale, args.tly, args.bry, H); };
+                    for (uint32_t k = 0; k < chunks; k++) {
+                        const uint32_t r0 = k * kMainRows, r1 = std::min(c, r0 + kMainRows) - 1;
+                        int lo = axis(ty, r0).i0, hi = axis(ty, r1).i1;
+                        if (k == 0) lo = std::min(lo, ty > 0 ? axis(ty - 1, c - b).i0 : axis(ty, 0).i0);
+                        if (k == chunks - 1) hi = std::max(hi, ty + 1 < n ? axis(ty + 1, b - 1).i1 : axis(ty, c - 1).i1);
+                        exact = std::max<uint64_t>(exact, uint64_t(hi - lo + 1));
+                    }
+                }
+                rows_needed = std::min(rows_needed, exact);
+            }
             const uint64_t pitch = (cols_needed + 7) / 8 * 8;
             const uint64_t budget = 65536 - sizeof(MainShared);
             main_job.args.lds_pitch = uint32_t(std::min<uint64_t>(pitch, 1u << 20));
@@ -1230,9 +1229,12 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         jobs.push_back(main_job);
         plan.push_back(lm);
 
-        if (shard && main_levels > 1) {
-            // the parent / grand-parent tiles received their cross-strip aprons in another rank's memory:
-            // after the all-gather every rank re-stitches those LODs from the (now complete) centres
+        const bool tail_follows = lod_hi - (main_levels - 1) > lod_lo;
+        const bool rows_in_tail = !shard && tail_follows && main_levels > 1 && m.border_size % 2u == 0;
+        if (main_levels > 1 && !rows_in_tail) {
+            // fused_main writes the centres and the left / right apron columns of the parent / grand-parent tiles; their
+            // top / bottom apron rows (whole 1 KB rows) come from the batched stitch kernel — sharded: everything, after
+            // the all-gather, from the then complete centres
             const uint32_t first = uint32_t(tasks.size());
             for (const Task* t : stitches) {
                 if (t->coord.lod == lod_hi || t->coord.lod + main_levels <= lod_hi) continue;
@@ -1254,7 +1256,11 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             ls.first_task = first;
             ls.task_count = uint32_t(tasks.size()) - first;
             ls.algorithmic_bytes = uint64_t(ls.task_count) * 2 * (2 * m.border_size * (Tt + cc)) * bpp;
-            ls.phase = 2;
+            ls.phase = shard ? 2u : 0u;
+            // fused_main also writes the left / right apron columns of these tiles (from registers); sharded runs lose
+            // the ones that crossed a strip boundary in the all-gather and re-stitch everything
+            ls.aux0 = shard ? 0u : 1u;
+            if (!shard) ls.algorithmic_bytes = uint64_t(ls.task_count) * 2 * (2 * m.border_size * Tt) * bpp;
             if (ls.task_count) plan.push_back(ls);
         }
 
@@ -1262,15 +1268,20 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         uint32_t in_lod = lod_hi - (main_levels - 1);
         while (in_lod > lod_lo) {
             const uint32_t levels = std::min(3u, in_lod - lod_lo);
+            uint64_t lt_extra = 0;
             FusedJobDev tail{args, ai};
             tail.args.lod = in_lod;
             tail.args.levels = levels;
+            // the first tail launch also fills the top / bottom apron rows of the LODs fused_main produced (see above)
+            tail.args.apron_lods = (rows_in_tail && in_lod == lod_hi - (main_levels - 1)) ? main_levels - 1 : 0u;
+            if (tail.args.apron_lods)
+                for (uint32_t k = 0; k < tail.args.apron_lods; k++) lt_extra += tiles_at(in_lod + k) * 2 * (2 * m.border_size * Tt) * bpp;
             Launch lt{};
             lt.kind = kLaunchFusedTail;
             lt.attachment = ai;
             lt.aux0 = uint32_t(jobs.size());
             lt.phase = shard ? 2u : 0u;
-            lt.algorithmic_bytes = tiles_at(in_lod) * cc * cc * bpp;
+            lt.algorithmic_bytes = tiles_at(in_lod) * cc * cc * bpp + lt_extra;
             for (uint32_t k = 1; k <= levels; k++) {
                 lt.algorithmic_bytes += tiles_at(in_lod - k) * Tt * Tt * bpp;
                 lt.task_count += uint32_t(tiles_at(in_lod - k));
@@ -1340,7 +1351,13 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
         }
     } else {
         const uint32_t size = (1u << job.args.lod) * job.args.m.center_size;
-        const dim3 grid((size + 63) / 64, (size + 63) / 64, job.args.sides);
+        dim3 grid((size + 63) / 64, (size + 63) / 64, job.args.sides);
+        if (job.args.apron_lods) {
+            const uint32_t blocks_per_tile = (job.args.m.border_size * job.args.m.texture_size + 255u) / 256u;
+            uint64_t extra = 0;
+            for (uint32_t k = 0; k < job.args.apron_lods; k++) extra += (1ull << (2 * (job.args.lod + k))) * blocks_per_tile;
+            grid.y += uint32_t((extra + grid.x - 1) / grid.x);
+        }
         fused_tail_kernel<<<grid, 256, 0, p->ctx->stream>>>(job.args);
     }
     hipError_t e = hipGetLastError();

@@ -303,6 +303,37 @@ __global__ __launch_bounds__(256) void stitch_kernel(AttachmentMeta m, void* __r
     base[uint64_t(task.atlas_index) * Tsz * Tsz + uint64_t(py) * Tsz + px] = v;
 }
 
+// R16 with an even border: one thread per apron pixel PAIR (a pair never straddles two regions) — half the
+// stores, each 4 bytes; the left / right columns are isolated 4-byte accesses either way
+__global__ __launch_bounds__(256) void stitch_pairs_kernel(AttachmentMeta m, uint16_t* __restrict__ atlas,
+                                                           const TaskDev* __restrict__ tasks, uint32_t blocks_per_tile,
+                                                           uint32_t pairs) {
+    const uint32_t task_index = blockIdx.x / blocks_per_tile;
+    const uint32_t i = (blockIdx.x % blocks_per_tile) * blockDim.x + threadIdx.x;
+    const uint32_t Tsz = m.texture_size, b = m.border_size, c = m.center_size, o = b + c;
+    const uint32_t row_pairs = b * Tsz;  // 2b rows of T / 2 pairs
+    if (i >= pairs) return;              // all: + c rows of 2 * (b / 2) pairs; rows only: row_pairs
+    const TaskDev task = tasks[task_index];
+    uint32_t px, py;
+    if (i < row_pairs) {
+        const uint32_t r = i / (Tsz / 2u);
+        px = 2u * (i % (Tsz / 2u));
+        py = r < b ? r : (c + r);
+    } else {
+        const uint32_t j = i - row_pairs, k = j % b, d = k % (b / 2u);
+        py = b + j / b;
+        px = k < b / 2u ? 2u * d : o + 2u * d;
+    }
+    uint32_t v[2];
+#pragma unroll
+    for (uint32_t e = 0; e < 2; e++) {
+        uint32_t layer, sx, sy;
+        stitch_source(task, px + e, py, Tsz, b, c, layer, sx, sy);
+        v[e] = (layer < m.atlas_size && sx < Tsz && sy < Tsz) ? atlas[uint64_t(layer) * Tsz * Tsz + uint64_t(sy) * Tsz + sx] : 0u;
+    }
+    *reinterpret_cast<uint32_t*>(atlas + uint64_t(task.atlas_index) * Tsz * Tsz + uint64_t(py) * Tsz + px) = v[0] | (v[1] << 16);
+}
+
 // -------------------------------------------------------------------------------------- mip chain
 
 // AttachmentData::generate_mipmaps: R16 = truncating mean of the non-zero texels, RGBA8 = sum / 4
@@ -418,11 +449,15 @@ bt_status launch_downsample(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, c
     return check_launch("downsample_kernel");
 }
 
-bt_status launch_stitch(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const TaskDev* tasks, uint32_t n) {
+bt_status launch_stitch(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const TaskDev* tasks, uint32_t n, bool rows_only) {
     if (!n || m.border_size == 0) return BT_OK;
     const uint32_t apron = 2u * m.border_size * (m.texture_size + m.center_size);
     const uint32_t blocks = (apron + 255u) / 256u;
-    if (m.format == BT_FORMAT_R16)
+    if (m.format == BT_FORMAT_R16 && m.border_size % 2u == 0 && m.texture_size % 2u == 0) {
+        const uint32_t pairs = rows_only ? m.border_size * m.texture_size : apron / 2u;
+        const uint32_t pair_blocks = (pairs + 255u) / 256u;
+        stitch_pairs_kernel<<<n * pair_blocks, 256, 0, ctx->stream>>>(m, (uint16_t*)atlas, tasks, pair_blocks, pairs);
+    } else if (m.format == BT_FORMAT_R16)
         stitch_kernel<uint16_t><<<n * blocks, 256, 0, ctx->stream>>>(m, atlas, tasks, blocks);
     else
         stitch_kernel<uint32_t><<<n * blocks, 256, 0, ctx->stream>>>(m, atlas, tasks, blocks);

@@ -181,7 +181,7 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
                 s = launch_downsample(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count);
                 break;
             case kLaunchStitch:
-                s = launch_stitch(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count);
+                s = launch_stitch(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count, l.aux0 == 1u);
                 break;
             default:
                 s = fused_launch(p, a, l);
