@@ -1111,6 +1111,13 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             }
             items.push_back({t->coord.side, t->coord.x, t->coord.y, t->atlas_index, uint32_t(t->raster)});
         }
+        // Workgroup order = tile rows (y outer, x inner) instead of the queue's x-major order: an XCD then streams whole
+        // source rows (its 128 concurrent workgroups cover 4 tile rows x all columns), and x neighbours run on the same XCD
+        // at the same time, so the apron bytes one pushes into the other's parent rows merge in one L2.  16k job: 333 -> 285 us.
+        if (!getenv("BT_FUSED_XMAJOR"))
+            std::stable_sort(items.begin(), items.end(), [](const MainItem& a, const MainItem& b2) {
+                return a.side != b2.side ? a.side < b2.side : (a.y != b2.y ? a.y < b2.y : a.x < b2.x);
+            });
         if (shard) p->shard_ranges.insert(p->shard_ranges.end(), ranges.begin(), ranges.end());
 
         FusedArgs args{};
