@@ -58,7 +58,7 @@ struct FusedArgs {
     uint32_t* todo;       // fused_main: [0] count, [2..] chunks (item * chunks_per_tile + k) left to the generic variant
     uint32_t* todo_next;  // the list of the NEXT run (the two alternate): fused_todo zeroes its count, so no reset protocol
     uint32_t apron_lods;  // fused_tail: LODs lod, lod+1, ... (this many) get their top / bottom apron rows from extra workgroups
-    uint32_t ablate;      // debug only (env BT_FUSED_ABLATE): 1 no pyramid, 2 no finest stores, 4 no shading, 8 no staging loads, 16 prologue only, 32 no packed fast loop
+    uint32_t ablate;      // debug only (env BT_FUSED_ABLATE): 1 no pyramid, 2 no finest stores, 4 no parent stores, 64 no grand-parent stores (static path), 8 no staging loads, 16 prologue only, 256 / 512 finest / parent stores without arithmetic (use with 16)
 };
 
 // t / 65535.0f, correctly rounded, in 3 VALU ops (see header)
@@ -553,6 +553,18 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             }
         }
 
+        if ((A.ablate & 768u) && !is_idle) {  // (ablation 256 / 512, with 16: the chunk's finest / parent stores without any arithmetic — the memory skeleton)
+            uint32_t* dst5 = tile5_u32 + (((b + cr0) * T + px0) >> 1);
+            if (A.ablate & 256u) {
+#pragma unroll
+                for (uint32_t i = 0; i < kMainRows; i++) dst5[i * (T / 2)] = tid + i;
+            }
+            if (is_centre && do4 && (A.ablate & 512u)) {
+                uint16_t* dst = tile4 + (b + cy4_base + (cr0 >> 1)) * T + b + cx4;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) dst[j * T] = uint16_t(tid);
+            }
+        }
         if (!(A.ablate & 16u) && !skip_chunk) {
             if constexpr (kStaged && !kGeneric) {
                 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -622,13 +634,21 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         }
                     }
                     if (do4) {
-                        // centre + (edge columns) the x neighbour's apron column; apron rows come from the stitch launch
-                        if (is_centre) {
-                            uint16_t* dst = tile4 + (b + cy4_first) * T + b + cx4;
+                        // centre + (edge columns) the x neighbour's apron column; apron rows come from the stitch launch.
+                        // The lane pair (2m, 2m+1) holds two adjacent pixels: the even lane stores both as one aligned dword
+                        // (b, c / 2 even) — 2-byte stores cost the memory pipeline about as much as 4-byte ones.
+                        {
+                            uint32_t both[4];
 #pragma unroll
-                            for (uint32_t j = 0; j < 4; j++) dst[j * T] = uint16_t(q[j]);
+                            for (uint32_t j = 0; j < 4; j++)
+                                both[j] = q[j] | (uint32_t(__builtin_amdgcn_update_dpp(0, int(q[j]), 0xB1, 0xf, 0xf, true)) << 16);
+                            if (is_centre && (tid & 1u) == 0 && !(A.ablate & 4u)) {
+                                uint32_t* dst = reinterpret_cast<uint32_t*>(tile4 + (b + cy4_first) * T + b + cx4);
+#pragma unroll
+                                for (uint32_t j = 0; j < 4; j++) dst[j * (T / 2)] = both[j];
+                            }
                         }
-                        if (x4_count) {  // a few lanes of a tile; one texel each unless the x neighbour is absent
+                        if (x4_count && !(A.ablate & 4u)) {  // a few lanes of a tile; one texel each unless the x neighbour is absent
                             uint16_t* t = A.atlas + x4_off + cy4_first * T;
 #pragma unroll
                             for (uint32_t j = 0; j < 4; j++) t[j * T] = uint16_t(q[j]);
@@ -653,8 +673,8 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             const float s3 = (sa + sb) + sc;
                             const uint32_t w3 = uint32_t(0.5f + 65535.0f * (s3 * 0.25f));  // clamp is a no-op here, see quantise
                             const uint32_t row3 = (b + cy3_first + (even ? 0u : 1u)) * T;
-                            if (is_centre) tile3[row3 + b + cx3] = uint16_t(w3);
-                            if (x3_count) {
+                            if (is_centre && !(A.ablate & 64u)) tile3[row3 + b + cx3] = uint16_t(w3);
+                            if (x3_count && !(A.ablate & 64u)) {
                                 uint16_t* t = A.atlas + x3_off + (cy3_first + (even ? 0u : 1u)) * T;
                                 t[0] = uint16_t(w3);
                                 if (x3_count > 1)
