@@ -1366,7 +1366,8 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
     if (l.kind == kLaunchFusedMain) {
         const uint32_t blocks = job.args.item_count * job.args.groups;
         if (job.args.lds_rows) {
-            const size_t lds = sizeof(MainShared) + 2 * size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
+            size_t lds = sizeof(MainShared) + 2 * size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
+            if (const char* e = getenv("BT_FUSED_LDS_PAD")) lds = std::min<size_t>(65536, lds + size_t(atoi(e)));  // occupancy experiments
             if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528)
                 fused_main_kernel<true, false, 512, 528><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
             else
