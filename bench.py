@@ -88,11 +88,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # test hooks (tests/test_shard.py runs the N = 2 path with two processes on ONE GPU, which RCCL refuses):
+    # BT_BENCH_DEVICE pins every rank to one device, BT_BENCH_BACKEND=gloo replaces RCCL
+    if "BT_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["BT_BENCH_DEVICE"])
+    backend = os.environ.get("BT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     import bevy_terrain_amd as bt
@@ -130,7 +138,14 @@ def main():
     # the context launches on device.torch_stream; the events are recorded on that same stream
     stream = device.torch_stream
     spin_end = time.perf_counter() + args.spinup_ms / 1e3
-    while time.perf_counter() < spin_end:  # same on every rank: each step ends in the same collectives
+    while True:
+        go = time.perf_counter() < spin_end
+        if world > 1:  # every rank must run the same number of steps (each one ends in collectives): rank 0 decides
+            flag = torch.tensor([1 if go else 0], device="cuda")
+            dist.broadcast(flag, src=0)
+            go = bool(flag.item())
+        if not go:
+            break
         for _ in range(16):
             step()
         fence()
@@ -168,6 +183,7 @@ def main():
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
         "scaling": "strong" if world > 1 else "weak",
+        "collective_backend": backend if world > 1 else None,
         "vs_baseline": None,
         "dtype": "f32 arithmetic on u16 texels",
         "data": "synthetic",
@@ -199,10 +215,14 @@ def main():
                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                             "traffic_source": traffic_source,
                             "avg_launch_ms": dominant["avg_ms"], "algorithmic_bytes_per_launch": dominant["algorithmic_bytes"]}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"], oracle, shape = cpu_baseline(device, src_ptr)
+    if rank == 0 and ((world == 1 and not args.no_cpu_baseline) or args.verify):
+        baseline, oracle, shape = cpu_baseline(device, src_ptr)
+        if world == 1:
+            line["cpu_baseline"] = baseline  # reported at N = 1 only
         if args.verify:
             line["verify_vs_oracle"] = verify_against(atlas, oracle, shape)
+    if world > 1:
+        dist.barrier()  # the other ranks wait for rank 0's oracle run before tearing the group down
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

@@ -3,6 +3,7 @@ x-major atlas order makes each rank's strip one contiguous run of layers).  GPU 
 one after the other on a single device must reproduce the oracle bit for bit."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -167,3 +168,25 @@ def test_nccl_single_rank_group_runs_the_sharded_step():
         assert K.assert_atlas_equal(atlas, K.oracle_planar(src, 4, 128, 2, O.FORMAT_R16, atlas_size=128)) == 85
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_end_to_end_on_one_gpu():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), except that both
+    ranks share GPU 0 and the collective is gloo (RCCL refuses two ranks on one device): every rank preprocesses its
+    column strip of the 16k job, the in-place all-gathers assemble the atlas, and rank 0's atlas must equal the
+    oracle's for all 1365 tiles."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BT_BENCH_BACKEND="gloo", BT_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--spinup-ms", "20", "--verify"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["collective_backend"] == "gloo"
+    assert line["verify_vs_oracle"] == {"tiles": 1365, "identical": 1365, "index_contract": True}
+    assert "cpu_baseline" not in line
