@@ -199,3 +199,31 @@ def test_single_nodata_texel_is_seen_at_every_position_of_a_staging_load(device,
     atlas, pre = K.product_planar(device, src, 3, 128, 2, O.FORMAT_R16)
     assert pre.stats()["fused_jobs"] == 1
     assert K.assert_atlas_equal(atlas, K.oracle_planar(src, 3, 128, 2, O.FORMAT_R16)) == 21
+
+
+def test_config5_cube_8k_faces_full_size(device):
+    """BASELINE config 5 at full size: 6 cube faces of 8192^2 (R16), lod_count 5, T = 512 -> 2046 tiles through the
+    fused path (cube seams re-stitched by the batched kernel), every tile compared with the oracle."""
+    W, lods = 8192, 5
+    faces = [K.smooth_raster(W, W, seed=7 + s, device=device) for s in range(6)]
+    for s in range(6):
+        faces[s][1000 + 37 * s:1100 + 37 * s, 5000:5300] = 0  # a no-data patch on every face
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=2048, path="terrains/spherical")
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=512, border_size=2, format=bt.AttachmentFormat.R16))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer()
+    paths = [f"face{s}" for s in range(6)]
+    for p, f in zip(paths, faces):
+        server.insert(p, f)
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_spherical(
+        bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lods)), server, atlas)
+    pre.run(atlas)
+    assert pre.stats()["fused_jobs"] >= 1 and pre.stats()["tiles"] == 2046
+    oracle = O.OracleAtlas(lods, 2048, True, [(512, 2, 1, O.FORMAT_R16)])
+    oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(os.cpu_count() or 8)
+    assert [((c.side, c.lod, c.x, c.y), i) for c, i in atlas.tiles()] == oracle.tiles()
+    for first in range(0, 2046, 128):
+        count = min(128, 2046 - first)
+        data = atlas.download_tiles(0, first, count)
+        for k in range(count):
+            assert np.array_equal(data[k], oracle.tile(0, first + k)), (first + k, oracle.tiles()[first + k])
