@@ -557,6 +557,78 @@ bt_status bt_atlas_generate_mipmaps(bt_atlas* a, uint32_t ai, uint32_t first, ui
     return BT_OK;
 }
 
+// AtlasTileAttachmentWithData::start_loading (tile_atlas.rs:118-149) + GpuAtlasAttachment::upload_tiles
+// (gpu_tile_atlas.rs:309-336) for a batch of tiles: "{directory}/{coord}.bin" -> atlas layer of the tile (allocated
+// on demand, like request_tile does), then ONE batched mip-chain pass per run of consecutive layers instead of the
+// reference's per-tile CPU loop.  coords == NULL: every existing tile (load_tile_config) of the atlas.
+bt_status bt_atlas_load_tiles(bt_atlas* a, uint32_t ai, const char* directory, const bt_tile_coordinate* coords, uint32_t count) {
+    if (!a || ai >= a->attachments.size() || !directory || (count && !coords)) return BT_ERR_INVALID_ARGUMENT;
+    Attachment& at = a->attachments[ai];
+    std::vector<bt_tile_coordinate> all;
+    if (!coords) {
+        for (const auto& kv : a->tile_states)
+            if (kv.second.existing) all.push_back(kv.first);
+        std::sort(all.begin(), all.end(), [](const bt_tile_coordinate& x, const bt_tile_coordinate& y) {
+            return std::tie(x.side, x.lod, x.x, x.y) < std::tie(y.side, y.lod, y.x, y.y);
+        });
+        coords = all.data();
+        count = uint32_t(all.size());
+    }
+    if (!count) return BT_OK;
+    BT_HIP(hipSetDevice(a->ctx->device));
+    const uint32_t chunk = 64;
+    void* pinned = nullptr;
+    BT_HIP(hipHostMalloc(&pinned, at.tile_bytes * chunk, hipHostMallocDefault));
+    std::vector<uint32_t> layers;
+    bt_status rc = BT_OK;
+    for (uint32_t i = 0; i < count && rc == BT_OK; i += chunk) {
+        const uint32_t n = std::min(chunk, count - i);
+        std::vector<uint32_t> idx(n);
+        for (uint32_t k = 0; k < n && rc == BT_OK; k++) {
+            bt_atlas_tile tile;
+            rc = bt_atlas_get_or_allocate_tile(a, coords[i + k], &tile);
+            if (rc) break;
+            idx[k] = tile.atlas_index;
+            char name[64];
+            bt_tile_name(coords[i + k], name, sizeof name);
+            const std::string path = std::string(directory) + "/" + name + ".bin";
+            FILE* f = fopen(path.c_str(), "rb");
+            if (!f) {
+                set_error("tile file not found: %s", path.c_str());
+                rc = BT_ERR_IO;
+                break;
+            }
+            const size_t got = fread((uint8_t*)pinned + at.tile_bytes * k, 1, at.tile_bytes, f);
+            const bool longer = got == at.tile_bytes && fgetc(f) != EOF;
+            fclose(f);
+            if (got != at.tile_bytes || longer) {
+                set_error("tile file %s does not hold %llu bytes", path.c_str(), (unsigned long long)at.tile_bytes);
+                rc = BT_ERR_IO;
+            }
+        }
+        for (uint32_t k = 0; k < n && rc == BT_OK; k++) {
+            hipError_t e = hipMemcpyAsync((uint8_t*)at.level0 + at.tile_bytes * idx[k], (const uint8_t*)pinned + at.tile_bytes * k,
+                                          at.tile_bytes, hipMemcpyHostToDevice, a->ctx->stream);
+            if (e != hipSuccess) rc = hip_fail(e, "tile upload");
+            layers.push_back(idx[k]);
+        }
+        if (rc == BT_OK) {
+            hipError_t e = hipStreamSynchronize(a->ctx->stream);  // the pinned buffer is refilled next
+            if (e != hipSuccess) rc = hip_fail(e, "tile upload");
+        }
+    }
+    hipHostFree(pinned);
+    if (rc || at.mips.size() <= 1) return rc;
+    std::sort(layers.begin(), layers.end());
+    for (size_t i = 0; i < layers.size();) {
+        size_t j = i + 1;
+        while (j < layers.size() && layers[j] <= layers[j - 1] + 1) j++;
+        if (bt_status s = bt_atlas_generate_mipmaps(a, ai, layers[i], layers[j - 1] - layers[i] + 1)) return s;
+        i = j;
+    }
+    return BT_OK;
+}
+
 bt_status bt_atlas_mip_storage(const bt_atlas* a, uint32_t ai, uint32_t level, void** ptr, uint64_t* tile_bytes) {
     if (!a || ai >= a->attachments.size() || level >= a->attachments[ai].mips.size()) return BT_ERR_INVALID_ARGUMENT;
     const Attachment& at = a->attachments[ai];

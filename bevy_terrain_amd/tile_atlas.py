@@ -187,6 +187,18 @@ class TileAtlas:
     def load_tile_config(self, assets_root: str = "assets"):
         _ffi.check(_ffi.lib().bt_atlas_load_tile_config(self._h, os.path.join(assets_root, self.path, "config.tc").encode()))
 
+    def load_tiles(self, attachment_index: int, assets_root: str = "assets", coords: Optional[list] = None):
+        """The tile load path (start_loading + upload_tiles, tile_atlas.rs:118-149, gpu_tile_atlas.rs:309-336) for a
+        batch: `.bin` files -> atlas layers, then the mip chain of those layers on the GPU.  coords=None: every tile
+        of the loaded tile config."""
+        directory = self.attachment_directory(assets_root, attachment_index).encode()
+        if coords is None:
+            _ffi.check(_ffi.lib().bt_atlas_load_tiles(self._h, attachment_index, directory, None, 0))
+        else:
+            arr = (_ffi.TileCoordinateC * max(len(coords), 1))(*[c._c() for c in coords])
+            _ffi.check(_ffi.lib().bt_atlas_load_tiles(self._h, attachment_index, directory, arr, len(coords)))
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
             _ffi.lib().bt_atlas_destroy(self._h)

@@ -177,6 +177,12 @@ bt_status bt_generate_mipmaps(bt_ctx* ctx, uint32_t format, uint32_t texture_siz
 /* Whole atlas: builds mip levels 1.. of `count` layers starting at `first_layer` into the atlas's mip
  * storage (GpuAtlasAttachment::new allocates mip_level_count levels, gpu_tile_atlas.rs:195-237). */
 bt_status bt_atlas_generate_mipmaps(bt_atlas* atlas, uint32_t attachment_index, uint32_t first_layer, uint32_t count);
+/* The tile load path — AtlasTileAttachmentWithData::start_loading (tile_atlas.rs:118-149) + upload_tiles
+ * (gpu_tile_atlas.rs:309-336) for a batch: reads "{directory}/{coord}.bin" of each tile into its atlas layer
+ * (allocated on demand) and builds the mip levels of those layers on the GPU.  coords == NULL: every tile
+ * that load_tile_config marked as existing.  A missing or wrongly sized file is BT_ERR_IO. */
+bt_status bt_atlas_load_tiles(bt_atlas* atlas, uint32_t attachment_index, const char* directory,
+                              const bt_tile_coordinate* coords, uint32_t count);
 bt_status bt_atlas_mip_storage(const bt_atlas* atlas, uint32_t attachment_index, uint32_t mip_level,
                                void** device_ptr, uint64_t* tile_bytes);
 

@@ -227,3 +227,40 @@ def test_config5_cube_8k_faces_full_size(device):
         data = atlas.download_tiles(0, first, count)
         for k in range(count):
             assert np.array_equal(data[k], oracle.tile(0, first + k)), (first + k, oracle.tiles()[first + k])
+
+
+@pytest.mark.parametrize("fmt", [O.FORMAT_R16, O.FORMAT_RGBA8])
+def test_tile_load_path_round_trip(device, tmp_path, fmt):
+    """preprocess -> save -> (fresh atlas) load_tile_config + load_tiles: level 0 comes back byte
+    for byte, the mip levels equal the reference's CPU generate_mipmaps of every tile, a missing file is an IO error."""
+    T, lods = 32, 3
+    src = K.random_raster(fmt, 200, 200, seed=31, holes=0.05)
+    atlas, pre = K.product_planar(device, src, lods, T, 2, fmt, mips=4)
+    root = str(tmp_path / "assets")
+    pre.save(atlas, root)
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=64, path="terrains/test", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="att", texture_size=T, border_size=2, format=K.FMT[fmt], mip_level_count=4))
+    fresh = bt.TileAtlas.new(cfg, device)
+    fresh.load_tile_config(root)
+    fresh.load_tiles(0, root)
+    loaded = {(c.side, c.lod, c.x, c.y): i for c, i in fresh.tiles()}
+    original = {(c.side, c.lod, c.x, c.y): i for c, i in atlas.tiles()}
+    assert set(loaded) == set(original) and len(loaded) == 21
+    ch = 1 if fmt == O.FORMAT_R16 else 4
+    for coord, idx in loaded.items():
+        level0 = fresh.download_tile(0, idx)
+        assert np.array_equal(level0, atlas.download_tile(0, original[coord])), coord
+        chain = np.asarray(O.generate_mipmaps(fmt, level0, 4))
+        off = T * T * ch
+        for mip in (1, 2, 3):
+            s = T >> mip
+            assert np.array_equal(fresh.download_mip(0, mip, idx).ravel(), chain[off:off + s * s * ch]), (coord, mip)
+            off += s * s * ch
+    # explicit coordinate list + error path
+    os.remove(os.path.join(root, "terrains/test/data/att", "0_2_3_1.bin"))
+    again = bt.TileAtlas.new(cfg, device)
+    again.load_tiles(0, root, [bt.TileCoordinate(0, 0, 0, 0), bt.TileCoordinate(0, 1, 1, 0)])
+    assert len(again.tiles()) == 2
+    with pytest.raises(bt._ffi.BtError) as e:
+        again.load_tiles(0, root, [bt.TileCoordinate(0, 2, 3, 1)])
+    assert e.value.status == -5 or "not found" in str(e.value)
