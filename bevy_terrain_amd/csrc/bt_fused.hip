@@ -1334,6 +1334,10 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                     d.rel_index[i] = t->rel[i].atlas_index;
                     d.rel_side[i] = t->rel[i].coordinate.side;
                 }
+                // only the apron regions whose neighbour lives on another face: the fused kernels already wrote the rest
+                for (int i = 0; i < 8; i++)
+                    if (d.rel_index[i] != BT_INVALID_ATLAS_INDEX && d.rel_side[i] != d.side) d.regions |= 1u << i;
+                if (!d.regions) continue;
                 tasks.push_back(d);
             }
             Launch ls{};

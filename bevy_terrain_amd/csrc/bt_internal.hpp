@@ -69,6 +69,7 @@ struct TaskDev {
     uint32_t side, lod, x, y;
     float tlx, tly, brx, bry;
     uint32_t raster;
+    uint32_t regions;       // stitch: bit r set = only apron region r (0 top .. 7 bottom-left) is written; 0 = all eight
     uint32_t rel_index[8];  // children (4) or neighbours (8): atlas indices, INVALID if absent
     uint32_t rel_side[8];   // neighbour sides (stitch across cube faces)
 };

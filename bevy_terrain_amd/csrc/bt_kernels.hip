@@ -295,6 +295,12 @@ __global__ __launch_bounds__(256) void stitch_kernel(AttachmentMeta m, void* __r
         py = b + j / (2u * b);
         px = k < b ? k : (c + k);
     }
+    if (task.regions) {
+        const uint32_t o = b + c;
+        const int rx = px < b ? -1 : (px >= o ? 1 : 0), ry = py < b ? -1 : (py >= o ? 1 : 0);
+        const uint32_t region = ry < 0 ? (rx < 0 ? 4u : (rx > 0 ? 5u : 0u)) : (ry > 0 ? (rx < 0 ? 7u : (rx > 0 ? 6u : 2u)) : (rx > 0 ? 1u : 3u));
+        if (!((task.regions >> region) & 1u)) return;
+    }
     uint32_t layer, sx, sy;
     stitch_source(task, px, py, Tsz, b, c, layer, sx, sy);
     T* base = (T*)atlas;
@@ -323,6 +329,11 @@ __global__ __launch_bounds__(256) void stitch_pairs_kernel(AttachmentMeta m, uin
         const uint32_t j = i - row_pairs, k = j % b, d = k % (b / 2u);
         py = b + j / b;
         px = k < b / 2u ? 2u * d : o + 2u * d;
+    }
+    if (task.regions) {  // a pair lies in one region (b even)
+        const int rx = px < b ? -1 : (px >= o ? 1 : 0), ry = py < b ? -1 : (py >= o ? 1 : 0);
+        const uint32_t region = ry < 0 ? (rx < 0 ? 4u : (rx > 0 ? 5u : 0u)) : (ry > 0 ? (rx < 0 ? 7u : (rx > 0 ? 6u : 2u)) : (rx > 0 ? 1u : 3u));
+        if (!((task.regions >> region) & 1u)) return;
     }
     uint32_t v[2];
 #pragma unroll

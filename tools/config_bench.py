@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Timing of the non-headline BASELINE configs (parity cases, not bench lines): config 2 (4k height + albedo)
+and config 5 (cube, 6 x 8192^2 height).  Prints ms per job and the launch profile."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402,F401
+
+import bevy_terrain_amd as bt  # noqa: E402
+
+
+def time_job(device, pre, atlas, steps=50):
+    for _ in range(10):
+        pre.run(atlas, keep_queue=True, sync=False)
+    device.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record(device.torch_stream)
+    for _ in range(steps):
+        pre.run(atlas, keep_queue=True, sync=False, profile=True)
+    e.record(device.torch_stream)
+    device.synchronize()
+    return s.elapsed_time(e) / steps, pre.profile(), pre.stats()
+
+
+def main():
+    device = bt.Device(0)
+    out = {}
+    # config 2
+    h = device.synth_fbm_r16(4096, 4096, 1234)
+    rng = np.random.default_rng(1235)
+    albedo = rng.integers(1, 256, size=(4096, 4096, 4), dtype=np.uint8)
+    cfg = bt.TerrainConfig(lod_count=4, path="terrains/planar", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=512, border_size=2, format=bt.AttachmentFormat.R16))
+    cfg.add_attachment(bt.AttachmentConfig(name="albedo", texture_size=512, border_size=2, format=bt.AttachmentFormat.Rgba8))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer().insert("h", (h, 4096, 4096)).insert("a", albedo)
+    for name, att, path in (("config2_height_4k", 0, "h"), ("config2_albedo_4k", 1, "a")):
+        pre = bt.Preprocessor.new().clear_attachment(att, atlas).preprocess_tile(
+            bt.PreprocessDataset(attachment_index=att, path=path, lod_range=range(0, 4)), server, atlas)
+        ms, prof, st = time_job(device, pre, atlas)
+        out[name] = {"ms": ms, "tiles": st["tiles"], "launches": [(l["kind"], round(l["avg_ms"] * 1e3, 1)) for l in prof]}
+    # config 5 (height)
+    faces = [(device.synth_fbm_r16(8192, 8192, 7 + s), 8192, 8192) for s in range(6)]
+    cfg = bt.TerrainConfig(lod_count=5, atlas_size=2048, path="terrains/spherical")
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=512, border_size=2, format=bt.AttachmentFormat.R16))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer()
+    paths = [f"face{s}" for s in range(6)]
+    for p, f in zip(paths, faces):
+        server.insert(p, f)
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_spherical(
+        bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, 5)), server, atlas)
+    ms, prof, st = time_job(device, pre, atlas)
+    out["config5_cube_height_8k"] = {"ms": ms, "tiles": st["tiles"], "launches": [(l["kind"], round(l["avg_ms"] * 1e3, 1)) for l in prof]}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
