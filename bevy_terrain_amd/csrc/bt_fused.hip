@@ -990,6 +990,11 @@ __global__ void selftest_kernel(uint32_t* failures) {
         volatile float d = 65535.0f;
         if (unorm16_to_float(t) != float(t) / d) atomicAdd(failures, 1u);
     }
+    if (t < 256u) {  // the 8-bit conversion of the batched kernels (same construction)
+        volatile float d = 255.0f;
+        const float x = float(t), r = 1.0f / 255.0f, q0 = x * r;
+        if (__builtin_fmaf(__builtin_fmaf(-q0, 255.0f, x), r, q0) != x / d) atomicAdd(failures, 1u);
+    }
 }
 
 }  // namespace

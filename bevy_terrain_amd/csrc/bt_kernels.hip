@@ -22,8 +22,18 @@ namespace {
 
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 
-__device__ __forceinline__ float unorm16_to_float(uint32_t t) { return float(t) / 65535.0f; }
-__device__ __forceinline__ float unorm8_to_float(uint32_t t) { return float(t) / 255.0f; }
+// t / 65535 and t / 255, correctly rounded, as mul + two fma (Markstein): equal to the IEEE division for every
+// input of the range — exhaustively checked on the device by bt_selftest and on the CPU by the oracle tests
+__device__ __forceinline__ float unorm16_to_float(uint32_t t) {
+    const float x = float(t), r = 1.0f / 65535.0f;
+    const float q0 = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-q0, 65535.0f, x), r, q0);
+}
+__device__ __forceinline__ float unorm8_to_float(uint32_t t) {
+    const float x = float(t), r = 1.0f / 255.0f;
+    const float q0 = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-q0, 255.0f, x), r, q0);
+}
 
 // pack2x16unorm / pack4x8unorm component: floor(0.5 + N * clamp(e, 0, 1))
 __device__ __forceinline__ uint32_t float_to_unorm(float e, float n) {
@@ -79,15 +89,15 @@ __device__ __forceinline__ bool is_border(uint32_t px, uint32_t py, uint32_t b, 
 // ------------------------------------------------------------------------------------------ split
 
 // value of one centre pixel as a texel (u16 or packed rgba8); `previous` = the atlas texel before the task
-template <uint32_t FORMAT>
-__device__ __forceinline__ uint32_t split_texel(const RasterDev& r, const Axis& ax, const Axis& ay, uint32_t previous) {
+template <uint32_t FORMAT, typename P>
+__device__ __forceinline__ uint32_t split_texel(const RasterDev& r, const Axis& ax, const Axis& ay, const P* previous) {
     const uint8_t* row0 = (const uint8_t*)r.data + uint64_t(ay.i0) * r.pitch;
     const uint8_t* row1 = (const uint8_t*)r.data + uint64_t(ay.i1) * r.pitch;
     if constexpr (FORMAT == BT_FORMAT_R16) {
         const uint32_t t00 = ((const uint16_t*)row0)[ax.i0], t10 = ((const uint16_t*)row0)[ax.i1];
         const uint32_t t01 = ((const uint16_t*)row1)[ax.i0], t11 = ((const uint16_t*)row1)[ax.i1];
         const bool valid = t00 != 0 && t10 != 0 && t01 != 0 && t11 != 0;  // textureGather(0, ..) != 0
-        if (!valid) return previous;
+        if (!valid) return *previous;  // keep what the atlas holds (read only in this case)
         const float top = mixf(unorm16_to_float(t00), unorm16_to_float(t10), ax.fr);
         const float bot = mixf(unorm16_to_float(t01), unorm16_to_float(t11), ax.fr);
         return float_to_unorm(mixf(top, bot, ay.fr), 65535.0f);
@@ -95,7 +105,7 @@ __device__ __forceinline__ uint32_t split_texel(const RasterDev& r, const Axis& 
         const uint32_t t00 = ((const uint32_t*)row0)[ax.i0], t10 = ((const uint32_t*)row0)[ax.i1];
         const uint32_t t01 = ((const uint32_t*)row1)[ax.i0], t11 = ((const uint32_t*)row1)[ax.i1];
         const bool valid = (t00 & 0xFFu) != 0 && (t10 & 0xFFu) != 0 && (t01 & 0xFFu) != 0 && (t11 & 0xFFu) != 0;
-        if (!valid) return previous;
+        if (!valid) return *previous;  // keep what the atlas holds (read only in this case)
         uint32_t out = 0;
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) {
@@ -128,28 +138,37 @@ __global__ __launch_bounds__(256) void split_kernel(AttachmentMeta m, void* __re
     T* tile = (T*)atlas + uint64_t(task.atlas_index) * Tsz * Tsz;
 
     const uint32_t rows = min(kRows, Tsz - row0);
-    for (uint32_t e = threadIdx.x; e < entries_per_row * rows; e += blockDim.x) {
-        const uint32_t py = row0 + e / entries_per_row;
-        const uint32_t ex = e % entries_per_row;
-        uint32_t texels[kPer];
-        Axis ay{};
-        const bool row_is_centre = py >= b && py < b + c;
-        if (row_is_centre) ay = split_axis(py, b, c, task.y, scale, task.tly, task.bry, raster.height);
+    // y parameters once per row (threads 0..rows-1), x parameters once per thread and column: the only divisions
+    __shared__ Axis s_ay[kRows];
+    if (threadIdx.x < rows) {
+        const uint32_t py = row0 + threadIdx.x;
+        if (py >= b && py < b + c) s_ay[threadIdx.x] = split_axis(py, b, c, task.y, scale, task.tly, task.bry, raster.height);
+    }
+    __syncthreads();
+    for (uint32_t ex = threadIdx.x; ex < entries_per_row; ex += blockDim.x) {
+        Axis ax[kPer];
+        bool col_is_centre[kPer];
 #pragma unroll
         for (uint32_t k = 0; k < kPer; k++) {
             const uint32_t px = ex * kPer + k;
-            if (!row_is_centre || px < b || px >= b + c) {
-                texels[k] = 0;  // split.wgsl:19-21: border pixels are zero until stitch fills them
-                continue;
-            }
-            const Axis ax = split_axis(px, b, c, task.x, scale, task.tlx, task.brx, raster.width);
-            const uint32_t previous = tile[uint64_t(py) * Tsz + px];
-            texels[k] = split_texel<FORMAT>(raster, ax, ay, previous);
+            col_is_centre[k] = px >= b && px < b + c;
+            ax[k] = col_is_centre[k] ? split_axis(px, b, c, task.x, scale, task.tlx, task.brx, raster.width) : Axis{};
         }
-        if constexpr (FORMAT == BT_FORMAT_R16)
-            ((uint32_t*)tile)[(uint64_t(py) * Tsz) / 2 + ex] = texels[0] | (texels[1] << 16);
-        else
-            tile[uint64_t(py) * Tsz + ex] = texels[0];
+        for (uint32_t r = 0; r < rows; r++) {
+            const uint32_t py = row0 + r;
+            const bool row_is_centre = py >= b && py < b + c;
+            uint32_t texels[kPer];
+#pragma unroll
+            for (uint32_t k = 0; k < kPer; k++) {
+                const uint32_t px = ex * kPer + k;
+                // split.wgsl:19-21: border pixels are zero until stitch fills them
+                texels[k] = (row_is_centre && col_is_centre[k]) ? split_texel<FORMAT>(raster, ax[k], s_ay[r], tile + uint64_t(py) * Tsz + px) : 0u;
+            }
+            if constexpr (FORMAT == BT_FORMAT_R16)
+                ((uint32_t*)tile)[(uint64_t(py) * Tsz) / 2 + ex] = texels[0] | (texels[1] << 16);
+            else
+                tile[uint64_t(py) * Tsz + ex] = texels[0];
+        }
     }
 }
 
