@@ -53,7 +53,14 @@ void generic_plan(const bt_preprocessor* p, const bt_atlas* a, std::vector<TaskD
         }
         size_t j = i;
         const uint32_t first = uint32_t(tasks.size());
-        while (j < q.size() && q[j].type == t.type && q[j].attachment_index == t.attachment_index) {
+        while (j < q.size()) {
+            // stitch phases of consecutive LODs are independent of each other (a stitch reads same-LOD centres and
+            // writes its own apron): the barriers / saves between them do not end the launch
+            if (t.type == kStitch && (q[j].type == kBarrier || q[j].type == kSave)) {
+                j++;
+                continue;
+            }
+            if (q[j].type != t.type || q[j].attachment_index != t.attachment_index) break;
             tasks.push_back(to_device_task(q[j]));
             j++;
         }
@@ -61,7 +68,7 @@ void generic_plan(const bt_preprocessor* p, const bt_atlas* a, std::vector<TaskD
         l.kind = t.type == kSplit ? kLaunchSplit : t.type == kDownsample ? kLaunchDownsample : kLaunchStitch;
         l.attachment = t.attachment_index;
         l.first_task = first;
-        l.task_count = uint32_t(j - i);
+        l.task_count = uint32_t(tasks.size()) - first;
         {   // algorithmic bytes of this launch
             const AttachmentMeta& m = a->attachments[t.attachment_index].meta;
             const uint64_t bpp = m.pixel_size, T = m.texture_size, c = m.center_size, b = m.border_size;
@@ -76,7 +83,7 @@ void generic_plan(const bt_preprocessor* p, const bt_atlas* a, std::vector<TaskD
             } else if (t.type == kDownsample) {
                 l.algorithmic_bytes = uint64_t(j - i) * (4 * c * c + T * T) * bpp;  // 4 child texels per centre pixel
             } else {
-                l.algorithmic_bytes = uint64_t(j - i) * 2 * (2 * b * (T + c)) * bpp;  // apron read + written
+                l.algorithmic_bytes = uint64_t(l.task_count) * 2 * (2 * b * (T + c)) * bpp;  // apron read + written
             }
         }
         plan.push_back(l);
