@@ -185,12 +185,12 @@ def main():
         "scaling": "strong" if world > 1 else "weak",
         "collective_backend": backend if world > 1 else None,
         "vs_baseline": None,
-        "dtype": "f32 arithmetic on u16 texels",
+        "dtype": "f32",  # IEEE binary32 arithmetic on u16 texels, results bit-exact vs the oracle
         "data": "synthetic",
         "config": {"workload": f"synthetic {SIZE}x{SIZE} fBm R16 heightmap (seed {SEED}), T={TEXTURE_SIZE}, b={BORDER}, "
                                f"lod_count={LOD_COUNT}: split + pyramid + stitch into {tiles} tiles",
                    "path": "generic (batched split/downsample/stitch)" if stats["fused_jobs"] == 0 else "fused",
-                   "kernel_launches_per_step": stats["kernel_launches"],
+                   "plan_launches_per_step": stats["kernel_launches"],  # fused_main (+ fused_todo) and fused_tail
                    "algorithmic_bytes_per_step": stats["algorithmic_bytes"],
                    "whole_step_GBps": stats["algorithmic_bytes"] / (ms_per_step / 1e3) / 1e9,
                    "host_wall_ms_per_step": wall_ms / args.steps,
