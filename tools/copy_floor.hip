@@ -6,7 +6,7 @@
 #include <cstdio>
 #include <cstdint>
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k(const uint16_t* src, uint16_t* tiles, uint16_t* parents, int mode, int depth) {
+__global__ __launch_bounds__(256) void k(const uint16_t* src, uint16_t* tiles, uint16_t* parents, int mode, int depth, int prot = 0) {
     // blockIdx -> XCD-contiguous work id, tile-row order
     const uint32_t total = gridDim.x, q = total / 8, xcd = blockIdx.x % 8, i = blockIdx.x / 8;
     const uint32_t work = xcd * q + i, ty = work / 32, tx = work % 32;
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k(const uint16_t* src, uint16_t* tiles, u
             else acc += v[j];
             if ((mode & 2) && ((r + 4 * j) & 1u) == 0) *(uint2*)(p + uint64_t((r + 4 * j) >> 1) * 512) = uint2{v[j].x, v[j].y};
             // the same parent bytes as whole 1 KB rows (every 4th row of the tile writes one)
-            if ((mode & 4) && ((r + 4 * j) & 3u) == 0) *(u32x4*)((uint8_t*)parents + uint64_t(tx * 32 + ty) * 131072 + uint64_t((r + 4 * j) >> 2) * 1024 + lane16 * 16) = v[j];
+            if ((mode & 4) && ((r + 4 * j) & 3u) == 0) *(u32x4*)((uint8_t*)parents + uint64_t(tx * 32 + ty) * 131072 + uint64_t((((r + 4 * j) >> 2) + prot) & 127u) * 1024 + lane16 * 16) = v[j];
         }
     }
     if (!(mode & 1) && acc.x == 0x12345678u) tiles[0] = 1;
@@ -61,6 +61,14 @@ int main() {
         const double bytes = 536870912.0 + ((mode & 1) ? 536870912.0 : 0) + ((mode & 6) ? 134217728.0 : 0);
         printf("loads in flight per lane %d, mode %d (%s): %.1f us  %.2f TB/s\n", depth, mode,
                mode == 0 ? "read only" : mode == 1 ? "read + tile write" : mode == 3 ? "read + tile + parent write (512-byte pieces)" : "read + tile + parent write (whole 1 KB rows)", ms * 10, bytes / (ms * 1e-5) / 1e12);
+    }
+    for (int prot : {0, 1, 7, 32, 64, 100}) {  // parent rows written out of phase with the tile rows
+        for (int i = 0; i < 200; i++) k<<<1024, 256>>>(src, tiles, parents, 5, 1, prot);
+        hipEventRecord(e0);
+        for (int i = 0; i < 100; i++) k<<<1024, 256>>>(src, tiles, parents, 5, 1, prot);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("parent rows rotated by %d: %.1f us\n", prot, ms * 10);
     }
     for (int blocks : {1024, 2048, 4096, 16384}) {
         for (int i = 0; i < 200; i++) stride_copy<<<blocks, 256>>>((const u32x4*)src, (u32x4*)tiles, 536870912ull / 16);
