@@ -168,6 +168,21 @@ def main():
         ms = float(t.item())
     ms_per_step = ms / args.steps
 
+    # N > 1: the same K steps once more without the collectives — kernels only (SURVEY §8e asks for both)
+    compute_only_ms = None
+    if job is not None:
+        fence()
+        start.record(stream)
+        for _ in range(args.steps):
+            job.step(False, gather=False)
+        stop.record(stream)
+        fence()
+        t = torch.tensor([start.elapsed_time(stop)], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        compute_only_ms = float(t.item()) / args.steps
+        job.step(False)  # leave a complete atlas behind (--verify)
+        fence()
+
     stats = pre.stats() if job is None else job.stats()
     tiles = stats["tiles"]
     launches = pre.profile() if job is None else job.profile()
@@ -194,6 +209,8 @@ def main():
                    "algorithmic_bytes_per_step": stats["algorithmic_bytes"],
                    "whole_step_GBps": stats["algorithmic_bytes"] / (ms_per_step / 1e3) / 1e9,
                    "host_wall_ms_per_step": wall_ms / args.steps,
+                   "kernels_only_ms_per_step": compute_only_ms,  # N > 1: without the all-gathers
+                   "all_gather_bytes_per_rank": (job.gather_bytes if job is not None else 0),
                    "launches": launches},
     }
     if dominant:

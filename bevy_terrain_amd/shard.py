@@ -74,7 +74,8 @@ class ShardedPreprocess:
     def _run(self, flags):
         _ffi.check(_ffi.lib().bt_preprocessor_run(self.pre._h, self.atlas._h, self.flags | flags))
 
-    def step(self, profile: bool = False):
+    def step(self, profile: bool = False, gather: bool = True):
+        """gather=False skips the collectives (timing of the kernels alone; the atlas is then incomplete)."""
         import torch
 
         p = _ffi.RUN_PROFILE if profile else 0
@@ -82,8 +83,9 @@ class ShardedPreprocess:
         if self._ranges is None:
             self._ranges = shard_ranges(self.pre)
             self.gather_bytes = sum(r["layers_per_rank"] * self.world * self.tile_bytes for r in self._ranges)
-        with torch.cuda.stream(self.stream):  # same queue as the kernels: ordered without host syncs
-            all_gather_ranges(self.storage, self.tile_bytes, self._ranges, self.rank, self.world, self.dist)
+        if gather:
+            with torch.cuda.stream(self.stream):  # same queue as the kernels: ordered without host syncs
+                all_gather_ranges(self.storage, self.tile_bytes, self._ranges, self.rank, self.world, self.dist)
         self._run(_ffi.RUN_SHARD_FINISH)
 
     def stats(self):
