@@ -131,13 +131,14 @@ __device__ __forceinline__ TileNb load_tile_nb(const FusedArgs& A, uint32_t side
 //  - the tile's own apron where the neighbour on that side is absent (repeat_data clamps into the centre),
 //  - the facing apron of each existing neighbour whose b-wide strip contains the pixel.
 // Neighbours are looked up only for the few pixels within b of a tile edge.
+template <bool kCentre = true>
 __device__ __forceinline__ void push_pixel(const FusedArgs& A, uint32_t side, uint32_t lod, uint32_t tx, uint32_t ty,
                                            uint32_t self_index, uint32_t cx, uint32_t cy, uint16_t v) {
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
     const uint64_t tile_texels = uint64_t(T) * T;
     uint16_t* atlas = A.atlas;
     uint16_t* self = atlas + uint64_t(self_index) * tile_texels;
-    self[uint64_t(b + cy) * T + b + cx] = v;
+    if (kCentre) self[uint64_t(b + cy) * T + b + cx] = v;  // (false: the caller stored the centre texel, e.g. as half of a pair)
     const int ex = cx < b ? -1 : (cx >= c - b ? 1 : 0);
     const int ey = cy < b ? -1 : (cy >= c - b ? 1 : 0);
     if (ex == 0 && ey == 0) return;
@@ -959,10 +960,14 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
         const uint32_t x1 = gx >> 1, y1 = gy >> 1;
         const uint32_t self = self1;
         if (self != kInvalid) {
+            // the two pixels of a row are one aligned dword of the tile (x1, b, c even); aprons per pixel, edge pixels only
+            uint16_t* centre = A.atlas + uint64_t(self) * tile_texels + (b + y1 % c) * T + b + x1 % c;
 #pragma unroll
-            for (int r = 0; r < 2; r++)
+            for (int r = 0; r < 2; r++) {
+                *reinterpret_cast<uint32_t*>(centre + r * T) = q[r][0] | (q[r][1] << 16);
 #pragma unroll
-                for (int k = 0; k < 2; k++) push_pixel(A, side, A.lod - 1, x1 / c, y1 / c, self, x1 % c + k, y1 % c + r, uint16_t(q[r][k]));
+                for (int k = 0; k < 2; k++) push_pixel<false>(A, side, A.lod - 1, x1 / c, y1 / c, self, x1 % c + k, y1 % c + r, uint16_t(q[r][k]));
+            }
         }
     }
     if (A.levels < 2) return;
