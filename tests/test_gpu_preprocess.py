@@ -264,3 +264,13 @@ def test_tile_load_path_round_trip(device, tmp_path, fmt):
     with pytest.raises(bt._ffi.BtError) as e:
         again.load_tiles(0, root, [bt.TileCoordinate(0, 2, 3, 1)])
     assert e.value.status == -5 or "not found" in str(e.value)
+
+
+@pytest.mark.parametrize("T,b,W", [(512, 4, 2100), (512, 8, 1900), (256, 2, 1100), (384, 6, 1500)])
+def test_fused_path_other_borders_and_sizes(device, T, b, W):
+    # wider aprons / other texture sizes through the fused kernels (runtime-shape template instance for T != 512 or b != 2)
+    src = K.smooth_raster(W, W + 64, seed=T + b, device=device)
+    src[W // 2:W // 2 + 9, W // 3:W // 3 + 40] = 0
+    atlas, pre = K.product_planar(device, src, 3, T, b, O.FORMAT_R16)
+    assert pre.stats()["fused_jobs"] == 1
+    assert K.assert_atlas_equal(atlas, K.oracle_planar(src, 3, T, b, O.FORMAT_R16)) == 21
