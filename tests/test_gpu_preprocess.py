@@ -274,3 +274,13 @@ def test_fused_path_other_borders_and_sizes(device, T, b, W):
     atlas, pre = K.product_planar(device, src, 3, T, b, O.FORMAT_R16)
     assert pre.stats()["fused_jobs"] == 1
     assert K.assert_atlas_equal(atlas, K.oracle_planar(src, 3, T, b, O.FORMAT_R16)) == 21
+
+
+@pytest.mark.parametrize("W,H", [(200, 170), (2500, 2300), (4100, 600)])
+def test_fused_path_resample_ratios(device, W, H):
+    # mosaic of 4 x 124 = 496 pixels per side: upsampling (0.4x), strong downsampling (5x: the source window no longer
+    # fits the LDS budget, the kernel variant that reads the raster directly takes over) and a very anisotropic raster
+    src = K.random_raster(O.FORMAT_R16, H, W, seed=W, holes=0.002)
+    atlas, pre = K.product_planar(device, src, 3, 128, 2, O.FORMAT_R16)
+    assert pre.stats()["fused_jobs"] == 1
+    assert K.assert_atlas_equal(atlas, K.oracle_planar(src, 3, 128, 2, O.FORMAT_R16)) == 21
