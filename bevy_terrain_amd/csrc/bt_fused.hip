@@ -1073,6 +1073,8 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         if (m.format != BT_FORMAT_R16 || m.texture_size > 512 || (m.border_size & 1u) || (m.center_size & 3u) ||
             m.center_size < 2 * m.border_size || m.border_size == 0 || m.border_size > 8)
             return false;
+        // the kernels keep texel offsets into the atlas in 32 bits
+        if (uint64_t(a->config.atlas_size) * m.texture_size * m.texture_size >= (1ull << 32)) return false;
         const uint32_t lod_hi = splits[0]->coord.lod;
         uint32_t lod_lo = lod_hi;
         for (const Task* t : downs) lod_lo = std::min(lod_lo, t->coord.lod);
