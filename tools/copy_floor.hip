@@ -30,6 +30,20 @@ __global__ __launch_bounds__(256) void k(const uint16_t* src, uint16_t* tiles, u
     }
     if (!(mode & 1) && acc.x == 0x12345678u) tiles[0] = 1;
 }
+// the job's geometry with P workgroups per tile: contiguous row ranges (inter = 0) or 8-row chunks dealt round-robin
+// (inter = 1); the P workgroups of a tile have consecutive work ids (same XCD, same time)
+__global__ __launch_bounds__(256) void kparts(const uint16_t* src, uint16_t* tiles, uint32_t P, int inter) {
+    const uint32_t total = gridDim.x, q = total / 8, xcd = blockIdx.x % 8, i = blockIdx.x / 8;
+    const uint32_t work = xcd * q + i, tile = work / P, part = work % P, ty = tile / 32, tx = tile % 32;
+    const uint32_t lane16 = threadIdx.x & 63u, rsub = threadIdx.x >> 6;
+    const uint8_t* s = (const uint8_t*)src + (uint64_t(ty) * 512) * 32768 + uint64_t(tx) * 1024 + lane16 * 16;
+    uint8_t* d = (uint8_t*)tiles + uint64_t(tx * 32 + ty) * 524288 + lane16 * 16;
+    const uint32_t chunks = 64 / P;
+    for (uint32_t c = 0; c < chunks; c++) {
+        const uint32_t k = inter ? c * P + part : part * chunks + c;
+        for (uint32_t r = k * 8 + rsub; r < k * 8 + 8; r += 4) *(u32x4*)(d + uint64_t(r) * 1024) = *(const u32x4*)(s + uint64_t(r) * 32768);
+    }
+}
 // reference points: a plain linear copy, and the two half-way geometries
 __global__ __launch_bounds__(256) void lin(const uint8_t* src, uint8_t* dst, uint64_t bytes, int mode) {
     // mode 0: linear -> linear.  mode 1: tile-geometry reads -> linear writes.  mode 2: linear reads -> tile-geometry writes
@@ -69,6 +83,14 @@ int main() {
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("parent rows rotated by %d: %.1f us\n", prot, ms * 10);
+    }
+    for (int inter : {0, 1}) for (uint32_t P : {1u, 2u, 4u, 8u}) {
+        for (int i = 0; i < 200; i++) kparts<<<1024 * P, 256>>>(src, tiles, P, inter);
+        hipEventRecord(e0);
+        for (int i = 0; i < 100; i++) kparts<<<1024 * P, 256>>>(src, tiles, P, inter);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("read + tile write, %u workgroups per tile, %s: %.1f us\n", P, inter ? "chunks dealt round-robin" : "contiguous row ranges", ms * 10);
     }
     for (int blocks : {1024, 2048, 4096, 16384}) {
         for (int i = 0; i < 200; i++) stride_copy<<<blocks, 256>>>((const u32x4*)src, (u32x4*)tiles, 536870912ull / 16);
