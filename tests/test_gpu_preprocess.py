@@ -284,3 +284,46 @@ def test_fused_path_resample_ratios(device, W, H):
     atlas, pre = K.product_planar(device, src, 3, 128, 2, O.FORMAT_R16)
     assert pre.stats()["fused_jobs"] == 1
     assert K.assert_atlas_equal(atlas, K.oracle_planar(src, 3, 128, 2, O.FORMAT_R16)) == 21
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("pad_texels", [8, 3])
+def test_padded_row_pitch_device_raster(device, generic, pad_texels):
+    # a device raster whose rows are padded (row_pitch > width * 2): 16-byte aligned pitch takes the wide staging
+    # loads, an odd pitch the texel-by-texel staging
+    h, w = 300, 520
+    src = K.random_raster(O.FORMAT_R16, h, w, seed=77, holes=0.01)
+    padded = np.full((h, w + pad_texels), 0xABCD, dtype=np.uint16)
+    padded[:, :w] = src
+    ptr = device.upload(padded)
+    cfg = bt.TerrainConfig(lod_count=3, atlas_size=64, path="terrains/test", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="att", texture_size=128, border_size=2, format=bt.AttachmentFormat.R16))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer().insert("src", (ptr, w, h, (w + pad_texels) * 2))
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_tile(
+        bt.PreprocessDataset(attachment_index=0, path="src", lod_range=range(0, 3)), server, atlas)
+    pre.run(atlas, generic=generic)
+    device.free(ptr)
+    assert K.assert_atlas_equal(atlas, K.oracle_planar(src, 3, 128, 2, O.FORMAT_R16)) == 21
+
+
+def test_degenerate_inputs(device):
+    cfg = bt.TerrainConfig(lod_count=3, atlas_size=32, path="terrains/test", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="att", texture_size=16, border_size=2, format=bt.AttachmentFormat.R16))
+    src = K.random_raster(O.FORMAT_R16, 40, 40, seed=5)
+    # an empty LOD range (the reference underflows `lod_range.end - 1`, preprocessor.rs:300-312) is an argument error,
+    # and nothing is queued; running an empty queue is a no-op
+    atlas = bt.TileAtlas.new(cfg, device)
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas)
+    with pytest.raises(bt._ffi.BtError) as e:
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="s", lod_range=range(0, 0)), bt.AssetServer().insert("s", src), atlas)
+    assert e.value.status == -1
+    assert sum(pre.task_counts().values()) == 0
+    pre.run(atlas)
+    assert atlas.tiles() == []
+    # a 1 x 1 raster: every pixel of every tile is that texel (clamp-to-edge), through both paths
+    one = np.array([[12345]], dtype=np.uint16)
+    for generic in (False, True):
+        a, _ = K.product_planar(device, one, 2, 16, 2, O.FORMAT_R16, generic=generic)
+        assert K.assert_atlas_equal(a, K.oracle_planar(one, 2, 16, 2, O.FORMAT_R16)) == 5
+        assert int(a.download_tile(0, 0)[8, 8]) == 12345
