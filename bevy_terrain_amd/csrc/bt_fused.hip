@@ -1010,6 +1010,7 @@ struct FusedJobDev {  // device buffers of one fused job, kept alive in the prep
     FusedArgs args;
     uint32_t attachment;
     uint32_t main_runs = 0;  // parity selects the todo list
+    uint32_t lds_pad = 0;    // debug (env BT_FUSED_LDS_PAD at plan time): extra dynamic LDS per workgroup
 };
 
 static std::vector<FusedJobDev>& jobs_of(bt_preprocessor* p);
@@ -1197,6 +1198,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         const uint32_t nlods = lod_hi - lod_lo + 1;
         const uint32_t main_levels = std::min(3u, nlods);
         FusedJobDev main_job{args, ai};
+        if (const char* e = getenv("BT_FUSED_LDS_PAD")) main_job.lds_pad = uint32_t(atoi(e));
         main_job.args.lod = lod_hi;
         main_job.args.levels = main_levels;
         main_job.args.item_count = uint32_t(items.size());
@@ -1383,7 +1385,7 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
         const uint32_t blocks = job.args.item_count * job.args.groups;
         if (job.args.lds_rows) {
             size_t lds = sizeof(MainShared) + 2 * size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
-            if (const char* e = getenv("BT_FUSED_LDS_PAD")) lds = std::min<size_t>(65536, lds + size_t(atoi(e)));  // occupancy experiments
+            lds = std::min<size_t>(65536, lds + job.lds_pad);  // (occupancy experiments)
             if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528)
                 fused_main_kernel<true, false, 512, 528><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
             else
