@@ -123,6 +123,7 @@ PROTOTYPES = {
     "bt_atlas_save_tile_config": (_i32, [_vp, C.c_char_p]),
     "bt_atlas_load_tile_config": (_i32, [_vp, C.c_char_p]),
     "bt_atlas_load_tiles": (_i32, [_vp, _u32, C.c_char_p, _vp, _u32]),
+    "bt_atlas_sample": (_i32, [_vp, _u32, _vp, _u32, _vp]),
     "bt_tc_encode": (_u64, [_P(TileCoordinateC), _u32, _vp, _u64]),
     "bt_tc_decode": (C.c_int64, [_vp, _u64, _P(TileCoordinateC), _u32]),
     "bt_generate_mipmaps": (_i32, [_vp, _u32, _u32, _u32, _vp, _vp, _u64]),

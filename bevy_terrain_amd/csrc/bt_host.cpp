@@ -629,6 +629,25 @@ bt_status bt_atlas_load_tiles(bt_atlas* a, uint32_t ai, const char* directory, c
     return BT_OK;
 }
 
+bt_status bt_atlas_sample(bt_atlas* a, uint32_t ai, const bt_tile_lookup* lookups, uint32_t count, float* out) {
+    if (!a || ai >= a->attachments.size() || (count && (!lookups || !out))) return BT_ERR_INVALID_ARGUMENT;
+    const Attachment& at = a->attachments[ai];
+    if (at.meta.format != BT_FORMAT_R16 && at.meta.format != BT_FORMAT_RGBA8) return BT_ERR_UNSUPPORTED;
+    if (!count) return BT_OK;
+    BT_HIP(hipSetDevice(a->ctx->device));
+    void* dev = nullptr;
+    const size_t in_bytes = sizeof(bt_tile_lookup) * size_t(count), out_bytes = 16 * size_t(count);
+    BT_HIP(hipMalloc(&dev, in_bytes + out_bytes));
+    hipError_t e = hipMemcpyAsync(dev, lookups, in_bytes, hipMemcpyHostToDevice, a->ctx->stream);
+    bt_status rc = BT_OK;
+    if (e == hipSuccess) rc = launch_sample(a->ctx, at.meta, at.level0, (const bt_tile_lookup*)dev, count, (float*)((uint8_t*)dev + in_bytes));
+    if (e == hipSuccess && rc == BT_OK) e = hipMemcpyAsync(out, (uint8_t*)dev + in_bytes, out_bytes, hipMemcpyDeviceToHost, a->ctx->stream);
+    if (e == hipSuccess && rc == BT_OK) e = hipStreamSynchronize(a->ctx->stream);
+    hipFree(dev);
+    if (e != hipSuccess) return hip_fail(e, "bt_atlas_sample");
+    return rc;
+}
+
 bt_status bt_atlas_mip_storage(const bt_atlas* a, uint32_t ai, uint32_t level, void** ptr, uint64_t* tile_bytes) {
     if (!a || ai >= a->attachments.size() || level >= a->attachments[ai].mips.size()) return BT_ERR_INVALID_ARGUMENT;
     const Attachment& at = a->attachments[ai];

@@ -407,6 +407,57 @@ __global__ __launch_bounds__(256) void mip_rgba8_kernel(const uint32_t* __restri
     }
 }
 
+// -------------------------------------------------------------------------- atlas sampling (CPU-side queries)
+
+// AtlasAttachment::sample + AttachmentData::sample (tile_atlas.rs:249-258, terrain_data/mod.rs:220-263), one lookup
+// per thread.  Same operation order as the reference's f32 code (glam lerp = a + (b - a) * s, no contraction);
+// texel coordinates clamped into the tile where the reference would index out of bounds.
+__global__ __launch_bounds__(256) void sample_kernel(AttachmentMeta m, const void* __restrict__ atlas, const bt_tile_lookup* __restrict__ lookups,
+                                                     uint32_t count, float4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const bt_tile_lookup l = lookups[i];
+    if (l.atlas_index >= m.atlas_size) {  // INVALID_ATLAS_INDEX (or out of range): "Todo: Handle this better" -> zero
+        out[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
+    const uint32_t T = m.texture_size;
+    const float scale = float(m.center_size) / float(T), offset = float(m.border_size) / float(T);
+    float rem[2];
+    int ixy[2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        const float u = l.atlas_uv[a] * scale + offset;
+        const float uv = u * float(T) - 0.5f;
+        rem[a] = fmodf(uv, 1.0f);
+        ixy[a] = int(uv);
+    }
+    float v[2][2][4];
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int y = 0; y < 2; y++) {
+            const uint32_t px = uint32_t(min(max(ixy[0] + x, 0), int(T) - 1)), py = uint32_t(min(max(ixy[1] + y, 0), int(T) - 1));
+            const uint64_t index = uint64_t(l.atlas_index) * T * T + uint64_t(py) * T + px;
+            if (m.format == BT_FORMAT_R16) {
+                v[x][y][0] = unorm16_to_float(((const uint16_t*)atlas)[index]);
+                v[x][y][1] = v[x][y][2] = v[x][y][3] = 0.0f;
+            } else {
+                const uint32_t t = ((const uint32_t*)atlas)[index];
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[x][y][k] = unorm8_to_float((t >> (8 * k)) & 0xFFu);
+            }
+        }
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float a = v[0][0][k] + (v[0][1][k] - v[0][0][k]) * rem[1];
+        const float b = v[1][0][k] + (v[1][1][k] - v[1][0][k]) * rem[1];
+        r[k] = a + (b - a) * rem[0];
+    }
+    out[i] = make_float4(r[0], r[1], r[2], r[3]);
+}
+
 // -------------------------------------------------------------------- synthetic fBm (bench input)
 
 __device__ __forceinline__ uint64_t hash2(uint64_t ix, uint64_t iy, uint32_t seed) {
@@ -492,6 +543,12 @@ bt_status launch_stitch(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const
     else
         stitch_kernel<uint32_t><<<n * blocks, 256, 0, ctx->stream>>>(m, atlas, tasks, blocks);
     return check_launch("stitch_kernel");
+}
+
+bt_status launch_sample(bt_ctx* ctx, const AttachmentMeta& m, const void* atlas, const bt_tile_lookup* lookups, uint32_t count, float* out) {
+    if (!count) return BT_OK;
+    sample_kernel<<<(count + 255u) / 256u, 256, 0, ctx->stream>>>(m, atlas, lookups, count, (float4*)out);
+    return check_launch("sample_kernel");
 }
 
 bt_status launch_mip_level(bt_ctx* ctx, uint32_t format, const void* parent, void* child, uint32_t parent_size,

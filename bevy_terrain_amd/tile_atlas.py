@@ -199,6 +199,21 @@ class TileAtlas:
             _ffi.check(_ffi.lib().bt_atlas_load_tiles(self._h, attachment_index, directory, arr, len(coords)))
         return self
 
+    def sample(self, attachment_index: int, atlas_indices, atlas_uvs, atlas_lods=None) -> np.ndarray:
+        """TileAtlas::sample_attachment for a batch of TileLookups (tile_atlas.rs:249-258, 569-571): bilinear sample
+        of level 0 of tile `atlas_indices[i]` at `atlas_uvs[i]` (uv over the tile's centre) -> (n, 4) float32."""
+        idx = np.ascontiguousarray(atlas_indices, dtype=np.uint32).ravel()
+        uv = np.ascontiguousarray(atlas_uvs, dtype=np.float32).reshape(-1, 2)
+        n = len(idx)
+        lookups = np.zeros(n, dtype=np.dtype([("atlas_index", "<u4"), ("atlas_lod", "<u4"), ("atlas_uv", "<f4", (2,))]))
+        lookups["atlas_index"] = idx
+        lookups["atlas_lod"] = 0 if atlas_lods is None else np.asarray(atlas_lods, dtype=np.uint32)
+        lookups["atlas_uv"] = uv
+        out = np.empty((n, 4), dtype=np.float32)
+        _ffi.check(_ffi.lib().bt_atlas_sample(self._h, attachment_index, lookups.ctypes.data_as(C.c_void_p), n,
+                                              out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def close(self):
         if getattr(self, "_h", None):
             _ffi.lib().bt_atlas_destroy(self._h)

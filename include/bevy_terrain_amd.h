@@ -186,6 +186,19 @@ bt_status bt_atlas_load_tiles(bt_atlas* atlas, uint32_t attachment_index, const 
 bt_status bt_atlas_mip_storage(const bt_atlas* atlas, uint32_t attachment_index, uint32_t mip_level,
                                void** device_ptr, uint64_t* tile_bytes);
 
+/* TileLookup (terrain_data/tile_tree.rs:67-81): the best loaded tile for a position and the uv inside its centre. */
+typedef struct bt_tile_lookup {
+    uint32_t atlas_index; /* BT_INVALID_ATLAS_INDEX: nothing loaded -> the sample is vec4(0) (tile_atlas.rs:250-252) */
+    uint32_t atlas_lod;
+    float atlas_uv[2];
+} bt_tile_lookup;
+/* TileAtlas::sample_attachment -> AtlasAttachment::sample + AttachmentData::sample (tile_atlas.rs:249-258, 569-571;
+ * terrain_data/mod.rs:220-263) for a batch of lookups: bilinear sample of the tile's level 0, vec4 per lookup
+ * (R16: x = height in [0, 1]).  The reference keeps a CPU copy of every loaded tile for this; here the tiles live in
+ * HBM, so the query runs there: `lookups_host` in, `out_vec4_host` (4 floats per lookup) out, synchronous. */
+bt_status bt_atlas_sample(bt_atlas* atlas, uint32_t attachment_index, const bt_tile_lookup* lookups_host, uint32_t count,
+                          float* out_vec4_host);
+
 /* ------------------------------- Preprocessor (preprocess/preprocessor.rs) */
 bt_status bt_preprocessor_create(bt_ctx* ctx, bt_preprocessor** out); /* Preprocessor::new :224-232 */
 void bt_preprocessor_destroy(bt_preprocessor* p);

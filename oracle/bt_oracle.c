@@ -859,6 +859,40 @@ int orc_save_tile_config(const orc_atlas* a, const char* path) {
 /* terrain_data/mod.rs:143-219  generate_mipmaps                             */
 /* ======================================================================== */
 
+void orc_sample_tile(uint32_t format, uint32_t texture_size, uint32_t border_size, const void* level0,
+                     const float atlas_uv[2], float out[4]) {
+    const uint32_t T = texture_size, c = T - 2u * border_size;
+    const float scale = (float)c / (float)T, offset = (float)border_size / (float)T; /* tile_atlas.rs:183-184 */
+    float uv[2], rem[2];
+    int ixy[2];
+    for (int a = 0; a < 2; a++) {
+        const float u = atlas_uv[a] * scale + offset;        /* tile_atlas.rs:255 */
+        uv[a] = u * (float)T - 0.5f;                          /* mod.rs:221 */
+        rem[a] = fmodf(uv[a], 1.0f);                          /* `uv % 1.0`, mod.rs:223 */
+        ixy[a] = (int)uv[a];                                  /* as_ivec2: truncation, mod.rs:224 */
+    }
+    float v[2][2][4];
+    for (int x = 0; x < 2; x++)
+        for (int y = 0; y < 2; y++) {                         /* iproduct!(0..2, 0..2), mod.rs:228 */
+            int px = ixy[0] + x, py = ixy[1] + y;
+            px = px < 0 ? 0 : (px > (int)T - 1 ? (int)T - 1 : px);
+            py = py < 0 ? 0 : (py > (int)T - 1 ? (int)T - 1 : py);
+            const size_t index = (size_t)py * T + (size_t)px;
+            if (format == ORC_FORMAT_R16) {
+                v[x][y][0] = (float)((const uint16_t*)level0)[index] / 65535.0f;
+                v[x][y][1] = v[x][y][2] = v[x][y][3] = 0.0f;
+            } else {
+                const uint8_t* t = (const uint8_t*)level0 + 4 * index;
+                for (int k = 0; k < 4; k++) v[x][y][k] = (float)t[k] / 255.0f;
+            }
+        }
+    for (int k = 0; k < 4; k++) {                             /* mod.rs:258-262 */
+        const float a = v[0][0][k] + (v[0][1][k] - v[0][0][k]) * rem[1];
+        const float b = v[1][0][k] + (v[1][1][k] - v[1][0][k]) * rem[1];
+        out[k] = a + (b - a) * rem[0];
+    }
+}
+
 size_t orc_generate_mipmaps(uint32_t format, uint32_t texture_size, uint32_t mip_level_count,
                             const void* level0, void* out) {
     size_t start = 0, parent_size = texture_size, len = (size_t)texture_size * texture_size;

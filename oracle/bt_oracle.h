@@ -107,6 +107,12 @@ void orc_split_pixel(uint32_t format, uint32_t T, uint32_t b, orc_coord tile, co
 
 /* ---- terrain_data/mod.rs:143-219 -------------------------------------- */
 /* out holds all levels concatenated (level 0 copied first); returns texels written */
+/* AtlasAttachment::sample (tile_atlas.rs:249-258) + AttachmentData::sample (terrain_data/mod.rs:220-263): bilinear
+ * sample of level 0 of one tile at `atlas_uv` (the TileLookup's uv over the tile's centre).  out = vec4 (R16: x only).
+ * Vec4::lerp is glam's `a + (b - a) * s` (bevy 0.14.0 pins glam 0.27; glam is not vendored in the reference).
+ * Defined here where the reference would panic (index out of bounds): texel coordinates are clamped into the tile. */
+void orc_sample_tile(uint32_t format, uint32_t texture_size, uint32_t border_size, const void* level0,
+                     const float atlas_uv[2], float out[4]);
 size_t orc_generate_mipmaps(uint32_t format, uint32_t texture_size, uint32_t mip_level_count,
                             const void* level0, void* out);
 

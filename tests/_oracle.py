@@ -118,6 +118,8 @@ def lib():
     L.orc_tc_decode.restype = C.c_long
     L.orc_split_pixel.argtypes = [u32, u32, u32, Coord, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, u32,
                                   u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]
+    L.orc_sample_tile.argtypes = [u32, u32, u32, vp, vp, vp]
+    L.orc_sample_tile.restype = None
     L.orc_generate_mipmaps.argtypes = [u32, u32, u32, vp, vp]
     L.orc_generate_mipmaps.restype = sz
     L.orc_refine.argtypes = [C.POINTER(View), C.POINTER(Coord), u32, C.POINTER(u32), C.POINTER(u32)]
@@ -251,6 +253,14 @@ def tc_decode(data: bytes):
     out = (Coord * max(n, 1))()
     lib().orc_tc_decode(buf, len(data), out, n)
     return [out[i].tuple() for i in range(n)]
+
+
+def sample_tile(fmt, border_size, level0: np.ndarray, atlas_uv):
+    level0 = np.ascontiguousarray(level0)
+    uv = np.asarray(atlas_uv, dtype=np.float32)
+    out = np.zeros(4, dtype=np.float32)
+    lib().orc_sample_tile(fmt, level0.shape[0], border_size, _np_ptr(level0), _np_ptr(uv), _np_ptr(out))
+    return out
 
 
 def generate_mipmaps(fmt, level0: np.ndarray, mip_level_count: int):

@@ -327,3 +327,26 @@ def test_degenerate_inputs(device):
         a, _ = K.product_planar(device, one, 2, 16, 2, O.FORMAT_R16, generic=generic)
         assert K.assert_atlas_equal(a, K.oracle_planar(one, 2, 16, 2, O.FORMAT_R16)) == 5
         assert int(a.download_tile(0, 0)[8, 8]) == 12345
+
+
+@pytest.mark.parametrize("fmt", [O.FORMAT_R16, O.FORMAT_RGBA8])
+def test_atlas_sample_matches_the_cpu_sampling(device, fmt):
+    """SURVEY §8f row 4, the atlas half: TileAtlas::sample_attachment as a batched query on the tiles in HBM ==
+    the reference's CPU sampling (oracle restatement) bit for bit, INVALID lookups give zero."""
+    T, b = 32, 2
+    src = K.random_raster(fmt, 200, 200, seed=41)
+    atlas, _ = K.product_planar(device, src, 3, T, b, fmt)
+    rng = np.random.default_rng(9)
+    n = 2000
+    idx = rng.integers(0, 21, size=n).astype(np.uint32)
+    uv = rng.random((n, 2), dtype=np.float32)
+    uv[:8] = [[0, 0], [1, 1], [0, 1], [1, 0], [0.5, 0.5], [1e-7, 0.999999], [0.25, 0.75], [0.999, 0.001]]
+    idx[-1] = 0xFFFFFFFF
+    ours = atlas.sample(0, idx, uv)
+    tiles = atlas.download_tiles(0, 0, 21)
+    for i in range(n - 1):
+        exp = O.sample_tile(fmt, b, tiles[idx[i]], uv[i])
+        assert np.array_equal(ours[i], exp), (i, idx[i], uv[i], ours[i], exp)
+    assert np.array_equal(ours[-1], np.zeros(4, np.float32))
+    if fmt == O.FORMAT_R16:  # sample_height = lerp(min_height, max_height, value.x): heights stay inside the texel range
+        assert ours[:-1, 0].min() >= tiles.min() / 65535.0 - 1e-6 and ours[:-1, 0].max() <= tiles.max() / 65535.0 + 1e-6

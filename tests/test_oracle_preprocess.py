@@ -163,3 +163,22 @@ def test_markstein_unorm_division_is_exact_on_cpu():
     e = (np.float64(t) - np.float64(q0) * 65535.0).astype(np.float32)  # exact: the true fma result is representable
     q = (np.float64(q0) + np.float64(e) * np.float64(r)).astype(np.float32)
     assert np.array_equal(q, (t / np.float32(65535.0)).astype(np.float32))
+
+
+def test_sample_tile_known_answers():
+    """AtlasAttachment::sample + AttachmentData::sample (tile_atlas.rs:249-258, mod.rs:220-263): hand-computed cases."""
+    T, b = 8, 1
+    tile = np.zeros((T, T), dtype=np.uint16)
+    tile[:, :] = (np.arange(T)[None, :] * 8191).astype(np.uint16)  # a ramp in x: texel x holds x * 8191 (65528 at x = 8)
+    # uv = atlas_uv * (6/8) + 1/8; pixel = uv * 8 - 0.5.  atlas_uv.x = 0.5 -> uv 0.5 -> pixel 3.5: half-way texels 3 and 4
+    s = O.sample_tile(O.FORMAT_R16, b, tile, (0.5, 0.5))
+    a, c = np.float32(3 * 8191) / np.float32(65535), np.float32(4 * 8191) / np.float32(65535)
+    assert s[0] == np.float32(a + (c - a) * np.float32(0.5)) and s[1] == s[2] == s[3] == 0
+    # atlas_uv = 0 -> pixel 0.5: half-way between the apron texel 0 and the first centre texel 1
+    s = O.sample_tile(O.FORMAT_R16, b, tile, (0.0, 0.25))
+    assert s[0] == np.float32(np.float32(8191) / np.float32(65535) * np.float32(0.5))
+    # RGBA8: constant colour comes back exactly, all four channels
+    rgba = np.zeros((T, T, 4), dtype=np.uint8)
+    rgba[...] = (255, 128, 1, 77)
+    s = O.sample_tile(O.FORMAT_RGBA8, b, rgba, (0.3, 0.9))
+    assert np.array_equal(s, (np.array([255, 128, 1, 77], dtype=np.float32) / np.float32(255)).astype(np.float32))
