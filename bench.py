@@ -240,6 +240,16 @@ def main():
             line["verify_vs_oracle"] = verify_against(atlas, oracle, shape)
     if world > 1:
         dist.barrier()  # the other ranks wait for rank 0's oracle run before tearing the group down
+    if rank == 0 and world == 1:
+        # the other half of the hot path, for the record: the per-frame tiling prepass on scripted camera paths
+        # (latency-bound, one launch per frame; not part of `value`)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import refine_bench
+
+            line["config"]["tiling_prepass"] = refine_bench.measure(device)
+        except Exception as e:  # never lose the headline line over the side measurement
+            line["config"]["tiling_prepass"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

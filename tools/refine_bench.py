@@ -15,8 +15,7 @@ import numpy as np
 import bevy_terrain_amd as bt
 
 
-def main():
-    device = bt.Device(0)
+def measure(device):
     out = {}
     for name, model, positions in (
         ("planar_side1000", bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 250.0),
@@ -42,7 +41,11 @@ def main():
         out[name] = {"frames": len(views), "us_per_frame_avg": 1e3 * float(np.mean(ms)), "us_per_frame_max": 1e3 * float(np.max(ms)),
                      "final_tiles_avg": float(np.mean(counts)), "final_tiles_max": int(np.max(counts)),
                      "launches_per_frame": 1, "reference_dispatches_per_frame": 2 * cfg.refinement_count + 3}
-    print(json.dumps({"tiling_prepass": out}))
+    return out
+
+
+def main():
+    print(json.dumps({"tiling_prepass": measure(bt.Device(0))}))
 
 
 if __name__ == "__main__":
