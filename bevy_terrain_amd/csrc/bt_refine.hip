@@ -124,30 +124,23 @@ __global__ __launch_bounds__(kThreads) void tiling_prepass_kernel(bt_view_state 
                                                                   bt_tile_coordinate* __restrict__ final_tiles,
                                                                   bt_indirect* __restrict__ indirect,
                                                                   uint32_t* __restrict__ counters) {
-    __shared__ uint32_t s_divide[kWaves], s_final[kWaves];
-    __shared__ int s_child_index, s_final_index, s_counter;  // Parameters, types.wgsl:43-48
-    __shared__ uint32_t s_tile_count, s_overflow, s_visited;
+    // The pass state (Parameters, types.wgsl:43-48) is uniform and kept in registers by every thread; only the
+    // per-wave counts of a sweep go through LDS (double-buffered by sweep parity: ONE barrier per sweep).
+    __shared__ uint32_t s_divide[2][kWaves], s_final[2][kWaves];
 
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const int N = int(capacity);
 
     // prepare_root (prepare_prepass.wgsl:4-23)
-    if (tid == 0) {
-        s_counter = -1;
-        s_child_index = N - 1;
-        s_final_index = 0;
-        s_tile_count = view.spherical ? 6u : 1u;
-        s_overflow = 0;
-        s_visited = 0;
-    }
-    if (tid < (view.spherical ? 6u : 1u)) temporary_tiles[tid] = {tid, 0u, 0u, 0u};
+    int counter = -1, child_index = N - 1, final_index = 0;
+    uint32_t tile_count = view.spherical ? 6u : 1u, visited = 0, sweep = 0;
+    bool overflow = false;
+    if (tid < tile_count) temporary_tiles[tid] = {tid, 0u, 0u, 0u};
     __syncthreads();
 
     for (uint32_t pass = 0; pass <= view.refinement_count; pass++) {
-        const uint32_t tile_count = s_tile_count;
-        const int counter = s_counter;
         // refine_tiles (refine_tiles.wgsl:33-44), 1024 invocation ids per sweep
-        for (uint32_t base = 0; base < tile_count; base += kThreads) {
+        for (uint32_t base = 0; base < tile_count; base += kThreads, sweep++) {
             const uint32_t id = base + tid;
             const bool active = id < tile_count;
             bt_tile_coordinate tile{};
@@ -160,21 +153,20 @@ __global__ __launch_bounds__(kThreads) void tiling_prepass_kernel(bt_view_state 
             const bool fin = active && !divide;
             const unsigned long long ballot_d = __ballot(divide), ballot_f = __ballot(fin);
             if (lane == 0) {
-                s_divide[wave] = uint32_t(__popcll(ballot_d));
-                s_final[wave] = uint32_t(__popcll(ballot_f));
+                s_divide[sweep & 1u][wave] = uint32_t(__popcll(ballot_d));
+                s_final[sweep & 1u][wave] = uint32_t(__popcll(ballot_f));
             }
             __syncthreads();
             uint32_t before_d = 0, before_f = 0, total_d = 0, total_f = 0;
 #pragma unroll
             for (uint32_t w = 0; w < kWaves; w++) {
-                const uint32_t d = s_divide[w], f = s_final[w];
+                const uint32_t d = s_divide[sweep & 1u][w], f = s_final[sweep & 1u][w];
                 before_d += w < wave ? d : 0u;
                 before_f += w < wave ? f : 0u;
                 total_d += d;
                 total_f += f;
             }
             const unsigned long long below = (1ull << lane) - 1ull;
-            const int child_index = s_child_index, final_index = s_final_index;
             if (divide) {  // subdivide (:24-31): 4 children at consecutive child_index() values
                 const int rank = int(before_d + uint32_t(__popcll(ballot_d & below)));
 #pragma unroll
@@ -188,39 +180,34 @@ __global__ __launch_bounds__(kThreads) void tiling_prepass_kernel(bt_view_state 
                 const int fi = final_index + int(before_f + uint32_t(__popcll(ballot_f & below)));
                 if (fi < N) final_tiles[fi] = tile;
             }
-            __syncthreads();
-            if (tid == 0) {
-                s_child_index = child_index + counter * 4 * int(total_d);
-                s_final_index = final_index + int(total_f);
-                s_visited += min(kThreads, tile_count - base);
-                // children may not run into the parents still to be read, nor finals past the buffer
-                const int children_so_far = counter > 0 ? s_child_index : (N - 1 - s_child_index);
-                if (children_so_far + int(tile_count) > N || s_final_index > N) s_overflow = 1;
-            }
-            __syncthreads();
-            if (s_overflow) break;  // uniform: the buffers are too small, stop before indices run wild
+            child_index += counter * 4 * int(total_d);
+            final_index += int(total_f);
+            visited += min(kThreads, tile_count - base);
+            // children may not run into the parents still to be read, nor finals past the buffer
+            const int children_so_far = counter > 0 ? child_index : (N - 1 - child_index);
+            if (children_so_far + int(tile_count) > N || final_index > N) overflow = true;
+            if (overflow) break;  // uniform: the buffers are too small, stop before indices run wild
         }
-        if (s_overflow || pass == view.refinement_count) break;
+        if (overflow || pass == view.refinement_count) break;
         // prepare_next (prepare_prepass.wgsl:25-36)
-        if (tid == 0) {
-            if (s_counter == 1) {
-                s_tile_count = uint32_t(s_child_index);
-                s_child_index = N - 1;
-            } else {
-                s_tile_count = uint32_t(N - 1 - s_child_index);
-                s_child_index = 0;
-            }
-            s_counter = -s_counter;
+        if (counter == 1) {
+            tile_count = uint32_t(child_index);
+            child_index = N - 1;
+        } else {
+            tile_count = uint32_t(N - 1 - child_index);
+            child_index = 0;
         }
-        __syncthreads();  // also orders this pass's child stores before the next pass's parent loads
+        counter = -counter;
+        if (tile_count == 0) break;  // nothing left to refine: the remaining passes of the reference are no-ops
+        __syncthreads();  // orders this pass's child stores before the next pass's parent loads
     }
 
     // prepare_render (prepare_prepass.wgsl:38-44)
     if (tid == 0) {
-        *indirect = {view.vertices_per_tile * uint32_t(s_final_index), 1u, 0u, 0u};
-        counters[0] = uint32_t(s_final_index);
-        counters[1] = s_overflow;
-        counters[2] = s_visited;
+        *indirect = {view.vertices_per_tile * uint32_t(final_index), 1u, 0u, 0u};
+        counters[0] = uint32_t(final_index);
+        counters[1] = overflow ? 1u : 0u;
+        counters[2] = visited;
         counters[3] = view.refinement_count + 1;
     }
 }
