@@ -121,6 +121,9 @@ __device__ __forceinline__ uint32_t split_texel(const RasterDev& r, const Axis& 
 // grid.x = tasks * ceil(T / kRows); 256 threads sweep kRows rows of one tile, one 32-bit entry per step
 // (the reference's thread = one u32 entry, preprocessing.wgsl:59-90)
 constexpr uint32_t kRows = 8;
+// downsample: every texel costs a chain of dependent loads (task -> child texels), so its workgroups take fewer rows —
+// more of them in flight instead of 16 serial round trips per thread
+// (only for small launches: with many tiles the 8-row workgroups stream better)
 
 template <uint32_t FORMAT>
 __global__ __launch_bounds__(256) void split_kernel(AttachmentMeta m, void* __restrict__ atlas,
@@ -216,11 +219,11 @@ __device__ __forceinline__ uint32_t downsample_texel(const typename Texel<FORMAT
 
 template <uint32_t FORMAT>
 __global__ __launch_bounds__(256) void downsample_kernel(AttachmentMeta m, void* __restrict__ atlas,
-                                                         const TaskDev* __restrict__ tasks, uint32_t row_blocks) {
+                                                         const TaskDev* __restrict__ tasks, uint32_t row_blocks, uint32_t rows_per_block) {
     using T = typename Texel<FORMAT>::type;
     constexpr uint32_t kPer = Texel<FORMAT>::kPerEntry;
     const uint32_t task_index = blockIdx.x / row_blocks;
-    const uint32_t row0 = (blockIdx.x % row_blocks) * kRows;
+    const uint32_t row0 = (blockIdx.x % row_blocks) * rows_per_block;
     const TaskDev task = tasks[task_index];
     const uint32_t Tsz = m.texture_size, b = m.border_size, c = m.center_size;
     const uint32_t entries_per_row = Tsz / kPer;
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256) void downsample_kernel(AttachmentMeta m, void*
     T* base = (T*)atlas;
     T* tile = base + uint64_t(task.atlas_index) * Tsz * Tsz;
 
-    const uint32_t rows = min(kRows, Tsz - row0);
+    const uint32_t rows = min(rows_per_block, Tsz - row0);
     for (uint32_t e = threadIdx.x; e < entries_per_row * rows; e += blockDim.x) {
         const uint32_t py = row0 + e / entries_per_row;
         const uint32_t ex = e % entries_per_row;
@@ -522,11 +525,12 @@ bt_status launch_split(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const 
 
 bt_status launch_downsample(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const TaskDev* tasks, uint32_t n) {
     if (!n) return BT_OK;
-    const uint32_t row_blocks = (m.texture_size + kRows - 1) / kRows;
+    const uint32_t rows_per_block = n <= 4 ? 1u : (n <= 16 ? 2u : kRows);
+    const uint32_t row_blocks = (m.texture_size + rows_per_block - 1) / rows_per_block;
     if (m.format == BT_FORMAT_R16)
-        downsample_kernel<BT_FORMAT_R16><<<n * row_blocks, 256, 0, ctx->stream>>>(m, atlas, tasks, row_blocks);
+        downsample_kernel<BT_FORMAT_R16><<<n * row_blocks, 256, 0, ctx->stream>>>(m, atlas, tasks, row_blocks, rows_per_block);
     else
-        downsample_kernel<BT_FORMAT_RGBA8><<<n * row_blocks, 256, 0, ctx->stream>>>(m, atlas, tasks, row_blocks);
+        downsample_kernel<BT_FORMAT_RGBA8><<<n * row_blocks, 256, 0, ctx->stream>>>(m, atlas, tasks, row_blocks, rows_per_block);
     return check_launch("downsample_kernel");
 }
 
