@@ -350,3 +350,14 @@ def test_atlas_sample_matches_the_cpu_sampling(device, fmt):
     assert np.array_equal(ours[-1], np.zeros(4, np.float32))
     if fmt == O.FORMAT_R16:  # sample_height = lerp(min_height, max_height, value.x): heights stay inside the texel range
         assert ours[:-1, 0].min() >= tiles.min() / 65535.0 - 1e-6 and ours[:-1, 0].max() <= tiles.max() / 65535.0 + 1e-6
+
+
+@pytest.mark.parametrize("lod_count,T,W", [(1, 64, 100), (2, 64, 150), (8, 16, 1600)])
+def test_fused_path_shallow_and_deep_pyramids(device, lod_count, T, W):
+    # one LOD (no pyramid at all), two (no tail launch: the apron rows of the parent come from the rows-only stitch),
+    # eight (fused_main + two tail launches, 21845 tiles)
+    src = K.random_raster(O.FORMAT_R16, W, W + 7, seed=lod_count, holes=0.001)
+    n = sum(4 ** l for l in range(lod_count))
+    atlas, pre = K.product_planar(device, src, lod_count, T, 2, O.FORMAT_R16, atlas_size=n + 3)
+    assert pre.stats()["fused_jobs"] == 1
+    assert K.assert_atlas_equal(atlas, K.oracle_planar(src, lod_count, T, 2, O.FORMAT_R16, atlas_size=n + 3)) == n
