@@ -33,6 +33,14 @@ namespace bt {
 namespace {
 
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+
+// Ablation switches of the profiling build (tools/, -DBT_DEBUG_HOOKS): compiled out of the product library, where
+// the branches they guard fold away and no environment variable is read.
+#ifdef BT_DEBUG_HOOKS
+#define BT_ABLATE(A, bits) ((A).ablate & (bits))
+#else
+#define BT_ABLATE(A, bits) 0u
+#endif
 constexpr uint32_t kMainRows = 8;                // centre rows per fused_main workgroup (multiple of 4)
 constexpr uint32_t kMaxBorder = 8;
 
@@ -443,7 +451,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     uint16_t* tile3 = A.atlas + uint64_t(self3 == kInvalid ? 0u : self3) * tile_texels;
     const uint32_t cx4 = (it.x & 1u) * half_c + tid, cy4_base = (it.y & 1u) * half_c;
     const uint32_t cx3 = (it.x & 3u) * (c / 4) + (tid >> 1), cy3_base = (it.y & 3u) * (c / 4);
-    const bool do4 = A.levels >= 2 && !(A.ablate & 1u), do3 = A.levels >= 3 && !(A.ablate & 1u);
+    const bool do4 = A.levels >= 2 && !BT_ABLATE(A, 1u), do3 = A.levels >= 3 && !BT_ABLATE(A, 1u);
     // Left / right apron columns of the parent (shift 1) and grand-parent (shift 2) tile: a centre column within b of
     // the tile's x edge is also the x neighbour's apron column (stitch.wgsl:79-88); with that neighbour absent the
     // own apron repeats the edge column (stitch.wgsl:105-118) and the edge column's thread writes all b of them.
@@ -483,7 +491,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     bool nodata = !kStaged;
     u32x4 pre[kBatch];
     window(k_begin, ymin, slots);
-    if (kStaged && !(A.ablate & 8u)) {
+    if (kStaged && !BT_ABLATE(A, 8u)) {
         if (wide) {
             stage_issue(ymin, slots, pre);
             nodata = stage_commit(s_buf + (k_begin & 1u) * buf_texels, slots, pre);
@@ -514,7 +522,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         const bool more = k + 1 < k_end;
         if (more) {
             window(k + 1, next_ymin, next_slots);
-            if (kStaged && wide && !(A.ablate & 8u)) stage_issue(next_ymin, next_slots, pre);
+            if (kStaged && wide && !BT_ABLATE(A, 8u)) stage_issue(next_ymin, next_slots, pre);
         }
 
         auto fetch_row = [&](int y) -> Texel4 {
@@ -554,35 +562,43 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             }
         }
 
-        if ((A.ablate & 768u) && !is_idle) {  // (ablation 256 / 512, with 16: the chunk's finest / parent stores without any arithmetic — the memory skeleton)
+        if (BT_ABLATE(A, 768u) && !is_idle) {  // (ablation 256 / 512, with 16: the chunk's finest / parent stores without any arithmetic — the memory skeleton)
             uint32_t* dst5 = tile5_u32 + (((b + cr0) * T + px0) >> 1);
-            if (A.ablate & 256u) {
+            if (BT_ABLATE(A, 256u)) {
 #pragma unroll
                 for (uint32_t i = 0; i < kMainRows; i++) dst5[i * (T / 2)] = tid + i;
             }
-            if (is_centre && do4 && (A.ablate & 512u)) {
+            if (is_centre && do4 && BT_ABLATE(A, 512u)) {
                 uint16_t* dst = tile4 + (b + cy4_base + (cr0 >> 1)) * T + b + cx4;
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++) dst[j * T] = uint16_t(tid);
             }
         }
-        if (!(A.ablate & 16u) && !skip_chunk) {
+        if (!BT_ABLATE(A, 16u) && !skip_chunk) {
             if constexpr (kStaged && !kGeneric) {
                 typedef float f2 __attribute__((ext_vector_type(2)));
                 const f2 gx = {gxa, gxb}, fx = {fxa, fxb};
-                const f2 kr = {1.0f / 65535.0f, 1.0f / 65535.0f}, kn = {65535.0f, 65535.0f}, khalf = {0.5f, 0.5f};
-                const f2 kzero = {0.0f, 0.0f}, kquarter = {0.25f, 0.25f};
-                auto conv2 = [&](uint32_t ta, uint32_t tb) -> f2 {  // (ta, tb) / 65535, correctly rounded (see header)
+                // The fast loop works on texel values scaled by 2^16: F(t) = 65536 * RN(t / 65535).  Every later
+                // operation (weighted sums, x 0.25) is homogeneous in the texel values and a power-of-two scale commutes
+                // with IEEE rounding (no overflow / underflow here: values in [1, 65536], weights in [0, 1]), so every
+                // intermediate is exactly 65536 x the oracle's, and 65535 * v == (65535 / 65536) * V as real numbers with
+                // 65535 / 65536 exactly representable: the quantised results are bit-identical.  What it buys: F(t) is ONE
+                // operation, fma(x, r, x) with x = float(t), r = RN(1 / 65535) — a single rounding of x + x * r, equal
+                // to 65536 * RN(t / 65535) for all 65536 inputs (checked on the device by bt_selftest and exactly, in
+                // rational arithmetic, by tests/test_oracle_preprocess.py) — instead of the three of the unscaled division.
+                const f2 kr = {1.0f / 65535.0f, 1.0f / 65535.0f}, kn = {65535.0f / 65536.0f, 65535.0f / 65536.0f}, khalf = {0.5f, 0.5f};
+                const f2 kzero = {0.0f, 0.0f}, knq = {0.25f * (65535.0f / 65536.0f), 0.25f * (65535.0f / 65536.0f)};
+                auto conv2 = [&](uint32_t ta, uint32_t tb) -> f2 {  // (F(ta), F(tb))
                     const f2 x = {float(ta), float(tb)};
-                    const f2 q0 = x * kr;
-                    const f2 e = __builtin_elementwise_fma(-q0, kn, x);
-                    return __builtin_elementwise_fma(e, kr, q0);
+                    return __builtin_elementwise_fma(x, kr, x);
                 };
-                // 0.5 + 65535 * clamp(v, 0, 1); the u32 conversion then floors.  In this loop every input lies in
-                // (0, 1] and the weights in [0, 1], so v is in (0, 1 + a few ulp]: the clamp can only act on an excess
-                // of ~1e-7, and floor(0.5 + 65535 * (1 + 1e-7)) = 65535 = floor(0.5 + 65535 * 1) — it is a no-op on the
-                // result and is left out (tests: saturated rasters, all-65535 blocks).
+                // 0.5 + 65535 * clamp(v, 0, 1) with v = V / 65536; the u32 conversion then floors.  In this loop every
+                // input lies in (0, 1] and the weights in [0, 1], so v is in (0, 1 + a few ulp]: the clamp can only act on an
+                // excess of ~1e-7, and floor(0.5 + 65535 * (1 + 1e-7)) = 65535 = floor(0.5 + 65535 * 1) — it is a no-op on
+                // the result and is left out (tests: saturated rasters, all-65535 blocks).
                 auto quantise = [&](f2 v) -> f2 { return khalf + kn * v; };
+                // the same for a sum of four: (s * 0.25) is exact, so RN((s * 0.25) * k) == RN(s * (0.25 * k))
+                auto quantise_quarter = [&](f2 s) -> f2 { return khalf + knq * s; };
                 const uint32_t cy4_first = cy4_base + (cr0 >> 1), cy3_first = cy3_base + (cr0 >> 2);
                 if (kMainRows == 8 && __builtin_amdgcn_readfirstlane(int(S.win_slots[k - k_begin])) < 0) {
                     // ---- static fast path: the 8 rows use 9 consecutive source rows: straight-line code, row offsets
@@ -622,14 +638,14 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             ua[i] = uint32_t(w.x);
                             ub[i] = uint32_t(w.y);
                         }
-                        if (!is_idle && !(A.ablate & 2u)) {
+                        if (!is_idle && !BT_ABLATE(A, 2u)) {
 #pragma unroll
                             for (uint32_t i = 0; i < 4; i++) dst5[(4 * quad + i) * (T / 2)] = ua[i] | (ub[i] << 16);
                         }
                         if (do4) {
                             // two level-1 pixels (row pairs 0-1, 2-3 of the quad), one per packed lane: ((a0 + a1) + b0) + b1, / 4
                             const f2 sum = ((conv2(ua[0], ua[2]) + conv2(ua[1], ua[3])) + conv2(ub[0], ub[2])) + conv2(ub[1], ub[3]);
-                            const f2 wq = quantise(sum * kquarter);
+                            const f2 wq = quantise_quarter(sum);
                             q[2 * quad] = uint32_t(wq.x);
                             q[2 * quad + 1] = uint32_t(wq.y);
                         }
@@ -643,13 +659,13 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
 #pragma unroll
                             for (uint32_t j = 0; j < 4; j++)
                                 both[j] = q[j] | (uint32_t(__builtin_amdgcn_update_dpp(0, int(q[j]), 0xB1, 0xf, 0xf, true)) << 16);
-                            if (is_centre && (tid & 1u) == 0 && !(A.ablate & 4u)) {
+                            if (is_centre && (tid & 1u) == 0 && !BT_ABLATE(A, 4u)) {
                                 uint32_t* dst = reinterpret_cast<uint32_t*>(tile4 + (b + cy4_first) * T + b + cx4);
 #pragma unroll
                                 for (uint32_t j = 0; j < 4; j++) dst[j * (T / 2)] = both[j];
                             }
                         }
-                        if (x4_count && !(A.ablate & 4u)) {  // a few lanes of a tile; one texel each unless the x neighbour is absent
+                        if (x4_count && !BT_ABLATE(A, 4u)) {  // a few lanes of a tile; one texel each unless the x neighbour is absent
                             uint16_t* t = A.atlas + x4_off + cy4_first * T;
 #pragma unroll
                             for (uint32_t j = 0; j < 4; j++) t[j * T] = uint16_t(q[j]);
@@ -672,10 +688,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             const float recv1 = swap_pair(even ? colsum.y : c02.x), recv2 = swap_pair(c13.x);
                             const float sa = even ? colsum.x : recv1, sb = even ? recv1 : c02.y, sc = even ? recv2 : c13.y;
                             const float s3 = (sa + sb) + sc;
-                            const uint32_t w3 = uint32_t(0.5f + 65535.0f * (s3 * 0.25f));  // clamp is a no-op here, see quantise
+                            const uint32_t w3 = uint32_t(0.5f + (0.25f * (65535.0f / 65536.0f)) * s3);  // scaled domain, see quantise_quarter; the clamp is a no-op here
                             const uint32_t row3 = (b + cy3_first + (even ? 0u : 1u)) * T;
-                            if (is_centre && !(A.ablate & 64u)) tile3[row3 + b + cx3] = uint16_t(w3);
-                            if (x3_count && !(A.ablate & 64u)) {
+                            if (is_centre && !BT_ABLATE(A, 64u)) tile3[row3 + b + cx3] = uint16_t(w3);
+                            if (x3_count && !BT_ABLATE(A, 64u)) {
                                 uint16_t* t = A.atlas + x3_off + (cy3_first + (even ? 0u : 1u)) * T;
                                 t[0] = uint16_t(w3);
                                 if (x3_count > 1)
@@ -708,14 +724,14 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         ub[i] = uint32_t(w.y);
                     }
                     const uint32_t py = b + cr0 + q;
-                    if (!is_idle && !(A.ablate & 2u)) {
+                    if (!is_idle && !BT_ABLATE(A, 2u)) {
 #pragma unroll
                         for (uint32_t i = 0; i < 4; i++) tile5_u32[((py + i) * T + px0) >> 1] = ua[i] | (ub[i] << 16);
                     }
                     if (do4) {
                         // two level-1 pixels (row pairs 0-1 and 2-3) in the two packed lanes: ((a0 + a1) + b0) + b1, then / 4
                         const f2 s = ((conv2(ua[0], ua[2]) + conv2(ua[1], ua[3])) + conv2(ub[0], ub[2])) + conv2(ub[1], ub[3]);
-                        const f2 wq = quantise(s * kquarter);
+                        const f2 wq = quantise_quarter(s);
                         const uint32_t q0 = uint32_t(wq.x), q1 = uint32_t(wq.y);
                         const uint32_t cy = cr0 + q, cy4 = cy4_base + (cy >> 1);
                         if (is_centre) {
@@ -732,7 +748,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             if (is_centre && (tid & 1u) == 0) {
                                 const f2 mine = conv2(q0, q1), theirs = conv2(other0, other1);
                                 const float s3 = ((mine.x + mine.y) + theirs.x) + theirs.y;
-                                const uint32_t w3 = float_to_unorm16(s3 * 0.25f);
+                                const uint32_t w3 = uint32_t(0.5f + (0.25f * (65535.0f / 65536.0f)) * s3);  // scaled domain (conv2)
                                 const uint32_t cy3 = cy3_base + (cy >> 2);
                                 tile3[(b + cy3) * T + b + cx3] = uint16_t(w3);
                                 if (x3_count) xpush3(cy3, uint16_t(w3));
@@ -810,7 +826,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         // chunk k + 1 goes into the other staging buffer (nobody reads it any more: its last readers passed the
         // previous barrier), the row table of chunk k + 3 replaces the one of chunk k after the barrier
         nodata = !kStaged;
-        if (kStaged && !(A.ablate & 8u)) {
+        if (kStaged && !BT_ABLATE(A, 8u)) {
             uint16_t* s_next = s_buf + ((k + 1) & 1u) * buf_texels;
             nodata = wide ? stage_commit(s_next, next_slots, pre) : stage_narrow(s_next, next_ymin, next_slots);
         }
@@ -824,7 +840,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
 template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_main_kernel(FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t work = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t work = BT_ABLATE(A, 1024u) ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);  // (1024: dispatch order, no XCD remap)
     const uint32_t chunks_per_tile = (A.m.center_size + kMainRows - 1) / kMainRows;
     const uint32_t part = work % A.groups;
     const uint32_t k_begin = part * chunks_per_tile / A.groups, k_end = (part + 1) * chunks_per_tile / A.groups;
@@ -994,6 +1010,9 @@ __global__ void selftest_kernel(uint32_t* failures) {
     if (t < 65536u) {
         volatile float d = 65535.0f;
         if (unorm16_to_float(t) != float(t) / d) atomicAdd(failures, 1u);
+        // the fast loop's scaled conversion: fma(x, r, x) == 65536 * RN(t / 65535)
+        const float x = float(t);
+        if (__builtin_fmaf(x, 1.0f / 65535.0f, x) != 65536.0f * (x / d)) atomicAdd(failures, 1u);
     }
     if (t < 256u) {  // the 8-bit conversion of the batched kernels (same construction)
         volatile float d = 255.0f;
@@ -1147,7 +1166,9 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         // Workgroup order = tile rows (y outer, x inner) instead of the queue's x-major order: an XCD then streams whole
         // source rows (its 128 concurrent workgroups cover 4 tile rows x all columns), and x neighbours run on the same XCD
         // at the same time, so the apron bytes one pushes into the other's parent rows merge in one L2.  16k job: 333 -> 285 us.
+#ifdef BT_DEBUG_HOOKS
         if (!getenv("BT_FUSED_XMAJOR"))
+#endif
             std::stable_sort(items.begin(), items.end(), [](const MainItem& a, const MainItem& b2) {
                 return a.side != b2.side ? a.side < b2.side : (a.y != b2.y ? a.y < b2.y : a.x < b2.x);
             });
@@ -1155,7 +1176,9 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
 
         FusedArgs args{};
         args.m = m;
+#ifdef BT_DEBUG_HOOKS
         if (const char* e = getenv("BT_FUSED_ABLATE")) args.ablate = uint32_t(atoi(e));
+#endif
         args.atlas = (uint16_t*)at.level0;
         args.rasters = p->rasters_dev;  // (re)allocated by bt_preprocessor_run before the first launch
         args.tlx = splits[0]->tl[0];
@@ -1198,7 +1221,9 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         const uint32_t nlods = lod_hi - lod_lo + 1;
         const uint32_t main_levels = std::min(3u, nlods);
         FusedJobDev main_job{args, ai};
+#ifdef BT_DEBUG_HOOKS
         if (const char* e = getenv("BT_FUSED_LDS_PAD")) main_job.lds_pad = uint32_t(atoi(e));
+#endif
         main_job.args.lod = lod_hi;
         main_job.args.levels = main_levels;
         main_job.args.item_count = uint32_t(items.size());
@@ -1207,8 +1232,11 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             // 4 workgroups of 4 waves per CU (128 VGPRs each) = 1024 resident: pick the number of parts per tile so
             // that the grid is a whole number of 1024-workgroup rounds where possible
             uint32_t parts = 1;
+#ifdef BT_DEBUG_HOOKS
             if (const char* e = getenv("BT_FUSED_PARTS")) parts = uint32_t(atoi(e));
-            else {
+            else
+#endif
+            {
                 while (parts < chunks && uint64_t(items.size()) * parts < 1024) parts++;
                 for (uint32_t cand = parts; cand <= std::min(chunks, parts + 8); cand++)
                     if ((uint64_t(items.size()) * cand) % 1024 == 0) { parts = cand; break; }

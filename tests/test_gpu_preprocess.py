@@ -361,3 +361,51 @@ def test_fused_path_shallow_and_deep_pyramids(device, lod_count, T, W):
     atlas, pre = K.product_planar(device, src, lod_count, T, 2, O.FORMAT_R16, atlas_size=n + 3)
     assert pre.stats()["fused_jobs"] == 1
     assert K.assert_atlas_equal(atlas, K.oracle_planar(src, lod_count, T, 2, O.FORMAT_R16, atlas_size=n + 3)) == n
+
+
+def _nodata_mask_16k(seed=43):
+    """the 16k variant with a 5 % zero "no-data" mask (seed 43).  5 % of the 37 x 53 texel cells of the
+    raster are zeroed (odd cell sizes, so the holes meet every staging-load lane, chunk and tile edge) plus one
+    isolated no-data texel per 2^14 texels."""
+    rng = np.random.default_rng(seed)
+    cells = rng.random((16384 // 37 + 1, 16384 // 53 + 1)) < 0.05
+    mask = np.repeat(np.repeat(cells, 37, axis=0), 53, axis=1)[:16384, :16384]
+    single = rng.integers(0, 16384, size=(16384, 2))
+    mask[single[:, 0], single[:, 1]] = True
+    return mask
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_config3_16k_single_gpu_all_tiles(device, masked):
+    """BASELINE config 3 at N = 1, the workload bench.py times: 16384^2 fBm (seed 42), T = 512, b = 2, lod_count 6 ->
+    1365 tiles through the fused plan (1024 workgroups, fused_main / fused_todo / fused_tail), every tile byte-compared
+    with the oracle; the masked variant (seed 43, 5 % no-data) drives fused_todo at full size."""
+    size, lods = 16384, 6
+    ptr = device.synth_fbm_r16(size, size, 42)
+    src = device.download(ptr, (size, size), np.uint16)
+    if masked:
+        hole = _nodata_mask_16k()
+        assert 0.04 < hole.mean() < 0.06
+        src[hole] = 0
+        device.free(ptr)
+        ptr = device.upload(src)
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=2048, path="terrains/bench16k",
+                           model=bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=512, border_size=2, format=bt.AttachmentFormat.R16))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer().insert("synthetic/fbm16k", (ptr, size, size))
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_tile(
+        bt.PreprocessDataset(attachment_index=0, path="synthetic/fbm16k", lod_range=range(0, lods)), server, atlas)
+    pre.run(atlas, keep_queue=True)
+    pre.run(atlas)  # a second run of the same queue (the todo lists alternate between runs) must give the same atlas
+    device.free(ptr)
+    st = pre.stats()
+    assert st["fused_jobs"] == 1 and st["tiles"] == 1365 and st["algorithmic_bytes"] == 1252524032
+    oracle = O.OracleAtlas(lods, 2048, False, [(512, 2, 1, O.FORMAT_R16)])
+    oracle.clear_attachment(0).preprocess_tile(0, src, (0, lods)).run(os.cpu_count() or 8)
+    assert [((c.side, c.lod, c.x, c.y), i) for c, i in atlas.tiles()] == oracle.tiles()
+    for first in range(0, 1365, 128):
+        count = min(128, 1365 - first)
+        data = atlas.download_tiles(0, first, count)
+        for k in range(count):
+            assert np.array_equal(data[k], oracle.tile(0, first + k)), (first + k, oracle.tiles()[first + k])

@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""bench.py against the profiling build of the library (tools/libbevy_terrain_amd_dbg.so, `make -C
+bevy_terrain_amd/csrc debug`), whose fused kernels honour the BT_FUSED_* ablation variables.  Results of ablated
+runs are NOT valid tiles; this exists only for tools/ablate_sweep.sh."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bevy_terrain_amd import _ffi
+
+_ffi.LIB_PATH = os.path.join(ROOT, "tools", "libbevy_terrain_amd_dbg.so")
+import bench
+
+bench.main()
