@@ -11,10 +11,12 @@ from .terrain import (AttachmentConfig, AttachmentFormat, TerrainConfig, Terrain
 from .tile_atlas import Device, TileAtlas, generate_mipmaps, tc_decode, tc_encode
 from .preprocess import AssetServer, PreprocessDataset, Preprocessor, SphericalDataset
 from .tiling_prepass import TilingPrepass, make_view_state
+from .tile_tree import TileTree, sample_attachment, sample_height, view_state_from_config
 
 __all__ = [
     "AttachmentConfig", "AttachmentFormat", "TerrainConfig", "TerrainModel", "TerrainViewConfig", "TileCoordinate",
     "Device", "TileAtlas", "generate_mipmaps", "tc_decode", "tc_encode",
     "AssetServer", "PreprocessDataset", "Preprocessor", "SphericalDataset",
     "TilingPrepass", "make_view_state",
+    "TileTree", "sample_attachment", "sample_height", "view_state_from_config",
 ]

@@ -89,6 +89,23 @@ class IndirectC(C.Structure):
                 ("base_instance", C.c_uint32)]
 
 
+class TileTreeEntryC(C.Structure):
+    _fields_ = [("atlas_index", C.c_uint32), ("atlas_lod", C.c_uint32)]
+
+
+class TerrainModelC(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("_padding", C.c_uint32), ("position", C.c_double * 3), ("a", C.c_double),
+                ("b", C.c_double), ("min_height", C.c_float), ("max_height", C.c_float)]
+
+
+class TerrainViewConfigC(C.Structure):
+    _fields_ = [("tree_size", C.c_uint32), ("geometry_tile_count", C.c_uint32), ("refinement_count", C.c_uint32),
+                ("grid_size", C.c_uint32), ("subdivision_tolerance", C.c_double),
+                ("precision_threshold_distance", C.c_double), ("load_distance", C.c_double),
+                ("morph_distance", C.c_double), ("blend_distance", C.c_double), ("morph_range", C.c_float),
+                ("blend_range", C.c_float), ("origin_lod", C.c_uint32), ("_padding", C.c_uint32)]
+
+
 _vp, _u32, _u64, _i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
 _P = C.POINTER
 
@@ -115,6 +132,11 @@ PROTOTYPES = {
     "bt_atlas_destroy": (None, [_vp]),
     "bt_atlas_get_tile": (_i32, [_vp, TileCoordinateC, _P(AtlasTileC)]),
     "bt_atlas_get_or_allocate_tile": (_i32, [_vp, TileCoordinateC, _P(AtlasTileC)]),
+    "bt_atlas_request_tile": (_i32, [_vp, TileCoordinateC]),
+    "bt_atlas_release_tile": (_i32, [_vp, TileCoordinateC]),
+    "bt_atlas_get_best_tile": (_i32, [_vp, TileCoordinateC, _P(TileTreeEntryC)]),
+    "bt_atlas_update": (_i32, [_vp, C.c_char_p, _u32, _P(_u32), _P(_u32)]),
+    "bt_atlas_pending_loads": (_u32, [_vp]),
     "bt_atlas_tiles": (_u32, [_vp, _P(TileCoordinateC), _P(_u32), _u32]),
     "bt_atlas_attachment_storage": (_i32, [_vp, _u32, _P(_vp), _P(_u64), _P(_u32)]),
     "bt_atlas_download_tiles": (_i32, [_vp, _u32, _u32, _u32, _vp, _u64]),
@@ -146,6 +168,19 @@ PROTOTYPES = {
     "bt_tiling_prepass_run": (_i32, [_vp, _P(ViewStateC)]),
     "bt_tiling_prepass_buffers": (_i32, [_vp, _P(_vp), _P(_vp)]),
     "bt_tiling_prepass_read": (_i32, [_vp, _P(TileCoordinateC), _u32, _P(_u32), _P(IndirectC)]),
+    "bt_terrain_view_config_default": (None, [_P(TerrainViewConfigC)]),
+    "bt_view_state_from_config": (_i32, [_P(TerrainModelC), _P(TerrainViewConfigC), _P(C.c_double), C.c_float, _P(ViewStateC)]),
+    "bt_tile_tree_create": (_i32, [_vp, _P(TerrainModelC), _u32, _P(TerrainViewConfigC), _P(_vp)]),
+    "bt_tile_tree_destroy": (None, [_vp]),
+    "bt_tile_tree_update": (_i32, [_vp, _P(C.c_double)]),
+    "bt_tile_tree_requests": (_i32, [_vp, _P(_P(TileCoordinateC)), _P(_u32), _P(_P(TileCoordinateC)), _P(_u32)]),
+    "bt_tile_tree_apply_requests": (_i32, [_vp, _vp]),
+    "bt_tile_tree_adjust_to_tile_atlas": (_i32, [_vp, _vp]),
+    "bt_tile_tree_buffers": (_i32, [_vp, _P(_vp), _P(_vp)]),
+    "bt_tile_tree_read": (_i32, [_vp, _P(TileTreeEntryC), _u32, _P(_u32), _u32, _P(TileCoordinateC), _P(_u32)]),
+    "bt_tile_tree_sample_attachment": (_i32, [_vp, _vp, _u32, _P(C.c_double), _u32, _P(C.c_float), _P(C.c_float)]),
+    "bt_tile_tree_approximate_height": (_i32, [_vp, _vp, _P(C.c_float)]),
+    "bt_tile_tree_view_state": (_i32, [_vp, _P(ViewStateC)]),
     "bt_selftest": (_i32, [_vp, _P(_u32)]),
     "bt_synth_fbm_r16": (_i32, [_vp, _vp, _u32, _u32, _u64, _u32, _u32, _u32, _u32, _u32]),
 }
@@ -171,7 +206,7 @@ def lib():
         fn = getattr(L, name)  # AttributeError = ABI mismatch, also loud
         fn.restype = restype
         fn.argtypes = argtypes
-    if L.bt_abi_version() != 1:
+    if L.bt_abi_version() != 2:
         raise ImportError("libbevy_terrain_amd.so ABI version mismatch")
     _lib = L
     return L

@@ -1112,12 +1112,13 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         auto cell = [&](const bt_tile_coordinate& c) -> uint32_t& {
             return grids[grid_offsets[c.side * 32 + c.lod] + (size_t(c.x) << c.lod) + c.y];
         };
+        auto in_face = [](const bt_tile_coordinate& c) { return c.x < (1u << c.lod) && c.y < (1u << c.lod); };
         for (const Task* t : splits) {
-            if (t->coord.side >= sides || t->coord.lod != lod_hi) return false;
+            if (t->coord.side >= sides || t->coord.lod != lod_hi || !in_face(t->coord)) return false;
             cell(t->coord) = t->atlas_index;
         }
         for (const Task* t : downs) {
-            if (t->coord.side >= sides) return false;
+            if (t->coord.side >= sides || t->coord.lod < lod_lo || t->coord.lod > lod_hi || !in_face(t->coord)) return false;
             cell(t->coord) = t->atlas_index;
         }
         // completeness: every downsample tile has its four children in the grids
@@ -1131,6 +1132,21 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         size_t present = 0;
         for (uint32_t v : grids) present += v != kInvalid;
         if (present != stitches.size()) return false;
+        // The fused kernels take a tile's apron from the job's own grid; the queue recorded the neighbours the ATLAS holds
+        // (stitch_and_save_layer -> get_tile).  They differ when tiles of an earlier job or dataset border this one: then
+        // only the generic path stitches across that seam, so the job does not qualify.
+        for (const Task* t : stitches) {
+            if (t->coord.side >= sides || t->coord.lod < lod_lo || t->coord.lod > lod_hi || !in_face(t->coord)) return false;
+            if (cell(t->coord) != t->atlas_index) return false;
+            bt_tile_coordinate nb[8];
+            tile_neighbours(t->coord, false, nb);  // same-face neighbours (cube seams are re-stitched by the generic kernel)
+            for (int i = 0; i < 8; i++) {
+                const bool same_face = !is_invalid(nb[i]);
+                const uint32_t in_grid = same_face ? cell(nb[i]) : kInvalid;
+                const bool recorded_same_face = t->rel[i].atlas_index != BT_INVALID_ATLAS_INDEX && t->rel[i].coordinate.side == t->coord.side && same_face;
+                if (same_face && in_grid != (recorded_same_face ? t->rel[i].atlas_index : kInvalid)) return false;
+            }
+        }
         // all split tasks share the dataset rectangle
         for (const Task* t : splits)
             if (t->tl[0] != splits[0]->tl[0] || t->tl[1] != splits[0]->tl[1] || t->br[0] != splits[0]->br[0] || t->br[1] != splits[0]->br[1])

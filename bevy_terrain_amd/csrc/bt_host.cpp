@@ -12,6 +12,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <tuple>
 
 #include "bt_internal.hpp"
 
@@ -280,7 +284,8 @@ bt_status bt_atlas_create(bt_ctx* ctx, const bt_terrain_config* config, bt_atlas
     bt_atlas* a = new bt_atlas();
     a->ctx = ctx;
     a->config = *config;
-    for (uint32_t i = 0; i < config->atlas_size; i++) a->unused_tiles.push_back(i);
+    for (uint32_t i = 0; i < config->atlas_size; i++)  // tile_atlas.rs:307-309
+        a->unused_tiles.push_back({{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, i, {0, 0, 0}});
     for (uint32_t i = 0; i < config->attachment_count; i++) {
         const bt_attachment_config& c = config->attachments[i];
         Attachment at;
@@ -319,44 +324,113 @@ void bt_atlas_destroy(bt_atlas* a) {
     delete a;
 }
 
-// tile_atlas.rs:369-381
+// tile_atlas.rs:369-381.  (A tile that load_tile_config marked as existing but that was never requested has no
+// TileState: the reference's `.unwrap()` panics there; here it reads as INVALID.)
 bt_status bt_atlas_get_tile(bt_atlas* a, bt_tile_coordinate c, bt_atlas_tile* out) {
     if (!a || !out) return BT_ERR_INVALID_ARGUMENT;
     *out = {c, BT_INVALID_ATLAS_INDEX, {0, 0, 0}};
     if (is_invalid(c)) return BT_OK;
+    if (!a->existing_tiles.count(c)) return BT_OK;
     auto it = a->tile_states.find(c);
-    if (it != a->tile_states.end() && it->second.existing) out->atlas_index = it->second.atlas_index;
+    if (it != a->tile_states.end()) out->atlas_index = it->second.atlas_index;
     return BT_OK;
 }
 
-// tile_atlas.rs:383-416
+// allocate_tile (tile_atlas.rs:383-389): the oldest unused slot; whatever tile was cached in it is forgotten
+static bt_status allocate_tile(bt_atlas* a, uint32_t* atlas_index) {
+    if (a->unused_tiles.empty()) {
+        set_error("Atlas out of indices (atlas_size %u)", a->config.atlas_size);
+        return BT_ERR_ATLAS_OUT_OF_INDICES;
+    }
+    const bt_atlas_tile unused = a->unused_tiles.front();
+    a->unused_tiles.pop_front();
+    a->tile_states.erase(unused.coordinate);
+    a->state_version++;
+    *atlas_index = unused.atlas_index;
+    return BT_OK;
+}
+
+// tile_atlas.rs:391-416
 bt_status bt_atlas_get_or_allocate_tile(bt_atlas* a, bt_tile_coordinate c, bt_atlas_tile* out) {
     if (!a || !out) return BT_ERR_INVALID_ARGUMENT;
     *out = {c, BT_INVALID_ATLAS_INDEX, {0, 0, 0}};
     if (is_invalid(c)) return BT_OK;
     auto it = a->tile_states.find(c);
-    if (it == a->tile_states.end()) it = a->tile_states.emplace(c, TileState{BT_INVALID_ATLAS_INDEX, true}).first;
-    if (it->second.atlas_index == BT_INVALID_ATLAS_INDEX) {
-        if (a->unused_tiles.empty()) {
-            set_error("Atlas out of indices (atlas_size %u)", a->config.atlas_size);
-            return BT_ERR_ATLAS_OUT_OF_INDICES;
-        }
-        it->second.atlas_index = a->unused_tiles.front();
-        a->unused_tiles.pop_front();
-        a->allocated = std::max(a->allocated, it->second.atlas_index + 1);
+    if (it == a->tile_states.end()) {
+        uint32_t index;
+        if (bt_status s = allocate_tile(a, &index)) return s;
+        it = a->tile_states.emplace(c, TileState{index, 1, 0}).first;
     }
-    it->second.existing = true;
+    a->existing_tiles.insert(c);
     out->atlas_index = it->second.atlas_index;
+    return BT_OK;
+}
+
+// tile_atlas.rs:418-457
+bt_status bt_atlas_request_tile(bt_atlas* a, bt_tile_coordinate c) {
+    if (!a) return BT_ERR_INVALID_ARGUMENT;
+    if (!a->existing_tiles.count(c)) return BT_OK;
+    auto it = a->tile_states.find(c);
+    if (it != a->tile_states.end()) {
+        if (it->second.requests == 0) {  // the tile is used again: take its slot out of the LRU
+            const uint32_t index = it->second.atlas_index;
+            a->unused_tiles.erase(std::remove_if(a->unused_tiles.begin(), a->unused_tiles.end(),
+                                                 [index](const bt_atlas_tile& t) { return t.atlas_index == index; }),
+                                  a->unused_tiles.end());
+        }
+        it->second.requests++;
+        return BT_OK;
+    }
+    uint32_t index;
+    if (bt_status s = allocate_tile(a, &index)) return s;
+    const uint32_t attachments = uint32_t(a->attachments.size());
+    a->tile_states.emplace(c, TileState{index, 1, attachments});
+    a->state_version++;
+    for (uint32_t ai = 0; ai < attachments; ai++) a->to_load.push_back({c, index, ai});
+    if (attachments == 0) a->tile_states[c].loading = 0;  // (Loading(0) never completes upstream; nothing to load here)
+    return BT_OK;
+}
+
+// tile_atlas.rs:459-476
+bt_status bt_atlas_release_tile(bt_atlas* a, bt_tile_coordinate c) {
+    if (!a) return BT_ERR_INVALID_ARGUMENT;
+    if (!a->existing_tiles.count(c)) return BT_OK;
+    auto it = a->tile_states.find(c);
+    if (it == a->tile_states.end() || it->second.requests == 0) {
+        set_error("Tried releasing a tile, which is not present.");  // the reference panics (:467)
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    if (--it->second.requests == 0) a->unused_tiles.push_back({c, it->second.atlas_index, {0, 0, 0}});
+    return BT_OK;
+}
+
+// tile_atlas.rs:478-503
+bt_status bt_atlas_get_best_tile(const bt_atlas* a, bt_tile_coordinate c, bt_tile_tree_entry* out) {
+    if (!a || !out) return BT_ERR_INVALID_ARGUMENT;
+    *out = {BT_INVALID_ATLAS_INDEX, BT_INVALID_LOD};
+    while (!is_invalid(c) && c.lod != BT_INVALID_LOD) {
+        auto it = a->tile_states.find(c);
+        if (it != a->tile_states.end() && it->second.loading == 0) {
+            *out = {it->second.atlas_index, c.lod};
+            return BT_OK;
+        }
+        c = bt_tile_parent(c);  // lod 0 -> lod - 1 wraps to INVALID_LOD, like the reference's u32 arithmetic
+    }
     return BT_OK;
 }
 
 uint32_t bt_atlas_tiles(const bt_atlas* a, bt_tile_coordinate* coords, uint32_t* idx, uint32_t cap) {
     if (!a) return 0;
     std::vector<std::pair<uint32_t, bt_tile_coordinate>> v;
-    v.reserve(a->tile_states.size());
-    for (const auto& kv : a->tile_states)
-        if (kv.second.existing) v.push_back({kv.second.atlas_index, kv.first});
-    std::sort(v.begin(), v.end(), [](const auto& l, const auto& r) { return l.first < r.first; });
+    v.reserve(a->existing_tiles.size());
+    for (const bt_tile_coordinate& c : a->existing_tiles) {
+        auto it = a->tile_states.find(c);
+        v.push_back({it != a->tile_states.end() ? it->second.atlas_index : BT_INVALID_ATLAS_INDEX, c});
+    }
+    std::sort(v.begin(), v.end(), [](const auto& l, const auto& r) {
+        if (l.first != r.first) return l.first < r.first;
+        return std::tie(l.second.side, l.second.lod, l.second.x, l.second.y) < std::tie(r.second.side, r.second.lod, r.second.x, r.second.y);
+    });
     for (uint32_t i = 0; i < v.size() && i < cap; i++) {
         if (coords) coords[i] = v[i].second;
         if (idx) idx[i] = v[i].first;
@@ -394,40 +468,171 @@ bt_status bt_atlas_upload_tile(bt_atlas* a, uint32_t ai, uint32_t layer, const v
     return BT_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// fs::write for a batch of files on a few threads (the reference spawns one AsyncComputeTaskPool task per tile,
+// tile_atlas.rs:77-116): jobs are (path, bytes) pairs; a chunk's pinned buffer is reused once its jobs are done.
+class FileWriters {
+  public:
+    struct Job {
+        std::string path;
+        const uint8_t* data;
+        size_t bytes;
+        uint32_t buffer;
+    };
+    FileWriters(uint32_t threads, uint32_t buffers) : pending_(buffers, 0) {
+        for (uint32_t i = 0; i < threads; i++) workers_.emplace_back([this] { run(); });
+    }
+    ~FileWriters() {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread& t : workers_) t.join();
+    }
+    void push(std::vector<Job>&& jobs) {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            for (Job& j : jobs) {
+                pending_[j.buffer]++;
+                queue_.push_back(std::move(j));
+            }
+        }
+        cv_.notify_all();
+    }
+    void wait_buffer(uint32_t buffer) {
+        std::unique_lock<std::mutex> lock(m_);
+        done_.wait(lock, [&] { return pending_[buffer] == 0; });
+    }
+    bt_status status() {
+        std::lock_guard<std::mutex> lock(m_);
+        if (failed_) set_error("%s", error_.c_str());
+        return failed_ ? BT_ERR_IO : BT_OK;
+    }
+
+  private:
+    void run() {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                cv_.wait(lock, [&] { return stop_ || !queue_.empty(); });
+                if (queue_.empty()) return;
+                j = std::move(queue_.front());
+                queue_.pop_front();
+            }
+            bool ok = false;
+            std::string why;
+            if (FILE* f = fopen(j.path.c_str(), "wb")) {
+                ok = fwrite(j.data, 1, j.bytes, f) == j.bytes;
+                ok = (fclose(f) == 0) && ok;
+                if (!ok) why = "short write to " + j.path;
+            } else {
+                why = "cannot open " + j.path + ": " + strerror(errno);
+            }
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                if (!ok && !failed_) {
+                    failed_ = true;
+                    error_ = why;
+                }
+                pending_[j.buffer]--;
+            }
+            done_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::deque<Job> queue_;
+    std::vector<uint32_t> pending_;
+    std::vector<std::thread> workers_;
+    bool stop_ = false, failed_ = false;
+    std::string error_;
+};
+
+// Download + write the given tiles of one attachment: D2H through three pinned buffers on the context's stream
+// (runs of consecutive layers are one copy), files written by the writer threads while the next chunk downloads.
+bt_status save_tiles(bt_atlas* a, uint32_t ai, const char* directory, std::vector<std::pair<uint32_t, bt_tile_coordinate>> tiles) {
+    const Attachment& at = a->attachments[ai];
+    if (bt_status s = make_dirs(directory)) return s;
+    std::sort(tiles.begin(), tiles.end(), [](const auto& l, const auto& r) { return l.first < r.first; });
+    tiles.erase(std::unique(tiles.begin(), tiles.end(), [](const auto& l, const auto& r) { return l.first == r.first && operator_eq(l.second, r.second); }),
+                tiles.end());
+    if (tiles.empty()) return BT_OK;
+    BT_HIP(hipSetDevice(a->ctx->device));
+    constexpr uint32_t kBuffers = 3;
+    const uint32_t chunk = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (32ull << 20) / at.tile_bytes)));
+    void* pinned[kBuffers] = {};
+    hipEvent_t copied[kBuffers] = {};
+    bt_status rc = BT_OK;
+    for (uint32_t k = 0; k < kBuffers && rc == BT_OK; k++) {
+        hipError_t e = hipHostMalloc(&pinned[k], at.tile_bytes * chunk, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&copied[k], hipEventDisableTiming);
+        if (e != hipSuccess) rc = hip_fail(e, "save buffers");
+    }
+    if (rc == BT_OK) {
+        const uint32_t threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        FileWriters writers(threads, kBuffers);
+        const size_t n = tiles.size(), chunks = (n + chunk - 1) / chunk;
+        auto hand_over = [&](size_t c) -> bt_status {  // chunk c has been enqueued: wait for its copies, queue its files
+            const uint32_t k = uint32_t(c % kBuffers);
+            hipError_t e = hipEventSynchronize(copied[k]);
+            if (e != hipSuccess) return hip_fail(e, "tile download");
+            std::vector<FileWriters::Job> jobs;
+            for (size_t i = c * chunk; i < std::min(n, (c + 1) * chunk); i++) {
+                char name[64];
+                bt_tile_name(tiles[i].second, name, sizeof name);
+                jobs.push_back({std::string(directory) + "/" + name + ".bin", (const uint8_t*)pinned[k] + at.tile_bytes * (i - c * chunk),
+                                size_t(at.tile_bytes), k});
+            }
+            writers.push(std::move(jobs));
+            return BT_OK;
+        };
+        for (size_t c = 0; c < chunks && rc == BT_OK; c++) {
+            const uint32_t k = uint32_t(c % kBuffers);
+            writers.wait_buffer(k);
+            const size_t lo = c * chunk, hi = std::min(n, lo + chunk);
+            for (size_t i = lo; i < hi && rc == BT_OK;) {
+                size_t run = 1;
+                while (i + run < hi && tiles[i + run].first == tiles[i].first + run) run++;
+                hipError_t e = hipMemcpyAsync((uint8_t*)pinned[k] + at.tile_bytes * (i - lo), (const uint8_t*)at.level0 + at.tile_bytes * tiles[i].first,
+                                              at.tile_bytes * run, hipMemcpyDeviceToHost, a->ctx->stream);
+                if (e != hipSuccess) rc = hip_fail(e, "tile download");
+                i += run;
+            }
+            if (rc == BT_OK) {
+                hipError_t e = hipEventRecord(copied[k], a->ctx->stream);
+                if (e != hipSuccess) rc = hip_fail(e, "tile download");
+            }
+            if (rc == BT_OK && c > 0) rc = hand_over(c - 1);
+        }
+        if (rc == BT_OK) rc = hand_over(chunks - 1);
+        for (uint32_t k = 0; k < kBuffers; k++) writers.wait_buffer(k);
+        if (rc == BT_OK) rc = writers.status();
+    }
+    for (uint32_t k = 0; k < kBuffers; k++) {
+        if (copied[k]) hipEventDestroy(copied[k]);
+        if (pinned[k]) hipHostFree(pinned[k]);
+    }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+// every existing tile that holds a slot (a tile known only from load_tile_config has no data to write)
 bt_status bt_atlas_save_attachment(bt_atlas* a, uint32_t ai, const char* directory) {
     if (!a || ai >= a->attachments.size() || !directory) return BT_ERR_INVALID_ARGUMENT;
-    const Attachment& at = a->attachments[ai];
-    const uint32_t n = bt_atlas_tiles(a, nullptr, nullptr, 0);
-    std::vector<bt_tile_coordinate> coords(n);
-    std::vector<uint32_t> idx(n);
-    bt_atlas_tiles(a, coords.data(), idx.data(), n);
-    if (bt_status s = make_dirs(directory)) return s;
-    // stream the tiles out in chunks through one pinned buffer: D2H at PCIe rate, then fs::write
-    const uint32_t chunk = 64;
-    void* pinned = nullptr;
-    BT_HIP(hipHostMalloc(&pinned, at.tile_bytes * chunk, hipHostMallocDefault));
-    bt_status rc = BT_OK;
-    uint32_t i = 0;
-    while (i < n && rc == BT_OK) {
-        // consecutive atlas indices download as one copy
-        uint32_t run = 1;
-        while (i + run < n && run < chunk && idx[i + run] == idx[i] + run) run++;
-        hipError_t e = hipMemcpyAsync(pinned, (const uint8_t*)at.level0 + at.tile_bytes * idx[i], at.tile_bytes * run,
-                                      hipMemcpyDeviceToHost, a->ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(a->ctx->stream);
-        if (e != hipSuccess) {
-            rc = hip_fail(e, "tile download");
-            break;
-        }
-        for (uint32_t k = 0; k < run && rc == BT_OK; k++) {
-            char name[64];
-            bt_tile_name(coords[i + k], name, sizeof name);
-            rc = write_file(std::string(directory) + "/" + name + ".bin", (const uint8_t*)pinned + at.tile_bytes * k, at.tile_bytes);
-        }
-        i += run;
+    std::vector<std::pair<uint32_t, bt_tile_coordinate>> tiles;
+    for (const bt_tile_coordinate& c : a->existing_tiles) {
+        auto it = a->tile_states.find(c);
+        if (it != a->tile_states.end() && it->second.atlas_index != BT_INVALID_ATLAS_INDEX) tiles.push_back({it->second.atlas_index, c});
     }
-    hipHostFree(pinned);
-    return rc;
+    return save_tiles(a, ai, directory, std::move(tiles));
 }
 
 uint64_t bt_tc_encode(const bt_tile_coordinate* tiles, uint32_t count, uint8_t* out, uint64_t cap) {
@@ -455,18 +660,13 @@ int64_t bt_tc_decode(const uint8_t* data, uint64_t bytes, bt_tile_coordinate* ti
 
 bt_status bt_atlas_save_tile_config(const bt_atlas* a, const char* file_path) {
     if (!a || !file_path) return BT_ERR_INVALID_ARGUMENT;
-    const uint32_t n = bt_atlas_tiles(a, nullptr, nullptr, 0);
-    std::vector<bt_tile_coordinate> coords(n);
-    bt_atlas_tiles(a, coords.data(), nullptr, n);
+    std::vector<bt_tile_coordinate> coords(a->existing_tiles.begin(), a->existing_tiles.end());
     // the reference writes HashSet iteration order (tile_atlas.rs:605-609); sorted here, compare as a set
     std::sort(coords.begin(), coords.end(), [](const bt_tile_coordinate& l, const bt_tile_coordinate& r) {
-        if (l.side != r.side) return l.side < r.side;
-        if (l.lod != r.lod) return l.lod < r.lod;
-        if (l.x != r.x) return l.x < r.x;
-        return l.y < r.y;
+        return std::tie(l.side, l.lod, l.x, l.y) < std::tie(r.side, r.lod, r.x, r.y);
     });
-    std::vector<uint8_t> buf(bt_tc_encode(coords.data(), n, nullptr, 0));
-    bt_tc_encode(coords.data(), n, buf.data(), buf.size());
+    std::vector<uint8_t> buf(bt_tc_encode(coords.data(), uint32_t(coords.size()), nullptr, 0));
+    bt_tc_encode(coords.data(), uint32_t(coords.size()), buf.data(), buf.size());
     return write_file(file_path, buf.data(), buf.size());
 }
 
@@ -489,12 +689,8 @@ bt_status bt_atlas_load_tile_config(bt_atlas* a, const char* file_path) {
     }
     std::vector<bt_tile_coordinate> coords(size_t(n) ? size_t(n) : 1);
     bt_tc_decode(buf.data(), buf.size(), coords.data(), uint32_t(n));
-    for (int64_t i = 0; i < n; i++) {
-        // existing_tiles only: a tile gets an atlas index when it is requested or preprocessed
-        auto it = a->tile_states.find(coords[i]);
-        if (it != a->tile_states.end()) it->second.existing = true;
-        else a->tile_states.emplace(coords[i], TileState{BT_INVALID_ATLAS_INDEX, true});
-    }
+    // existing_tiles only: a tile gets an atlas index when it is requested or preprocessed
+    for (int64_t i = 0; i < n; i++) a->existing_tiles.insert(coords[i]);
     return BT_OK;
 }
 
@@ -566,8 +762,7 @@ bt_status bt_atlas_load_tiles(bt_atlas* a, uint32_t ai, const char* directory, c
     Attachment& at = a->attachments[ai];
     std::vector<bt_tile_coordinate> all;
     if (!coords) {
-        for (const auto& kv : a->tile_states)
-            if (kv.second.existing) all.push_back(kv.first);
+        for (const bt_tile_coordinate& c : a->existing_tiles) all.push_back(c);
         std::sort(all.begin(), all.end(), [](const bt_tile_coordinate& x, const bt_tile_coordinate& y) {
             return std::tie(x.side, x.lod, x.x, x.y) < std::tie(y.side, y.lod, y.x, y.y);
         });
@@ -627,6 +822,89 @@ bt_status bt_atlas_load_tiles(bt_atlas* a, uint32_t ai, const char* directory, c
         i = j;
     }
     return BT_OK;
+}
+
+uint32_t bt_atlas_pending_loads(const bt_atlas* a) { return a ? uint32_t(a->to_load.size()) : 0u; }
+
+// TileAtlasState::update (tile_atlas.rs:327-345: start up to load_slots loads) + AtlasAttachment::update (:195-224:
+// finished loads -> loaded_tile_attachment, data into the atlas) + GpuAtlasAttachment::upload_tiles
+// (gpu_tile_atlas.rs:309-336), done synchronously for up to `max_loads` queued entries.
+bt_status bt_atlas_update(bt_atlas* a, const char* assets_root, uint32_t max_loads, uint32_t* loaded, uint32_t* failed) {
+    if (!a || !assets_root) return BT_ERR_INVALID_ARGUMENT;
+    if (loaded) *loaded = 0;
+    if (failed) *failed = 0;
+    if (a->to_load.empty()) return BT_OK;
+    BT_HIP(hipSetDevice(a->ctx->device));
+    uint64_t largest = 0;
+    for (const Attachment& at : a->attachments) largest = std::max(largest, at.tile_bytes);
+    const uint32_t chunk = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (32ull << 20) / std::max<uint64_t>(largest, 1))));
+    void* pinned = nullptr;
+    BT_HIP(hipHostMalloc(&pinned, largest * chunk, hipHostMallocDefault));
+    std::vector<std::vector<uint32_t>> mip_layers(a->attachments.size());
+    uint32_t budget = max_loads ? max_loads : 0xFFFFFFFFu, done = 0, bad = 0;
+    bt_status rc = BT_OK;
+    while (!a->to_load.empty() && budget && rc == BT_OK) {
+        std::vector<AtlasTileAttachment> batch;
+        while (!a->to_load.empty() && budget && batch.size() < chunk) {
+            batch.push_back(a->to_load.front());
+            a->to_load.pop_front();
+            budget--;
+        }
+        std::vector<bool> ok(batch.size(), false);
+        for (size_t k = 0; k < batch.size(); k++) {
+            const AtlasTileAttachment& t = batch[k];
+            const Attachment& at = a->attachments[t.attachment_index];
+            char name[64];
+            bt_tile_name(t.coordinate, name, sizeof name);
+            const std::string path = std::string(assets_root) + "/" + a->config.path + "/data/" + at.cfg.name + "/" + name + ".bin";
+            FILE* f = fopen(path.c_str(), "rb");
+            if (!f) continue;  // the reference returns the load slot and leaves the tile Loading (:202-204)
+            const size_t got = fread((uint8_t*)pinned + largest * k, 1, at.tile_bytes, f);
+            const bool longer = got == at.tile_bytes && fgetc(f) != EOF;
+            fclose(f);
+            ok[k] = got == at.tile_bytes && !longer;
+        }
+        for (size_t k = 0; k < batch.size() && rc == BT_OK; k++) {
+            if (!ok[k]) {
+                bad++;
+                continue;
+            }
+            const AtlasTileAttachment& t = batch[k];
+            const Attachment& at = a->attachments[t.attachment_index];
+            hipError_t e = hipMemcpyAsync((uint8_t*)at.level0 + at.tile_bytes * t.atlas_index, (const uint8_t*)pinned + largest * k, at.tile_bytes,
+                                          hipMemcpyHostToDevice, a->ctx->stream);
+            if (e != hipSuccess) rc = hip_fail(e, "tile upload");
+        }
+        if (rc == BT_OK) {
+            hipError_t e = hipStreamSynchronize(a->ctx->stream);  // the pinned buffer is refilled next
+            if (e != hipSuccess) rc = hip_fail(e, "tile upload");
+        }
+        for (size_t k = 0; k < batch.size() && rc == BT_OK; k++) {
+            if (!ok[k]) continue;
+            const AtlasTileAttachment& t = batch[k];
+            // loaded_tile_attachment (:347-359); a slot that was reused for another tile meanwhile is ignored
+            auto it = a->tile_states.find(t.coordinate);
+            if (it == a->tile_states.end() || it->second.atlas_index != t.atlas_index || it->second.loading == 0) continue;
+            if (--it->second.loading == 0) a->state_version++;
+            mip_layers[t.attachment_index].push_back(t.atlas_index);
+            done++;
+        }
+    }
+    hipHostFree(pinned);
+    for (uint32_t ai = 0; ai < a->attachments.size() && rc == BT_OK; ai++) {
+        std::vector<uint32_t>& layers = mip_layers[ai];
+        if (layers.empty() || a->attachments[ai].mips.size() <= 1) continue;
+        std::sort(layers.begin(), layers.end());
+        for (size_t i = 0; i < layers.size() && rc == BT_OK;) {
+            size_t j = i + 1;
+            while (j < layers.size() && layers[j] <= layers[j - 1] + 1) j++;
+            rc = bt_atlas_generate_mipmaps(a, ai, layers[i], layers[j - 1] - layers[i] + 1);
+            i = j;
+        }
+    }
+    if (loaded) *loaded = done;
+    if (failed) *failed = bad;
+    return rc;
 }
 
 bt_status bt_atlas_sample(bt_atlas* a, uint32_t ai, const bt_tile_lookup* lookups, uint32_t count, float* out) {
@@ -692,7 +970,7 @@ void bt_preprocessor_destroy(bt_preprocessor* p) {
 
 bt_status bt_preprocessor_clear_attachment(bt_preprocessor* p, bt_atlas* a, uint32_t ai, const char* directory) {
     if (!p || !a || ai >= a->attachments.size()) return BT_ERR_INVALID_ARGUMENT;
-    for (auto& kv : a->tile_states) kv.second.existing = false;  // existing_tiles.clear() — for ALL attachments, like :292
+    a->existing_tiles.clear();  // for ALL attachments, like :292; the slots (tile_states) stay assigned
     if (directory) {
         // reset_directory (preprocessor.rs:18-22)
         unlink((std::string(directory) + "/../../config.tc").c_str());
@@ -710,11 +988,12 @@ struct TileRange {
     uint32_t lx, ly, ux, uy;
 };
 
-// PreprocessDataset::overlapping_tiles (preprocessor.rs:58-66): f32 maths, as_uvec2 truncation
+// PreprocessDataset::overlapping_tiles (preprocessor.rs:58-66): f32 maths; `as_uvec2` saturates (negative -> 0).
+// The range is clamped to the face (tiles x, y >= 2^lod do not exist; upstream a bottom_right > 1 would invent them).
 TileRange overlapping_tiles(const bt_preprocess_dataset& d, uint32_t lod) {
     const float n = float(1u << lod);
-    return {uint32_t(d.top_left[0] * n), uint32_t(d.top_left[1] * n), uint32_t(std::ceil(d.bottom_right[0] * n)),
-            uint32_t(std::ceil(d.bottom_right[1] * n))};
+    auto sat = [&](float v) -> uint32_t { return !(v > 0.0f) ? 0u : (v >= n ? uint32_t(1u << lod) : uint32_t(v)); };
+    return {sat(d.top_left[0] * n), sat(d.top_left[1] * n), sat(std::ceil(d.bottom_right[0] * n)), sat(std::ceil(d.bottom_right[1] * n))};
 }
 
 bt_status add_raster(bt_preprocessor* p, const bt_atlas* a, uint32_t ai, const bt_raster* src, int32_t* index) {
@@ -733,6 +1012,10 @@ bt_status add_raster(bt_preprocessor* p, const bt_atlas* a, uint32_t ai, const b
     }
     const uint32_t px = fmt == BT_FORMAT_R16 ? 2 : 4;
     const uint64_t pitch = src->row_pitch ? src->row_pitch : uint64_t(src->width) * px;
+    if (pitch < uint64_t(src->width) * px || pitch % px) {
+        set_error("row_pitch %llu: must hold %u texels of %u bytes and be a multiple of the texel size", (unsigned long long)pitch, src->width, px);
+        return BT_ERR_INVALID_ARGUMENT;
+    }
     Raster r;
     r.format = fmt;
     r.owned = false;
@@ -740,8 +1023,10 @@ bt_status add_raster(bt_preprocessor* p, const bt_atlas* a, uint32_t ai, const b
     if (!src->on_device) {
         void* dev = nullptr;
         BT_HIP(hipSetDevice(p->ctx->device));
+        // the caller's buffer ends with the last texel of the last row, not with a whole pitch
+        const uint64_t bytes = pitch * (src->height - 1) + uint64_t(src->width) * px;
         BT_HIP(hipMalloc(&dev, pitch * src->height));
-        hipError_t e = hipMemcpyAsync(dev, src->data, pitch * src->height, hipMemcpyHostToDevice, p->ctx->stream);
+        hipError_t e = hipMemcpyAsync(dev, src->data, bytes, hipMemcpyHostToDevice, p->ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
         if (e != hipSuccess) {
             hipFree(dev);
@@ -844,6 +1129,12 @@ bt_status check_dataset(const bt_atlas* a, uint32_t ai, uint32_t lod_begin, uint
         set_error("center_size %u must be even to downsample", m.center_size);
         return BT_ERR_UNSUPPORTED;
     }
+    if (m.center_size < m.border_size) {
+        // stitch.wgsl:79-88 then reads a neighbour's apron (q = p +- c lands outside its centre) while that apron is being
+        // written by the same pass: undefined upstream, refused here
+        set_error("center_size %u < border_size %u", m.center_size, m.border_size);
+        return BT_ERR_UNSUPPORTED;
+    }
     if ((uint64_t(m.texture_size) * m.pixel_size) % 4u) {
         set_error("texture row must be a whole number of 32-bit entries");
         return BT_ERR_UNSUPPORTED;
@@ -867,6 +1158,7 @@ bt_status bt_preprocessor_preprocess_tile(bt_preprocessor* p, bt_atlas* a, const
     if (bt_status s = add_raster(p, a, d->attachment_index, src, &raster)) return s;
     const uint32_t job = p->jobs++;
     p->compiled = false;
+    p->saves_recorded = false;
     if (bt_status s = split_and_downsample(p, a, *d, raster, job)) return s;
     push_barrier(p, job);
     for (uint32_t lod = d->lod_begin; lod < d->lod_end; lod++)
@@ -880,6 +1172,7 @@ bt_status bt_preprocessor_preprocess_spherical(bt_preprocessor* p, bt_atlas* a, 
     if (bt_status s = check_dataset(a, sd->attachment_index, sd->lod_begin, sd->lod_end)) return s;
     const uint32_t job = p->jobs++;
     p->compiled = false;
+    p->saves_recorded = false;
     bt_preprocess_dataset side[6];
     int32_t raster[6];
     for (uint32_t s = 0; s < 6; s++) {
@@ -906,16 +1199,19 @@ uint32_t bt_preprocessor_task_counts(const bt_preprocessor* p, uint32_t counts[5
 
 bt_status bt_preprocessor_save(bt_preprocessor* p, bt_atlas* a, const char* assets_root) {
     if (!p || !a || !assets_root) return BT_ERR_INVALID_ARGUMENT;
-    // which attachments have pending Save tasks
-    const bool* wanted = p->save_pending;
+    // exactly the tiles of the Save tasks that have run (select_ready_tasks -> tile_atlas.save, preprocessor.rs:378-380)
     const std::string terrain = std::string(assets_root) + "/" + a->config.path;
     for (uint32_t ai = 0; ai < a->attachments.size(); ai++) {
-        if (!wanted[ai]) continue;
+        std::vector<std::pair<uint32_t, bt_tile_coordinate>> tiles;
+        for (const AtlasTileAttachment& t : a->to_save)
+            if (t.attachment_index == ai && t.atlas_index != BT_INVALID_ATLAS_INDEX) tiles.push_back({t.atlas_index, t.coordinate});
+        if (tiles.empty()) continue;
         // AtlasAttachment::new: path = "assets/{path}/data/{name}" (tile_atlas.rs:175)
         const std::string dir = terrain + "/data/" + a->attachments[ai].cfg.name;
-        if (bt_status s = bt_atlas_save_attachment(a, ai, dir.c_str())) return s;
+        if (bt_status s = save_tiles(a, ai, dir.c_str(), std::move(tiles))) return s;
     }
-    memset(p->save_pending, 0, sizeof p->save_pending);
+    a->to_save.clear();
+    p->saves_recorded = false;
     if (bt_status s = make_dirs(terrain)) return s;
     return bt_atlas_save_tile_config(a, (terrain + "/config.tc").c_str());
 }

@@ -9,6 +9,7 @@
 #include <deque>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "bevy_terrain_amd.h"
@@ -84,9 +85,18 @@ struct Attachment {
     std::vector<void*> mips;          // level k (k>=1): atlas_size x (T>>k)^2 texels; lazily allocated
 };
 
+// TileState of the atlas (tile_atlas.rs:260-277): `loading` = 0 is LoadingState::Loaded, n > 0 is Loading(n).
 struct TileState {
     uint32_t atlas_index;
-    bool existing;
+    uint32_t requests;
+    uint32_t loading;
+};
+
+// AtlasTileAttachment (tile_atlas.rs:62-67)
+struct AtlasTileAttachment {
+    bt_tile_coordinate coordinate;
+    uint32_t atlas_index;
+    uint32_t attachment_index;
 };
 
 enum TaskType : uint32_t { kSplit = 0, kStitch = 1, kDownsample = 2, kSave = 3, kBarrier = 4 };
@@ -121,9 +131,14 @@ struct bt_atlas {
     bt_ctx* ctx = nullptr;
     bt_terrain_config config{};
     std::vector<bt::Attachment> attachments;
+    // TileAtlasState (tile_atlas.rs:279-298)
+    std::unordered_set<bt_tile_coordinate, bt::CoordHash, bt::CoordEq> existing_tiles;
     std::unordered_map<bt_tile_coordinate, bt::TileState, bt::CoordHash, bt::CoordEq> tile_states;
-    std::deque<uint32_t> unused_tiles;  // FIFO of atlas indices (tile_atlas.rs:307-309)
-    uint32_t allocated = 0;             // high-water mark of handed-out indices
+    std::deque<bt_atlas_tile> unused_tiles;        // LRU of free / released slots (:307-309, 459-476)
+    std::deque<bt::AtlasTileAttachment> to_load;   // queued by request_tile (:445-451), drained by bt_atlas_update
+    uint64_t state_version = 1;                    // bumped whenever tile_states changes (device copies are rebuilt lazily)
+    // the Save tasks of the preprocessor runs since the last bt_preprocessor_save (preprocessor.rs:378-380)
+    std::vector<bt::AtlasTileAttachment> to_save;
 };
 
 namespace bt {
@@ -164,13 +179,13 @@ void tile_neighbours(bt_tile_coordinate c, bool spherical, bt_tile_coordinate ou
 struct bt_preprocessor {
     bt_ctx* ctx = nullptr;
     std::vector<bt::Task> queue;
-    bool save_pending[BT_MAX_ATTACHMENTS] = {};
     std::vector<bt::Raster> rasters;
     uint32_t jobs = 0;
     uint32_t shard_rank = 0, shard_world = 1;
     std::vector<bt_shard_range> shard_ranges;
     // compiled plan (rebuilt when the queue changes)
     bool compiled = false;
+    bool saves_recorded = false;  // the kept queue's Save tasks are already in the atlas's to_save list
     uint32_t compiled_flags = 0;
     std::vector<bt::Launch> plan;
     bt::TaskDev* tasks_dev = nullptr;

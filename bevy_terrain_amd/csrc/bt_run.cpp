@@ -201,8 +201,11 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
     if (profile) p->profiled_runs++;
 
     // Save tasks: remembered until bt_preprocessor_save (the reference starts them as tasks drain)
-    for (const Task& t : p->queue)
-        if (t.type == kSave) p->save_pending[t.attachment_index] = true;
+    if (!p->saves_recorded) {  // (re-runs of a kept queue produce the same tiles: recorded once per queue and save)
+        for (const Task& t : p->queue)
+            if (t.type == kSave) a->to_save.push_back({t.coord, t.atlas_index, t.attachment_index});
+        p->saves_recorded = true;
+    }
     if (!(flags & BT_RUN_KEEP_QUEUE)) {
         BT_HIP(hipStreamSynchronize(p->ctx->stream));  // borrowed rasters may be released by the caller afterwards
         p->queue.clear();
@@ -211,6 +214,7 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
         p->rasters.clear();
         p->jobs = 0;
         p->compiled = false;
+        p->saves_recorded = false;
     }
     return BT_OK;
 }

@@ -116,6 +116,12 @@ class TerrainModel:
         m.radius = float(radius)
         return m
 
+    @staticmethod
+    def ellipsoid(position, major_axis: float, minor_axis: float, min_height: float, max_height: float) -> "TerrainModel":
+        m = TerrainModel("ellipsoidal", position, (major_axis, minor_axis, major_axis), min_height, max_height)
+        m.major_axis, m.minor_axis = float(major_axis), float(minor_axis)
+        return m
+
     def is_spherical(self) -> bool:
         return self.kind != "planar"
 
@@ -123,7 +129,9 @@ class TerrainModel:
         return 6 if self.is_spherical() else 1
 
     def scale(self) -> float:  # terrain_model.rs:183-193
-        return self.side_length / 2.0 if self.kind == "planar" else self.radius
+        if self.kind == "planar":
+            return self.side_length / 2.0
+        return self.radius if self.kind == "spherical" else (self.major_axis + self.minor_axis) / 2.0
 
     # identity rotation (the reference constructors use DQuat::IDENTITY)
     def position_local_to_world(self, local, height: float = 0.0):

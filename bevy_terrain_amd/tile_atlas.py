@@ -138,6 +138,27 @@ class TileAtlas:
         _ffi.lib().bt_atlas_tiles(self._h, coords, idx, n)
         return [(TileCoordinate._from_c(coords[i]), idx[i]) for i in range(n)]
 
+    # --- the streaming half of TileAtlasState (tile_atlas.rs:418-503)
+    def request_tile(self, c: TileCoordinate):
+        _ffi.check(_ffi.lib().bt_atlas_request_tile(self._h, c._c()))
+
+    def release_tile(self, c: TileCoordinate):
+        _ffi.check(_ffi.lib().bt_atlas_release_tile(self._h, c._c()))
+
+    def get_best_tile(self, c: TileCoordinate) -> Tuple[int, int]:
+        e = _ffi.TileTreeEntryC()
+        _ffi.check(_ffi.lib().bt_atlas_get_best_tile(self._h, c._c(), C.byref(e)))
+        return e.atlas_index, e.atlas_lod
+
+    def pending_loads(self) -> int:
+        return _ffi.lib().bt_atlas_pending_loads(self._h)
+
+    def update(self, assets_root: str = "assets", max_loads: int = 0) -> Tuple[int, int]:
+        """TileAtlasState::update + AtlasAttachment::update: run the queued tile loads; (loaded, failed)."""
+        loaded, failed = C.c_uint32(), C.c_uint32()
+        _ffi.check(_ffi.lib().bt_atlas_update(self._h, assets_root.encode(), max_loads, C.byref(loaded), C.byref(failed)))
+        return loaded.value, failed.value
+
     def attachment_storage(self, attachment_index: int) -> Tuple[int, int, int]:
         """(device pointer, bytes per tile, layers) of the attachment's level-0 atlas."""
         p, tb, layers = C.c_void_p(), C.c_uint64(), C.c_uint32()

@@ -55,36 +55,13 @@ def project_to_side(side: int, uv: Tuple[float, float], other: int, model: Terra
 
 def make_view_state(model: TerrainModel, view_config: TerrainViewConfig, view_world_position: Sequence[float], *,
                     approximate_height: Optional[float] = None) -> _ffi.ViewStateC:
-    """Everything `refine_tiles` reads for one view and frame."""
-    scale = model.scale()
-    v = _ffi.ViewStateC()
-    v.spherical = int(model.is_spherical())
-    v.geometry_tile_count = view_config.geometry_tile_count
-    v.refinement_count = view_config.refinement_count
-    v.vertices_per_tile = 2 * view_config.grid_size * (view_config.grid_size + 2)
-    # f64 product, then `as f32` (tile_tree.rs:148-150, terrain_view_bind_group.rs:111)
-    v.subdivision_distance = float(np.float32(view_config.morph_distance * scale * (1.0 + view_config.subdivision_tolerance)))
-    v.origin_lod = view_config.origin_lod
+    """Everything `refine_tiles` reads for one view and frame: derived by the library (bt_view_state_from_config,
+    f64 on the host like TileTree::new / TerrainViewConfigUniform::from_tile_tree /
+    TerrainModelApproximation::compute).  approximate_height defaults to TileTree::new's (min + max) / 2."""
+    from .tile_tree import view_state_from_config
+
     height = (model.min_height + model.max_height) / 2.0 if approximate_height is None else approximate_height
-    v.approximate_height = float(np.float32(height))
-    side, uv = coordinate_from_world_position(view_world_position, model)
-    origin_count = float(1 << view_config.origin_lod)
-    for s in range(6):
-        if s >= model.side_count():
-            continue
-        puv = project_to_side(side, uv, s, model)
-        sx, sy = puv[0] * origin_count, puv[1] * origin_count
-        v.sides[s].view_xy[0], v.sides[s].view_xy[1] = int(sx), int(sy)  # as_ivec2 truncates
-        v.sides[s].view_uv[0] = float(np.float32(sx - math.trunc(sx)))   # fract() for non-negative values
-        v.sides[s].view_uv[1] = float(np.float32(sy - math.trunc(sy)))
-    for i in range(3):
-        v.world_position[i] = float(np.float32(view_world_position[i]))
-    wfl, lfwt = model.mesh_matrices()
-    for i in range(12):
-        v.world_from_local[i] = wfl[i]
-    for i in range(9):
-        v.local_from_world_transpose[i] = lfwt[i]
-    return v
+    return view_state_from_config(model, view_config, view_world_position, float(np.float32(height)))
 
 
 class TilingPrepass:

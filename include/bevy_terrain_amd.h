@@ -15,7 +15,8 @@
  *
  * Conventions: opaque handles; POD structs with explicit layout; every function returns a
  * bt_status (0 = ok, < 0 = error) and never throws or aborts; bt_last_error() returns the text of
- * the last error of the calling thread; no callbacks; no global state besides that error string;
+ * the last error of the calling thread; no callbacks; no global state besides that error string
+ * (per-queue device buffers live in the bt_preprocessor that built them);
  * one bt_ctx per GPU and per host thread that drives it.  All file:line citations are relative to the reference checkout.
  */
 #ifndef BEVY_TERRAIN_AMD_H
@@ -28,7 +29,7 @@
 extern "C" {
 #endif
 
-#define BT_ABI_VERSION 1u
+#define BT_ABI_VERSION 2u
 
 typedef int32_t bt_status;
 enum {
@@ -148,6 +149,26 @@ void bt_atlas_destroy(bt_atlas* atlas);
 /* TileAtlas::get_tile / get_or_allocate_tile (:553-559, 369-416). */
 bt_status bt_atlas_get_tile(bt_atlas* atlas, bt_tile_coordinate c, bt_atlas_tile* out);
 bt_status bt_atlas_get_or_allocate_tile(bt_atlas* atlas, bt_tile_coordinate c, bt_atlas_tile* out);
+/* TileTreeEntry (terrain_data/tile_tree.rs:49-66) — 8 bytes, also the GPU layout (types.wgsl: TileTreeEntry). */
+typedef struct bt_tile_tree_entry {
+    uint32_t atlas_index; /* BT_INVALID_ATLAS_INDEX: nothing loaded */
+    uint32_t atlas_lod;   /* BT_INVALID_LOD */
+} bt_tile_tree_entry;
+/* The streaming side of TileAtlasState (tile_atlas.rs:418-503): request_tile (a tile not present gets the oldest
+ * unused slot and is queued for loading, one entry per attachment), release_tile (the last release puts the slot at
+ * the back of the LRU; its data stays cached until the slot is reused), get_best_tile (the tile itself or its closest
+ * loaded ancestor).  Releasing a tile that is not present is BT_ERR_INVALID_ARGUMENT (the reference panics). */
+bt_status bt_atlas_request_tile(bt_atlas* atlas, bt_tile_coordinate c);
+bt_status bt_atlas_release_tile(bt_atlas* atlas, bt_tile_coordinate c);
+bt_status bt_atlas_get_best_tile(const bt_atlas* atlas, bt_tile_coordinate c, bt_tile_tree_entry* out);
+/* TileAtlasState::update + AtlasAttachment::update (:327-345, 195-224), synchronously: starts and finishes up to
+ * `max_loads` queued tile loads (0 = all): "{assets_root}/{config.path}/data/{name}/{coord}.bin" -> the tile's atlas
+ * layer (+ its mip levels); a tile is Loaded once all its attachments are.  A missing / short file leaves the tile
+ * Loading forever, like the reference (:202-204); *loaded / *failed (optional) count this call's outcomes. */
+bt_status bt_atlas_update(bt_atlas* atlas, const char* assets_root, uint32_t max_loads, uint32_t* loaded, uint32_t* failed);
+/* number of queued loads (to_load.len()) */
+uint32_t bt_atlas_pending_loads(const bt_atlas* atlas);
+
 /* existing_tiles in atlas-index (= allocation) order. Returns the tile count; fills up to `cap`. */
 uint32_t bt_atlas_tiles(const bt_atlas* atlas, bt_tile_coordinate* coords, uint32_t* atlas_indices, uint32_t cap);
 /* Device storage of one attachment: layer `i` starts at ptr + i*tile_bytes; rows are T*pixel_size
@@ -306,6 +327,78 @@ bt_status bt_tiling_prepass_buffers(const bt_tiling_prepass* t, void** final_til
 /* Synchronises and copies the final tile list (in the reference's sequential append order). */
 bt_status bt_tiling_prepass_read(bt_tiling_prepass* t, bt_tile_coordinate* final_tiles_host, uint32_t cap,
                                  uint32_t* count, bt_indirect* indirect);
+
+/* -------------------------- TerrainModel / TerrainViewConfig / TileTree (the per-frame CPU side of the prepass) */
+enum { BT_MODEL_PLANAR = 0, BT_MODEL_SPHERICAL = 1, BT_MODEL_ELLIPSOIDAL = 2 };
+/* TerrainModel (math/terrain_model.rs:41-115): rotation is the identity, as in all three reference constructors.
+ * planar: a = side_length; sphere: a = radius; ellipsoid: a = major_axis, b = minor_axis (scale = (a, b, a)). */
+typedef struct bt_terrain_model {
+    uint32_t kind; /* BT_MODEL_* */
+    uint32_t _padding;
+    double position[3];
+    double a, b;
+    float min_height, max_height;
+} bt_terrain_model;
+/* TerrainViewConfig (terrain_view.rs:18-63), same fields and defaults. */
+typedef struct bt_terrain_view_config {
+    uint32_t tree_size;           /* 8 */
+    uint32_t geometry_tile_count; /* 1000000 */
+    uint32_t refinement_count;    /* 30 */
+    uint32_t grid_size;           /* 16 */
+    double subdivision_tolerance; /* 0.1 */
+    double precision_threshold_distance; /* 0.001 */
+    double load_distance;         /* 2.5 */
+    double morph_distance;        /* 16.0 */
+    double blend_distance;        /* 2.0 */
+    float morph_range;            /* 0.2 */
+    float blend_range;            /* 0.2 */
+    uint32_t origin_lod;          /* 10 */
+    uint32_t _padding;
+} bt_terrain_view_config;
+void bt_terrain_view_config_default(bt_terrain_view_config* out);
+
+/* Everything the tiling prepass reads for one view and frame, derived the way the reference derives it:
+ * TileTree::new (tile_tree.rs:135-173), TerrainViewConfigUniform::from_tile_tree (terrain_view_bind_group.rs:98-116),
+ * TerrainModelApproximation::compute (terrain_model.rs:262-290: only origin_xy / origin_uv per side are read by
+ * refine_tiles, HIGH_PRECISION is never defined for it), CullingUniform.world_position, and the mesh uniform of
+ * TerrainModel::transform() (terrain_model.rs:195-201).  f64 on the host, `as f32` where the reference casts. */
+bt_status bt_view_state_from_config(const bt_terrain_model* model, const bt_terrain_view_config* view_config,
+                                    const double view_world_position[3], float approximate_height, bt_view_state* out);
+
+typedef struct bt_tile_tree bt_tile_tree; /* TileTree + GpuTileTree of one (terrain, view) pair */
+/* TileTree::new (tile_tree.rs:135-173).  The node tables (tile states, TileTreeEntry data, origins) live in HBM. */
+bt_status bt_tile_tree_create(bt_ctx* ctx, const bt_terrain_model* model, uint32_t lod_count,
+                              const bt_terrain_view_config* view_config, bt_tile_tree** out);
+void bt_tile_tree_destroy(bt_tile_tree* tree);
+/* TileTree::compute_requests -> update (tile_tree.rs:268-359) as ONE launch over sides x lods x tree_size^2 nodes
+ * (f64, like the reference): origins, per-node tile coordinate / distance / request state, and the released and
+ * requested tile lists in the reference's push order (stable ballot / prefix-sum compaction).  Synchronises; the lists
+ * stay readable until the next update. */
+bt_status bt_tile_tree_update(bt_tile_tree* tree, const double view_world_position[3]);
+bt_status bt_tile_tree_requests(const bt_tile_tree* tree, const bt_tile_coordinate** released, uint32_t* released_count,
+                                const bt_tile_coordinate** requested, uint32_t* requested_count);
+/* TileAtlas::update's second half (tile_atlas.rs:590-600): drains the lists into release_tile / request_tile. */
+bt_status bt_tile_tree_apply_requests(bt_tile_tree* tree, bt_atlas* atlas);
+/* TileTree::adjust_to_tile_atlas (:363-374): every node's TileTreeEntry = get_best_tile(node coordinate), looked up on
+ * the GPU in a device copy of the atlas's tile states (refreshed when they changed).  Asynchronous. */
+bt_status bt_tile_tree_adjust_to_tile_atlas(bt_tile_tree* tree, const bt_atlas* atlas);
+/* GpuTileTree buffers (gpu_tile_tree.rs:22-95), kept current on the device — no per-frame upload:
+ * entries = bt_tile_tree_entry[side][lod][x][y], origins = uint32[side][lod][2]. */
+bt_status bt_tile_tree_buffers(const bt_tile_tree* tree, void** entries_device, void** origins_device);
+/* host copies for inspection / tests (synchronise) */
+bt_status bt_tile_tree_read(bt_tile_tree* tree, bt_tile_tree_entry* entries, uint32_t entry_cap, uint32_t* origins_xy,
+                            uint32_t origin_cap, bt_tile_coordinate* node_coordinates, uint32_t* node_requested);
+/* sample_height / sample_attachment (terrain_data/mod.rs:265-307) for a batch of world positions: surface projection,
+ * TileTree::compute_blend (:223-239), lookup_tile (:241-266) at lod and lod - 1, bilinear tile samples
+ * (AtlasAttachment::sample) and their blend, on the GPU against the tree's entries and the atlas in HBM.
+ * out_vec4: 4 floats per position (the attachment value); heights (optional): lerp(min_height, max_height, value.x). */
+bt_status bt_tile_tree_sample_attachment(bt_tile_tree* tree, bt_atlas* atlas, uint32_t attachment_index,
+                                         const double* world_positions_xyz, uint32_t count, float* out_vec4, float* heights);
+/* TileTree::approximate_height (:376-386): sample_height at the view position of the last update; also kept by the tree
+ * for the next update's tile distances.  */
+bt_status bt_tile_tree_approximate_height(bt_tile_tree* tree, bt_atlas* atlas, float* height);
+/* the tree's current state as a prepass input (bt_view_state_from_config with the tree's view position / height) */
+bt_status bt_tile_tree_view_state(const bt_tile_tree* tree, bt_view_state* out);
 
 /* ---------------------------------------------------------------- diagnostics */
 /* Exhaustive device check that the kernels' 3-operation unorm16 -> f32 conversion equals the correctly

@@ -509,12 +509,28 @@ static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v
  * GPU's fixed-function filter, whose weights are implementation-defined.  Defined here as exact
  * f32 bilinear: texel centres at uv*N-0.5, clamp-to-edge, value = mix(mix(t00,t10,fx),
  * mix(t01,t11,fx), fy).  textureGather(0, ..) = channel 0 of the same four footprint texels. */
+/* Sampler model (orc_set_sampler_model).  0 bits = the exact-f32 definition above, which is what the product
+ * implements bit for bit.  N > 0 restates what a hardware sampler may legally do at split.wgsl:32: the filter weights
+ * carry only N fractional bits (D3D / Vulkan require at least 8: VkPhysicalDeviceLimits::subTexelPrecisionBits >= 4,
+ * every desktop GPU reports 8).  The weights are snapped to multiples of 2^-N, to nearest (mode 0) or by truncation
+ * (mode 1).  This bounds how far the reference, run on a real wgpu device, can sit from the exact definition. */
+static int g_weight_bits = 0, g_weight_mode = 0;
+void orc_set_sampler_model(int fractional_bits, int mode) {
+    g_weight_bits = fractional_bits;
+    g_weight_mode = mode;
+}
+static float snap_weight(float f) {
+    if (g_weight_bits <= 0) return f;
+    const float scale = (float)(1u << g_weight_bits);
+    return floorf(f * scale + (g_weight_mode == 0 ? 0.5f : 0.0f)) / scale;
+}
+
 static vec4 sample_bilinear(uint32_t format, const void* src, uint32_t w, uint32_t h, float u, float v,
                             int* all_nonzero) {
     float qx = u * (float)w - 0.5f;
     float qy = v * (float)h - 0.5f;
     float fx0 = floorf(qx), fy0 = floorf(qy);
-    float fx = qx - fx0, fy = qy - fy0;
+    float fx = snap_weight(qx - fx0), fy = snap_weight(qy - fy0);
     int ix = (int)fx0, iy = (int)fy0;
     int x0 = clampi(ix, 0, (int)w - 1), x1 = clampi(ix + 1, 0, (int)w - 1);
     int y0 = clampi(iy, 0, (int)h - 1), y1 = clampi(iy + 1, 0, (int)h - 1);

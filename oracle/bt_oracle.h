@@ -99,6 +99,11 @@ int orc_save_tile_config(const orc_atlas* a, const char* path);
 size_t orc_tc_encode(const orc_coord* tiles, uint32_t n, uint8_t* out, size_t cap);
 long orc_tc_decode(const uint8_t* in, size_t n, orc_coord* tiles, uint32_t cap);
 
+/* Sampler model for split (process-wide; test infrastructure): fractional_bits = 0 -> exact f32 bilinear (the
+ * definition the product implements); N > 0 -> filter weights snapped to N fractional bits, mode 0 to nearest,
+ * mode 1 truncated — what the hardware sampler behind split.wgsl:32 may do. */
+void orc_set_sampler_model(int fractional_bits, int mode);
+
 /* ---- per-task kernels exposed for unit tests --------------------------- */
 /* one pixel of split.wgsl:18-43; prev = previous atlas texel (unorm ints, 4 ch) */
 void orc_split_pixel(uint32_t format, uint32_t T, uint32_t b, orc_coord tile, const float tl[2],
@@ -143,6 +148,74 @@ long orc_refine(const orc_view* v, orc_coord* final_tiles, uint32_t cap, uint32_
                 uint32_t* passes_tile_counts /* refinement_count+1 entries or NULL */);
 /* refine_tiles.wgsl:17-22 for one tile (exposed for tests) */
 int orc_should_be_divided(const orc_view* v, orc_coord tile, float* view_distance);
+
+/* ======================================================================== */
+/* TileTree / streaming TileAtlasState / view-state derivation (f64 CPU side) */
+/* restated in oracle/bt_oracle_tree.c                                        */
+/* ======================================================================== */
+/* TerrainModel (math/terrain_model.rs:41-138); identity rotation as in the reference constructors.
+ * kind 0 planar (a = side_length), 1 sphere (a = radius), 2 ellipsoid (a = major, b = minor axis). */
+typedef struct {
+    uint32_t kind, _pad;
+    double position[3];
+    double a, b;
+    float min_height, max_height;
+} orc_model;
+/* TerrainViewConfig (terrain_view.rs:18-63) */
+typedef struct {
+    uint32_t tree_size, geometry_tile_count, refinement_count, grid_size;
+    double subdivision_tolerance, precision_threshold_distance, load_distance, morph_distance, blend_distance;
+    float morph_range, blend_range;
+    uint32_t origin_lod, _pad;
+} orc_view_config;
+typedef struct {
+    uint32_t atlas_index, atlas_lod;
+} orc_tree_entry; /* tile_tree.rs:49-66 */
+
+/* TerrainViewConfigUniform::from_tile_tree + TerrainModelApproximation::compute (origin_xy / origin_uv) + the mesh
+ * uniform: everything refine_tiles reads (terrain_view_bind_group.rs:98-116, terrain_model.rs:262-290, tile_tree.rs:135-173) */
+void orc_view_state_from_config(const orc_model* model, const orc_view_config* vc, const double view_world_position[3],
+                                float approximate_height, orc_view* out);
+/* Coordinate::from_world_position (coordinate.rs:69-113) -> side, uv; world_position (:115-135) */
+uint32_t orc_coordinate_from_world_position(const orc_model* model, const double world[3], double uv[2]);
+void orc_coordinate_world_position(const orc_model* model, uint32_t side, const double uv[2], float height, double out[3]);
+/* math/ellipsoid.rs */
+void orc_project_point_ellipsoid(const double e[3], const double y[3], double out[3]);
+
+/* the streaming half of TileAtlasState (tile_atlas.rs:279-503) */
+typedef struct orc_stream orc_stream;
+orc_stream* orc_stream_new(uint32_t atlas_size, uint32_t attachment_count);
+void orc_stream_free(orc_stream* s);
+void orc_stream_add_existing(orc_stream* s, const orc_coord* tiles, uint32_t n);
+int orc_stream_request_tile(orc_stream* s, orc_coord c);  /* 0, or -2 "Atlas out of indices" */
+int orc_stream_release_tile(orc_stream* s, orc_coord c);  /* 0, or -1 "Tried releasing a tile, which is not present." */
+orc_tree_entry orc_stream_get_best_tile(const orc_stream* s, orc_coord c);
+uint32_t orc_stream_pending_loads(const orc_stream* s);
+/* the first `n` queued loads finish (loaded_tile_attachment, :347-359); writes their (coordinate, atlas_index,
+ * attachment_index) triples to out (5 x u32 each) when non-NULL; returns how many finished */
+uint32_t orc_stream_finish_loads(orc_stream* s, uint32_t n, uint32_t* out);
+uint32_t orc_stream_atlas_index(const orc_stream* s, orc_coord c); /* tile_states[c].atlas_index or INVALID */
+
+/* TileTree (tile_tree.rs:103-387) */
+typedef struct orc_tile_tree orc_tile_tree;
+orc_tile_tree* orc_tile_tree_new(const orc_model* model, uint32_t lod_count, const orc_view_config* vc);
+void orc_tile_tree_free(orc_tile_tree* t);
+void orc_tile_tree_update(orc_tile_tree* t, const double view_world_position[3]); /* :268-333 */
+uint32_t orc_tile_tree_released(const orc_tile_tree* t, orc_coord* out, uint32_t cap);
+uint32_t orc_tile_tree_requested(const orc_tile_tree* t, orc_coord* out, uint32_t cap);
+int orc_tile_tree_apply_requests(orc_tile_tree* t, orc_stream* s);      /* TileAtlas::update :590-600 */
+void orc_tile_tree_adjust_to_tile_atlas(orc_tile_tree* t, const orc_stream* s); /* :363-374 */
+uint32_t orc_tile_tree_node_count(const orc_tile_tree* t);
+/* entries / node coordinates / node states in [side][lod][x][y] slot order; origins [side][lod][2] */
+void orc_tile_tree_read(const orc_tile_tree* t, orc_tree_entry* entries, uint32_t* origins, orc_coord* nodes, uint32_t* requested);
+void orc_tile_tree_set_approximate_height(orc_tile_tree* t, float h);
+/* compute_blend (:223-239) */
+void orc_tile_tree_compute_blend(const orc_tile_tree* t, const double sample_world_position[3], uint32_t* lod, float* ratio);
+/* sample_attachment / sample_height (terrain_data/mod.rs:265-307).  layers[atlas_index] = level-0 texels of that slot
+ * (NULL where nothing is loaded). */
+void orc_tile_tree_sample_attachment(const orc_tile_tree* t, uint32_t format, uint32_t texture_size, uint32_t border_size,
+                                     const void* const* layers, uint32_t atlas_size, const double* positions, uint32_t n,
+                                     float* out_vec4, float* heights);
 
 #ifdef __cplusplus
 }

@@ -67,11 +67,27 @@ class View(C.Structure):
     ]
 
 
+class Model(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("_pad", C.c_uint32), ("position", C.c_double * 3), ("a", C.c_double),
+                ("b", C.c_double), ("min_height", C.c_float), ("max_height", C.c_float)]
+
+
+class ViewConfig(C.Structure):
+    _fields_ = [("tree_size", C.c_uint32), ("geometry_tile_count", C.c_uint32), ("refinement_count", C.c_uint32),
+                ("grid_size", C.c_uint32), ("subdivision_tolerance", C.c_double),
+                ("precision_threshold_distance", C.c_double), ("load_distance", C.c_double),
+                ("morph_distance", C.c_double), ("blend_distance", C.c_double), ("morph_range", C.c_float),
+                ("blend_range", C.c_float), ("origin_lod", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class TreeEntry(C.Structure):
+    _fields_ = [("atlas_index", C.c_uint32), ("atlas_lod", C.c_uint32)]
+
+
 def build(force: bool = False) -> str:
-    src = os.path.join(ORACLE_DIR, "bt_oracle.c")
-    hdr = os.path.join(ORACLE_DIR, "bt_oracle.h")
+    sources = [os.path.join(ORACLE_DIR, n) for n in ("bt_oracle.c", "bt_oracle_tree.c", "bt_oracle.h", "Makefile")]
     stale = not os.path.exists(_LIB_PATH) or any(
-        os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr) if os.path.exists(p)
+        os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in sources if os.path.exists(p)
     )
     if force or stale:
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"], stdout=subprocess.DEVNULL)
@@ -122,6 +138,53 @@ def lib():
     L.orc_sample_tile.restype = None
     L.orc_generate_mipmaps.argtypes = [u32, u32, u32, vp, vp]
     L.orc_generate_mipmaps.restype = sz
+    L.orc_set_sampler_model.argtypes = [i32, i32]
+    L.orc_set_sampler_model.restype = None
+    dp = C.POINTER(C.c_double)
+    L.orc_view_state_from_config.argtypes = [C.POINTER(Model), C.POINTER(ViewConfig), dp, C.c_float, C.POINTER(View)]
+    L.orc_view_state_from_config.restype = None
+    L.orc_coordinate_from_world_position.argtypes = [C.POINTER(Model), dp, dp]
+    L.orc_coordinate_from_world_position.restype = u32
+    L.orc_coordinate_world_position.argtypes = [C.POINTER(Model), u32, dp, C.c_float, dp]
+    L.orc_coordinate_world_position.restype = None
+    L.orc_project_point_ellipsoid.argtypes = [dp, dp, dp]
+    L.orc_project_point_ellipsoid.restype = None
+    L.orc_stream_new.argtypes = [u32, u32]
+    L.orc_stream_new.restype = vp
+    L.orc_stream_free.argtypes = [vp]
+    L.orc_stream_add_existing.argtypes = [vp, C.POINTER(Coord), u32]
+    L.orc_stream_request_tile.argtypes = [vp, Coord]
+    L.orc_stream_release_tile.argtypes = [vp, Coord]
+    L.orc_stream_get_best_tile.argtypes = [vp, Coord]
+    L.orc_stream_get_best_tile.restype = TreeEntry
+    L.orc_stream_pending_loads.argtypes = [vp]
+    L.orc_stream_pending_loads.restype = u32
+    L.orc_stream_finish_loads.argtypes = [vp, u32, C.POINTER(u32)]
+    L.orc_stream_finish_loads.restype = u32
+    L.orc_stream_atlas_index.argtypes = [vp, Coord]
+    L.orc_stream_atlas_index.restype = u32
+    L.orc_tile_tree_new.argtypes = [C.POINTER(Model), u32, C.POINTER(ViewConfig)]
+    L.orc_tile_tree_new.restype = vp
+    L.orc_tile_tree_free.argtypes = [vp]
+    L.orc_tile_tree_update.argtypes = [vp, dp]
+    L.orc_tile_tree_update.restype = None
+    L.orc_tile_tree_released.argtypes = [vp, C.POINTER(Coord), u32]
+    L.orc_tile_tree_released.restype = u32
+    L.orc_tile_tree_requested.argtypes = [vp, C.POINTER(Coord), u32]
+    L.orc_tile_tree_requested.restype = u32
+    L.orc_tile_tree_apply_requests.argtypes = [vp, vp]
+    L.orc_tile_tree_adjust_to_tile_atlas.argtypes = [vp, vp]
+    L.orc_tile_tree_adjust_to_tile_atlas.restype = None
+    L.orc_tile_tree_node_count.argtypes = [vp]
+    L.orc_tile_tree_node_count.restype = u32
+    L.orc_tile_tree_read.argtypes = [vp, vp, vp, vp, vp]
+    L.orc_tile_tree_read.restype = None
+    L.orc_tile_tree_set_approximate_height.argtypes = [vp, C.c_float]
+    L.orc_tile_tree_set_approximate_height.restype = None
+    L.orc_tile_tree_compute_blend.argtypes = [vp, dp, C.POINTER(u32), C.POINTER(C.c_float)]
+    L.orc_tile_tree_compute_blend.restype = None
+    L.orc_tile_tree_sample_attachment.argtypes = [vp, u32, u32, u32, C.POINTER(vp), u32, dp, u32, vp, vp]
+    L.orc_tile_tree_sample_attachment.restype = None
     L.orc_refine.argtypes = [C.POINTER(View), C.POINTER(Coord), u32, C.POINTER(u32), C.POINTER(u32)]
     L.orc_refine.restype = C.c_long
     L.orc_should_be_divided.argtypes = [C.POINTER(View), Coord, C.POINTER(C.c_float)]
@@ -237,6 +300,19 @@ class OracleAtlas:
             raise OSError(rc, "orc_save_tile_config")
 
 
+class sampler_model:
+    """with sampler_model(8): ... — the oracle's split filters with weights of that many fractional bits."""
+
+    def __init__(self, fractional_bits, mode=0):
+        self.args = (fractional_bits, mode)
+
+    def __enter__(self):
+        lib().orc_set_sampler_model(*self.args)
+
+    def __exit__(self, *exc):
+        lib().orc_set_sampler_model(0, 0)
+
+
 def tc_encode(coords):
     arr = (Coord * max(len(coords), 1))(*[Coord(*c) for c in coords])
     n = lib().orc_tc_encode(arr, len(coords), None, 0)
@@ -312,3 +388,147 @@ def should_be_divided(view: View, tile):
     d = C.c_float()
     r = lib().orc_should_be_divided(C.byref(view), Coord(*tile), C.byref(d))
     return bool(r), d.value
+
+
+# ---- TileTree / streaming atlas / view-state derivation (oracle/bt_oracle_tree.c) -------------------------------
+
+def make_model(kind, position, a, b=0.0, min_height=0.0, max_height=1.0):
+    m = Model()
+    m.kind = {"planar": 0, "spherical": 1, "ellipsoidal": 2}[kind]
+    for i in range(3):
+        m.position[i] = float(position[i])
+    m.a, m.b, m.min_height, m.max_height = float(a), float(b), float(min_height), float(max_height)
+    return m
+
+
+def make_view_config(**kw):
+    d = dict(tree_size=8, geometry_tile_count=1000000, refinement_count=30, grid_size=16, subdivision_tolerance=0.1,
+             precision_threshold_distance=0.001, load_distance=2.5, morph_distance=16.0, blend_distance=2.0,
+             morph_range=0.2, blend_range=0.2, origin_lod=10)
+    d.update(kw)
+    c = ViewConfig()
+    for k, v in d.items():
+        setattr(c, k, v)
+    return c
+
+
+def view_state_from_config(model, view_config, view_world_position, approximate_height):
+    v = View()
+    pos = (C.c_double * 3)(*view_world_position)
+    lib().orc_view_state_from_config(C.byref(model), C.byref(view_config), pos, C.c_float(approximate_height), C.byref(v))
+    return v
+
+
+def coordinate_from_world_position(model, world):
+    uv = (C.c_double * 2)()
+    side = lib().orc_coordinate_from_world_position(C.byref(model), (C.c_double * 3)(*world), uv)
+    return side, (uv[0], uv[1])
+
+
+def coordinate_world_position(model, side, uv, height):
+    out = (C.c_double * 3)()
+    lib().orc_coordinate_world_position(C.byref(model), side, (C.c_double * 2)(*uv), C.c_float(height), out)
+    return tuple(out)
+
+
+def project_point_ellipsoid(e, y):
+    out = (C.c_double * 3)()
+    lib().orc_project_point_ellipsoid((C.c_double * 3)(*e), (C.c_double * 3)(*y), out)
+    return tuple(out)
+
+
+class Stream:
+    """The streaming half of TileAtlasState."""
+
+    def __init__(self, atlas_size, attachment_count, existing=()):
+        self._h = lib().orc_stream_new(atlas_size, attachment_count)
+        existing = list(existing)
+        if existing:
+            arr = (Coord * len(existing))(*[Coord(*c) for c in existing])
+            lib().orc_stream_add_existing(self._h, arr, len(existing))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_stream_free(self._h)
+            self._h = None
+
+    def request_tile(self, c):
+        return lib().orc_stream_request_tile(self._h, Coord(*c))
+
+    def release_tile(self, c):
+        return lib().orc_stream_release_tile(self._h, Coord(*c))
+
+    def get_best_tile(self, c):
+        e = lib().orc_stream_get_best_tile(self._h, Coord(*c))
+        return e.atlas_index, e.atlas_lod
+
+    def pending_loads(self):
+        return lib().orc_stream_pending_loads(self._h)
+
+    def finish_loads(self, n):
+        out = (C.c_uint32 * (5 * max(n, 1)))()
+        k = lib().orc_stream_finish_loads(self._h, n, out)
+        return [((out[5 * i], out[5 * i + 1], out[5 * i + 2], out[5 * i + 3]), out[5 * i + 4]) for i in range(k)]
+
+    def atlas_index(self, c):
+        return lib().orc_stream_atlas_index(self._h, Coord(*c))
+
+
+class TileTree:
+    def __init__(self, model, lod_count, view_config):
+        self.model, self.lod_count, self.view_config = model, lod_count, view_config
+        self._h = lib().orc_tile_tree_new(C.byref(model), lod_count, C.byref(view_config))
+        self.nodes = lib().orc_tile_tree_node_count(self._h)
+        self.sides = 1 if model.kind == 0 else 6
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_tile_tree_free(self._h)
+            self._h = None
+
+    def update(self, view_position):
+        lib().orc_tile_tree_update(self._h, (C.c_double * 3)(*view_position))
+        cap = 2 * self.nodes + 16
+        buf = (Coord * cap)()
+        n = lib().orc_tile_tree_released(self._h, buf, cap)
+        released = [buf[i].tuple() for i in range(n)]
+        n = lib().orc_tile_tree_requested(self._h, buf, cap)
+        requested = [buf[i].tuple() for i in range(n)]
+        return released, requested
+
+    def apply_requests(self, stream):
+        rc = lib().orc_tile_tree_apply_requests(self._h, stream._h)
+        if rc:
+            raise RuntimeError(f"orc_tile_tree_apply_requests rc={rc}")
+
+    def adjust_to_tile_atlas(self, stream):
+        lib().orc_tile_tree_adjust_to_tile_atlas(self._h, stream._h)
+
+    def read(self):
+        entries = np.zeros((self.nodes, 2), np.uint32)
+        origins = np.zeros((self.sides, self.lod_count, 2), np.uint32)
+        coords = np.zeros((self.nodes, 4), np.uint32)
+        requested = np.zeros(self.nodes, np.uint32)
+        lib().orc_tile_tree_read(self._h, _np_ptr(entries), _np_ptr(origins), _np_ptr(coords), _np_ptr(requested))
+        return entries, origins, coords, requested
+
+    def set_approximate_height(self, h):
+        lib().orc_tile_tree_set_approximate_height(self._h, C.c_float(h))
+
+    def compute_blend(self, position):
+        lod, ratio = C.c_uint32(), C.c_float()
+        lib().orc_tile_tree_compute_blend(self._h, (C.c_double * 3)(*position), C.byref(lod), C.byref(ratio))
+        return lod.value, ratio.value
+
+    def sample_attachment(self, fmt, texture_size, border_size, layers, positions):
+        """layers: {atlas_index: level-0 texel array}."""
+        atlas_size = (max(layers) + 1) if layers else 1
+        keep = {k: np.ascontiguousarray(v) for k, v in layers.items()}
+        ptrs = (C.c_void_p * atlas_size)(*[keep[i].ctypes.data if i in keep else None for i in range(atlas_size)])
+        positions = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
+        n = len(positions)
+        out = np.zeros((n, 4), np.float32)
+        heights = np.zeros(n, np.float32)
+        lib().orc_tile_tree_sample_attachment(self._h, fmt, texture_size, border_size, ptrs, atlas_size,
+                                              positions.ctypes.data_as(C.POINTER(C.c_double)), n, _np_ptr(out), _np_ptr(heights))
+        return out, heights

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import _oracle as O
+import _refine_model as R
 import bevy_terrain_amd as bt
 
 pytestmark = pytest.mark.gpu
@@ -33,15 +34,14 @@ def spiral(n, radius, h0, h1, seed=99):
         yield (r * math.cos(a), h0 + (h1 - h0) * t, r * math.sin(a))
 
 
-def check_quadtree(tiles, roots):
-    # final tiles are pairwise disjoint (no tile is an ancestor of another)
-    s = {tuple(t) for t in tiles.tolist()}
-    assert len(s) == len(tiles)
-    for side, lod, x, y in s:
-        l, xx, yy = lod, x, y
-        while l > 0:
-            l, xx, yy = l - 1, xx >> 1, yy >> 1
-            assert (side, l, xx, yy) not in s
+def check_quadtree(tiles, roots, view=None):
+    """disjoint, covers every root, neighbour LOD difference <= 1 (tests/_refine_model.py); with `view` also the
+    independent numpy model's list"""
+    none = np.zeros((0, 4), np.uint32)
+    assert R.check_quadtree(tiles, none, roots) <= 1
+    if view is not None:
+        final, dropped, _ = R.refine(view)
+        assert len(dropped) == 0 and np.array_equal(tiles, final)
 
 
 def test_planar_camera_path(device):
@@ -56,7 +56,7 @@ def test_planar_camera_path(device):
         exp, exp_indirect, _ = O.refine(oracle_view(v))
         assert np.array_equal(ours, exp), pos
         assert list(indirect) == exp_indirect
-        check_quadtree(ours, 1)
+        check_quadtree(ours, 1, v if total < 4000 else None)
         total += len(ours)
     assert total > 24 * 10
 
@@ -76,7 +76,7 @@ def test_spherical_camera_path(device):
         exp, exp_indirect, passes = O.refine(oracle_view(v))
         assert np.array_equal(ours, exp), (i, pos)
         assert list(indirect) == exp_indirect
-        check_quadtree(ours, 6)
+        check_quadtree(ours, 6, v if i % 5 == 0 else None)
         counts.append(len(ours))
     assert max(counts) > 300 and min(counts) >= 6
 

@@ -1,0 +1,185 @@
+"""TileTree on the GPU (update / adjust_to_tile_atlas / sample_height) + the streaming
+TileAtlasState of the library against the oracle's f64 restatement, frame by frame along scripted camera paths."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import _cases as K
+import _oracle as O
+import bevy_terrain_amd as bt
+from test_tile_tree_host import MODELS, positions
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def device():
+    return bt.Device(0)
+
+
+def camera_path(kind, n, seed=99):
+    """a descending spiral towards the terrain (SURVEY §8d refinement input), deterministic"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        t = i / max(n - 1, 1)
+        a = 2 * math.pi * 2.5 * t + rng.random() * 0.01
+        if kind == "planar":
+            r = 600.0 * (1 - 0.9 * t)
+            out.append((10.0 + r * math.cos(a), 800.0 * (1 - t) + 30.0, 3.0 + r * math.sin(a)))
+        else:
+            d = np.array([0.4 + 0.9 * (1 - t) * math.cos(a), 0.8, 0.3 + 0.9 * (1 - t) * math.sin(a)])
+            d /= np.linalg.norm(d)
+            out.append(tuple(d * (6371000.0 + 3.0e6 * (1 - t) ** 2 + 2.0e3)))
+    return out
+
+
+def dummy_atlas(device, model, lod_count):
+    cfg = bt.TerrainConfig(lod_count=lod_count, atlas_size=16, path="terrains/none", model=model)
+    cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=16, border_size=2))
+    return bt.TileAtlas.new(cfg, device)
+
+
+@pytest.mark.parametrize("kind", ["planar", "sphere", "ellipsoid"])
+@pytest.mark.parametrize("lods,tree_size", [(7, 8), (12, 4)])
+def test_update_lists_and_node_tables_equal_the_oracle(device, kind, lods, tree_size):
+    model, omodel = MODELS[kind]
+    vc = bt.TerrainViewConfig(tree_size=tree_size)
+    tree = bt.TileTree(dummy_atlas(device, model, lods), model, lods, vc)
+    otree = O.TileTree(omodel, lods, O.make_view_config(tree_size=tree_size))
+    total_req = 0
+    for frame, pos in enumerate(camera_path(kind, 40)):
+        released, requested = tree.update(pos)
+        exp_released, exp_requested = otree.update(pos)
+        assert released == exp_released, (frame, pos)
+        assert requested == exp_requested, (frame, pos)  # the same tiles in the same (push) order
+        entries, origins, coords, flags = tree.read()
+        e2, o2, c2, f2 = otree.read()
+        assert np.array_equal(origins, o2) and np.array_equal(coords, c2) and np.array_equal(flags, f2), frame
+        total_req += len(requested)
+    assert total_req > 100
+
+
+def build_terrain(device, tmp_path, model, lod_count, T=32, b=2, seed=3):
+    """preprocess a small terrain and save it: the streaming tests load it back tile by tile"""
+    W = 2 ** (lod_count - 1) * (T - 2 * b) + 13
+    if model.is_spherical():
+        cfg = bt.TerrainConfig(lod_count=lod_count, atlas_size=6 * 400, path="terrains/stream", model=model)
+    else:
+        cfg = bt.TerrainConfig(lod_count=lod_count, atlas_size=400, path="terrains/stream", model=model)
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=T, border_size=b, format=bt.AttachmentFormat.R16))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer()
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas)
+    if model.is_spherical():
+        paths = [f"face{s}" for s in range(6)]
+        for s, p in enumerate(paths):
+            server.insert(p, K.smooth_raster(W, W, seed=seed + s))
+        pre.preprocess_spherical(bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lod_count)), server, atlas)
+    else:
+        server.insert("src", K.smooth_raster(W, W, seed=seed))
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="src", lod_range=range(0, lod_count)), server, atlas)
+    pre.run(atlas)
+    root = str(tmp_path / "assets")
+    pre.save(atlas, root)
+    tiles = {(c.side, c.lod, c.x, c.y): atlas.download_tile(0, i) for c, i in atlas.tiles()}
+    return root, cfg, tiles
+
+
+@pytest.mark.parametrize("kind,atlas_size", [("planar", 256), ("planar", 40), ("sphere", 512)])
+def test_streaming_loop_entries_and_heights(device, tmp_path, kind, atlas_size):
+    """The reference's per-frame chain (plugin.rs:46-56): compute_requests -> TileAtlas::update -> adjust_to_tile_atlas
+    -> approximate_height, product vs oracle in lock step: same request / release lists, same atlas slots (LRU), same
+    best-tile table, and sample_height within float tolerance.  atlas_size 40 forces slot reuse (eviction)."""
+    model, omodel = MODELS[kind]
+    lods, T, b = 4, 32, 2
+    root, cfg, tiles = build_terrain(device, tmp_path, model, lods, T, b)
+    stream_cfg = bt.TerrainConfig(lod_count=lods, atlas_size=atlas_size, path=cfg.path, model=model)
+    stream_cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=T, border_size=b, format=bt.AttachmentFormat.R16, mip_level_count=3))
+    atlas = bt.TileAtlas.new(stream_cfg, device)
+    atlas.load_tile_config(root)
+    vc = bt.TerrainViewConfig(tree_size=4, load_distance=1.2, blend_distance=1.0)
+    ovc = O.make_view_config(tree_size=4, load_distance=1.2, blend_distance=1.0)
+    tree = bt.TileTree.new(atlas, vc)
+    otree = O.TileTree(omodel, lods, ovc)
+    stream = O.Stream(atlas_size, 1, existing=list(tiles))
+    layers = {}  # oracle's copy of the atlas contents: atlas_index -> texels
+    rng = np.random.default_rng(17)
+    loaded_total, evictions = 0, 0
+    for frame, pos in enumerate(camera_path(kind, 30, seed=5)):
+        # TileTree::compute_requests
+        assert tree.update(pos) == otree.update(pos), frame
+        # TileAtlas::update: finish the loads queued by earlier frames, then this frame's releases / requests
+        pending = stream.pending_loads()
+        assert atlas.pending_loads() == pending
+        loaded, failed = atlas.update(root)
+        assert (loaded, failed) == (pending, 0)
+        for coord, index in stream.finish_loads(pending):
+            evictions += index in layers
+            layers[index] = tiles[coord]
+        loaded_total += loaded
+        tree.apply_requests()
+        otree.apply_requests(stream)
+        # TileTree::adjust_to_tile_atlas
+        tree.adjust_to_tile_atlas()
+        otree.adjust_to_tile_atlas(stream)
+        entries, origins, coords, flags = tree.read()
+        e2, o2, c2, f2 = otree.read()
+        assert np.array_equal(coords, c2) and np.array_equal(entries, e2), frame
+        # every loaded slot holds the bytes of its tile
+        for coord in list(tiles)[:: max(1, len(tiles) // 7)]:
+            idx, lod = atlas.get_best_tile(bt.TileCoordinate(*coord))
+            assert (idx, lod) == stream.get_best_tile(coord)
+            if lod == coord[1]:
+                assert np.array_equal(atlas.download_tile(0, idx), tiles[coord])
+        # TileTree::approximate_height + a batch of sample_height queries around the view
+        h = tree.approximate_height()
+        _, exp_h = otree.sample_attachment(O.FORMAT_R16, T, b, layers, [pos])
+        assert h == pytest.approx(float(exp_h[0]), rel=1e-5, abs=1e-3), frame
+        otree.set_approximate_height(h)  # both sides continue from the same (f32) value
+        if kind == "planar":
+            pts = np.column_stack([rng.uniform(-480, 480, 64) + 10.0, rng.uniform(0, 300, 64), rng.uniform(-480, 480, 64) + 3.0])
+        else:
+            pts = np.asarray(pos) + rng.normal(size=(64, 3)) * 4.0e5
+        ours, ours_h = tree.sample_attachment(0, pts)
+        exp, exp_heights = otree.sample_attachment(O.FORMAT_R16, T, b, layers, pts)
+        # compute_blend's log2 is OCML on the device and libm in the oracle: the blend ratio may differ in its last
+        # bits; the values are unorm heights in [0, 1]
+        assert np.allclose(ours, exp, rtol=1e-5, atol=2e-6), (frame, np.abs(ours - exp).max())
+        assert np.allclose(ours_h, exp_heights, rtol=1e-5, atol=0.05)
+    assert loaded_total > 20
+    if atlas_size == 40:
+        assert evictions > 0
+    # the prepass input derived from the tree's state == bt_view_state_from_config of the same state
+    v = tree.view_state()
+    assert bytes(v) == bytes(bt.view_state_from_config(model, vc, camera_path(kind, 30, seed=5)[-1], v.approximate_height))
+
+
+def test_mips_of_streamed_tiles(device, tmp_path):
+    model, _ = MODELS["planar"]
+    root, cfg, tiles = build_terrain(device, tmp_path, model, 3)
+    scfg = bt.TerrainConfig(lod_count=3, atlas_size=64, path=cfg.path, model=model)
+    scfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=32, border_size=2, format=bt.AttachmentFormat.R16, mip_level_count=3))
+    atlas = bt.TileAtlas.new(scfg, device)
+    atlas.load_tile_config(root)
+    for c in [(0, 0, 0, 0), (0, 2, 3, 1), (0, 1, 1, 1)]:
+        atlas.request_tile(bt.TileCoordinate(*c))
+    assert atlas.pending_loads() == 3 and atlas.get_best_tile(bt.TileCoordinate(0, 2, 3, 1)) == (O.INVALID, O.INVALID)
+    assert atlas.update(root, max_loads=2) == (2, 0) and atlas.pending_loads() == 1
+    assert atlas.get_best_tile(bt.TileCoordinate(0, 2, 3, 1))[1] == 2 and atlas.get_best_tile(bt.TileCoordinate(0, 1, 1, 1)) == (0, 0)
+    assert atlas.update(root) == (1, 0)
+    for c in [(0, 0, 0, 0), (0, 2, 3, 1), (0, 1, 1, 1)]:
+        idx, lod = atlas.get_best_tile(bt.TileCoordinate(*c))
+        assert lod == c[1]
+        chain = O.generate_mipmaps(O.FORMAT_R16, tiles[c], 3)
+        assert np.array_equal(atlas.download_mip(0, 1, idx).ravel(), chain[32 * 32:32 * 32 + 16 * 16])
+        assert np.array_equal(atlas.download_mip(0, 2, idx).ravel(), chain[32 * 32 + 16 * 16:])
+    # a missing file: the tile stays Loading forever, like the reference (tile_atlas.rs:202-204)
+    os.remove(os.path.join(root, cfg.path, "data/height/0_2_0_0.bin"))
+    atlas.request_tile(bt.TileCoordinate(0, 2, 0, 0))
+    assert atlas.update(root) == (0, 1)
+    assert atlas.get_best_tile(bt.TileCoordinate(0, 2, 0, 0)) == (0, 0)
+    with pytest.raises(bt._ffi.BtError):
+        atlas.release_tile(bt.TileCoordinate(0, 2, 1, 1))  # existing, but never requested
