@@ -1025,40 +1025,41 @@ __global__ void selftest_kernel(uint32_t* failures) {
 
 // =============================================================================== host side: planning
 
-struct FusedJobDev {  // device buffers of one fused job, kept alive in the preprocessor
+struct FusedJobDev {  // one fused launch of a compiled queue
     FusedArgs args;
     uint32_t attachment;
     uint32_t main_runs = 0;  // parity selects the todo list
-    uint32_t lds_pad = 0;    // debug (env BT_FUSED_LDS_PAD at plan time): extra dynamic LDS per workgroup
+    uint32_t lds_pad = 0;    // profiling build only (BT_FUSED_LDS_PAD at plan time): extra dynamic LDS per workgroup
 };
 
-static std::vector<FusedJobDev>& jobs_of(bt_preprocessor* p);
+// the fused path's per-queue state, owned by the bt_preprocessor that compiled it (bt_preprocessor::fused)
+struct FusedState {
+    std::vector<FusedJobDev> jobs;
+    std::vector<void*> allocs;  // device buffers of the jobs (grids, item lists, todo lists)
+};
 
 }  // namespace bt
 
-// storage for fused jobs lives next to the preprocessor; keyed by pointer to avoid widening the struct
 #include <algorithm>
-#include <map>
-#include <mutex>
 namespace bt {
-static std::mutex g_jobs_mutex;
-static std::map<bt_preprocessor*, std::vector<FusedJobDev>> g_jobs;
-static std::map<bt_preprocessor*, std::vector<void*>> g_job_allocs;
 
-static std::vector<FusedJobDev>& jobs_of(bt_preprocessor* p) { return g_jobs[p]; }
+static FusedState& state_of(bt_preprocessor* p) {
+    if (!p->fused) p->fused = new FusedState();
+    return *p->fused;
+}
 
 void fused_release(bt_preprocessor* p) {
-    std::lock_guard<std::mutex> lock(g_jobs_mutex);
-    for (void* d : g_job_allocs[p]) hipFree(d);
-    g_job_allocs.erase(p);
-    g_jobs.erase(p);
+    if (!p->fused) return;
+    for (void* d : p->fused->allocs) hipFree(d);
+    delete p->fused;
+    p->fused = nullptr;
 }
 
 template <typename V>
 static bt_status upload_vector(bt_preprocessor* p, const std::vector<V>& v, const V** out) {
     void* d = nullptr;
     BT_HIP(hipMalloc(&d, v.size() * sizeof(V) ? v.size() * sizeof(V) : 1));
-    g_job_allocs[p].push_back(d);
+    state_of(p).allocs.push_back(d);
     if (!v.empty()) BT_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(V), hipMemcpyHostToDevice));
     *out = (const V*)d;
     return BT_OK;
@@ -1069,10 +1070,10 @@ static bt_status upload_vector(bt_preprocessor* p, const std::vector<V>& v, cons
 //  - at every LOD but the finest, each queued tile has all four children queued (full quadtree below it).
 // Otherwise the whole queue runs on the generic kernels.
 bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, std::vector<Launch>& plan) {
-    std::lock_guard<std::mutex> lock(g_jobs_mutex);
-    for (void* d : g_job_allocs[p]) hipFree(d);
-    g_job_allocs[p].clear();
-    std::vector<FusedJobDev>& jobs = jobs_of(p);
+    FusedState& state = state_of(p);
+    for (void* d : state.allocs) hipFree(d);
+    state.allocs.clear();
+    std::vector<FusedJobDev>& jobs = state.jobs;
     jobs.clear();
     if (p->queue.empty()) return false;
 
@@ -1413,17 +1414,13 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
 
 bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
     (void)a;
-    FusedJobDev job;
-    {
-        std::lock_guard<std::mutex> lock(g_jobs_mutex);
-        std::vector<FusedJobDev>& jobs = jobs_of(p);
-        if (l.aux0 >= jobs.size()) {
-            set_error("fused launch without a plan");
-            return BT_ERR_INVALID_ARGUMENT;
-        }
-        job = jobs[l.aux0];
-        if (l.kind == kLaunchFusedMain && (jobs[l.aux0].main_runs++ & 1u)) std::swap(job.args.todo, job.args.todo_next);
+    if (!p->fused || l.aux0 >= p->fused->jobs.size()) {
+        set_error("fused launch without a plan");
+        return BT_ERR_INVALID_ARGUMENT;
     }
+    std::vector<FusedJobDev>& jobs = p->fused->jobs;
+    FusedJobDev job = jobs[l.aux0];
+    if (l.kind == kLaunchFusedMain && (jobs[l.aux0].main_runs++ & 1u)) std::swap(job.args.todo, job.args.todo_next);
     job.args.rasters = p->rasters_dev;
     if (l.kind == kLaunchFusedMain) {
         const uint32_t blocks = job.args.item_count * job.args.groups;

@@ -167,7 +167,8 @@ bt_status launch_mip_level(bt_ctx* ctx, uint32_t format, const void* parent, voi
 bt_status launch_synth_fbm(bt_ctx* ctx, void* dst, uint32_t w, uint32_t h, uint64_t pitch, uint32_t x0, uint32_t y0,
                            uint32_t base_cell, uint32_t octaves, uint32_t seed);
 
-// fused-path device buffers of a preprocessor (bt_fused.hip)
+// fused-path state of a preprocessor (bt_fused.hip): launch descriptors + device buffers of its compiled queue
+struct FusedState;
 void fused_release(struct ::bt_preprocessor* p);
 
 // coordinate math (bt_host.cpp)
@@ -193,6 +194,7 @@ struct bt_preprocessor {
     bt::RasterDev* rasters_dev = nullptr;
     size_t rasters_dev_cap = 0;
     bt_run_stats stats{};
+    bt::FusedState* fused = nullptr;  // owned; freed by fused_release
     // BT_RUN_PROFILE: events[run * (plan.size() + 1) + i]; event 0 of a run precedes its first launch
     std::vector<hipEvent_t> events;
     uint32_t profiled_runs = 0;

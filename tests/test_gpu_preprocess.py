@@ -409,3 +409,67 @@ def test_config3_16k_single_gpu_all_tiles(device, masked):
         data = atlas.download_tiles(0, first, count)
         for k in range(count):
             assert np.array_equal(data[k], oracle.tile(0, first + k)), (first + k, oracle.tiles()[first + k])
+
+
+@pytest.mark.parametrize("second_run", [False, True])
+def test_adjacent_datasets_stitch_across_their_seam(device, second_run):
+    """Two datasets covering the left and the right half of the terrain (PreprocessDataset::top_left / bottom_right),
+    LODs 1..3 only (so no shared ancestor is queued and both quadtrees are complete): the aprons along the seam are the
+    OTHER dataset's centres (stitch_and_save_layer records the atlas's neighbours).  The fused path stitches from a
+    job's own grid only, so such jobs must fall back to the batched kernels: BT_RUN_AUTO == BT_RUN_GENERIC == oracle.
+    second_run: the right half is queued and run after the left half has finished (an earlier run on the same atlas)."""
+    T, b = 32, 2
+    left = K.random_raster(O.FORMAT_R16, 130, 70, seed=51, holes=0.01)
+    right = K.random_raster(O.FORMAT_R16, 130, 66, seed=52, holes=0.01)
+    halves = [("left", left, dict(top_left=(0.0, 0.0), bottom_right=(0.5, 1.0))), ("right", right, dict(top_left=(0.5, 0.0), bottom_right=(1.0, 1.0)))]
+    results = []
+    for generic in (True, False):
+        cfg = bt.TerrainConfig(lod_count=3, atlas_size=64, path="t", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+        cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=T, border_size=b))
+        atlas = bt.TileAtlas.new(cfg, device)
+        server = bt.AssetServer().insert("left", left).insert("right", right)
+        pre = bt.Preprocessor.new()
+        for name, _, rect in halves:
+            pre.preprocess_tile(bt.PreprocessDataset(path=name, lod_range=range(1, 3), **rect), server, atlas)
+            if second_run:
+                pre.run(atlas, generic=generic)
+        if not second_run:
+            pre.run(atlas, generic=generic)
+        results.append(atlas)
+    oracle = O.OracleAtlas(3, 64, False, [(T, b, 1, O.FORMAT_R16)])
+    for _, src, rect in halves:
+        oracle.preprocess_tile(0, src, (1, 3), **rect)
+        if second_run:
+            oracle.run()
+    if not second_run:
+        oracle.run()
+    for atlas in results:
+        assert K.assert_atlas_equal(atlas, oracle) == 4 + 16
+
+
+def test_dataset_rectangle_is_clamped_to_the_face(device):
+    # bottom_right > 1 and a negative top_left: `as_uvec2` saturates, tiles beyond the face do not exist
+    src = K.random_raster(O.FORMAT_R16, 64, 64, seed=8)
+    ds = dict(top_left=(-0.25, 0.0), bottom_right=(1.5, 1.0))
+    for generic in (True, False):
+        atlas, _ = K.product_planar(device, src, 3, 16, 2, O.FORMAT_R16, generic=generic, **ds)
+        coords = [(c.lod, c.x, c.y) for c, _ in atlas.tiles()]
+        assert len(coords) == 21 and all(x < (1 << lod) and y < (1 << lod) for lod, x, y in coords)
+
+
+def test_raster_pitch_is_validated(device):
+    cfg = bt.TerrainConfig(lod_count=1, atlas_size=4, path="t", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=16, border_size=2))
+    atlas = bt.TileAtlas.new(cfg, device)
+    ptr = device.upload(np.ones((8, 8), np.uint16))
+    for pitch in (15, 14):  # odd, and shorter than a row
+        with pytest.raises(bt._ffi.BtError) as e:
+            bt.Preprocessor.new().preprocess_tile(bt.PreprocessDataset(path="x"), bt.AssetServer().insert("x", (ptr, 8, 8, pitch)), atlas)
+        assert e.value.status == -1
+    device.free(ptr)
+    # center_size < border_size cannot be stitched in place (the reference would read aprons being written)
+    cfg2 = bt.TerrainConfig(lod_count=1, atlas_size=4, path="t", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+    cfg2.add_attachment(bt.AttachmentConfig(name="h", texture_size=16, border_size=6))
+    with pytest.raises(bt._ffi.BtError) as e:
+        bt.Preprocessor.new().preprocess_tile(bt.PreprocessDataset(path="x"), bt.AssetServer().insert("x", np.ones((8, 8), np.uint16)), bt.TileAtlas.new(cfg2, device))
+    assert e.value.status == -5

@@ -92,7 +92,7 @@ def build_terrain(device, tmp_path, model, lod_count, T=32, b=2, seed=3):
 def test_streaming_loop_entries_and_heights(device, tmp_path, kind, atlas_size):
     """The reference's per-frame chain (plugin.rs:46-56): compute_requests -> TileAtlas::update -> adjust_to_tile_atlas
     -> approximate_height, product vs oracle in lock step: same request / release lists, same atlas slots (LRU), same
-    best-tile table, and sample_height within float tolerance.  atlas_size 40 forces slot reuse (eviction)."""
+    best-tile table, and sample_height within float tolerance.  atlas_size 40 (at most 1 + 4 + 16 + 16 = 37 tiles are live at once) with a low sweep across the whole terrain forces slot reuse (eviction)."""
     model, omodel = MODELS[kind]
     lods, T, b = 4, 32, 2
     root, cfg, tiles = build_terrain(device, tmp_path, model, lods, T, b)
@@ -108,7 +108,10 @@ def test_streaming_loop_entries_and_heights(device, tmp_path, kind, atlas_size):
     layers = {}  # oracle's copy of the atlas contents: atlas_index -> texels
     rng = np.random.default_rng(17)
     loaded_total, evictions = 0, 0
-    for frame, pos in enumerate(camera_path(kind, 30, seed=5)):
+    path = camera_path(kind, 30, seed=5)
+    if atlas_size == 40:  # a low pass over the whole terrain: far more distinct tiles than slots
+        path = [(10.0 + 450.0 * math.sin(0.37 * i), 40.0, 3.0 + 450.0 * math.sin(0.23 * i + 1.0)) for i in range(60)]
+    for frame, pos in enumerate(path):
         # TileTree::compute_requests
         assert tree.update(pos) == otree.update(pos), frame
         # TileAtlas::update: finish the loads queued by earlier frames, then this frame's releases / requests
@@ -154,7 +157,7 @@ def test_streaming_loop_entries_and_heights(device, tmp_path, kind, atlas_size):
         assert evictions > 0
     # the prepass input derived from the tree's state == bt_view_state_from_config of the same state
     v = tree.view_state()
-    assert bytes(v) == bytes(bt.view_state_from_config(model, vc, camera_path(kind, 30, seed=5)[-1], v.approximate_height))
+    assert bytes(v) == bytes(bt.view_state_from_config(model, vc, path[-1], v.approximate_height))
 
 
 def test_mips_of_streamed_tiles(device, tmp_path):

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     exported = set(re.findall(r" T (bt_[a-z0-9_]+)", out))
     assert declared <= exported, sorted(declared - exported)
     assert declared == set(_ffi.PROTOTYPES), sorted(declared ^ set(_ffi.PROTOTYPES))
-    assert _ffi.lib().bt_abi_version() == 1
+    assert _ffi.lib().bt_abi_version() == 2
 
 
 def test_struct_layouts_match_reference_gpu_layouts():
@@ -90,3 +90,34 @@ def test_view_state_derivation():
     # the opposite face (-x, side 0) takes both coordinates over; the four adjacent faces get one pinned to an edge
     for side in (1, 2, 4, 5):
         assert v.sides[side].view_xy[0] in (0, 1024) or v.sides[side].view_xy[1] in (0, 1024)
+
+
+def test_c99_consumer_of_the_header_and_ctypes_mirror_layouts(tmp_path):
+    """tests/abi_consumer.c includes the header as C99, static-asserts every struct layout, loads the library with
+    dlopen and calls through it; its printed layouts must equal the hand-typed ctypes mirror field by field."""
+    import ctypes as C
+    import json
+
+    exe = str(tmp_path / "abi_consumer")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "abi_consumer.c"), "-ldl", "-o", exe])
+    out = json.loads(subprocess.check_output([exe, _ffi.LIB_PATH], text=True))
+    assert out["abi_version"] == 2 and out["done"]
+    assert out["ctx_create"] in (0, -1, -3)  # 0 on a GPU box; a clean error status (with a message) without one
+    assert out["view_state"] == [0, 614, 307, 2 * 16 * 18, 8]
+    mirror = {"bt_tile_coordinate": _ffi.TileCoordinateC, "bt_atlas_tile": _ffi.AtlasTileC, "bt_attachment_config": _ffi.AttachmentConfigC,
+              "bt_terrain_config": _ffi.TerrainConfigC, "bt_raster": _ffi.RasterC, "bt_preprocess_dataset": _ffi.PreprocessDatasetC,
+              "bt_spherical_dataset": _ffi.SphericalDatasetC, "bt_tile_tree_entry": _ffi.TileTreeEntryC, "bt_run_stats": _ffi.RunStatsC,
+              "bt_shard_range": _ffi.ShardRangeC, "bt_launch_profile": _ffi.LaunchProfileC, "bt_side_parameter": _ffi.SideParameterC,
+              "bt_view_state": _ffi.ViewStateC, "bt_indirect": _ffi.IndirectC, "bt_terrain_model": _ffi.TerrainModelC,
+              "bt_terrain_view_config": _ffi.TerrainViewConfigC}
+    checked = 0
+    for name, cls in mirror.items():
+        layout = out[name]
+        assert layout.pop("__size__")[1] == C.sizeof(cls), name
+        assert set(layout) == {f[0] for f in cls._fields_}, name
+        for field, (offset, size) in layout.items():
+            d = getattr(cls, field)
+            assert (d.offset, d.size) == (offset, size), (name, field)
+            checked += 1
+    assert checked > 80
