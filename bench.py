@@ -27,9 +27,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
 
 
 def cpu_baseline(device, src_ptr):
-    """The CPU oracle (a port: the reference has no CPU path and cannot be built here) timed on the host
-    cores.  With >= 32 cores the whole 16k workload is run (about 10 s); on smaller hosts a bounded sample:
-    the top-left 8192^2 window of the same heightmap with lod_count 5 (341 tiles)."""
+    """The CPU oracle (a port: the reference has no CPU path and cannot be built here) timed on the host cores, the
+    span the reference times (preprocessor.rs:363,419: sources in memory -> all tiles produced, and -> all files
+    written).  All cores: with >= 32 cores the whole 16k workload (about 5-10 s); on smaller hosts a bounded sample,
+    the top-left 8192^2 window of the same heightmap with lod_count 5 (341 tiles).  One thread: the top-left 4096^2
+    window with lod_count 4 (85 tiles, a few seconds)."""
+    import shutil
+    import tempfile
+
     import numpy as np
 
     import _oracle as O
@@ -39,16 +44,91 @@ def cpu_baseline(device, src_ptr):
     rows = device.download(src_ptr, (sample, SIZE), np.uint16)  # first `sample` rows, all columns
     window = np.ascontiguousarray(rows[:, :sample])
     del rows
-    a = O.OracleAtlas(lods, ATLAS_SIZE, False, [(TEXTURE_SIZE, BORDER, 1, O.FORMAT_R16)])
-    a.preprocess_tile(0, window, (0, lods))
-    t0 = time.perf_counter()
-    a.run(cores)
-    dt = time.perf_counter() - t0
+
+    def run(win, nlods, threads):
+        a = O.OracleAtlas(nlods, ATLAS_SIZE, False, [(TEXTURE_SIZE, BORDER, 1, O.FORMAT_R16)])
+        a.preprocess_tile(0, win, (0, nlods))
+        t0 = time.perf_counter()
+        a.run(threads)
+        return a, time.perf_counter() - t0
+
+    a, dt = run(window, lods, cores)
     tiles = len(a.tiles())
+    out_dir = tempfile.mkdtemp(prefix="bt_cpu_baseline_")
+    t0 = time.perf_counter()
+    a.save_attachment(0, out_dir)
+    a.save_tile_config(os.path.join(out_dir, "config.tc"))
+    dt_files = time.perf_counter() - t0
+    shutil.rmtree(out_dir, ignore_errors=True)
+    small = np.ascontiguousarray(window[:4096, :4096])
+    a1, dt1 = run(small, 4, 1)
+    tiles1 = len(a1.tiles())
+    del a1
     what = "the whole workload" if sample == SIZE else f"the top-left {sample}x{sample} window of the same heightmap"
     return {"value": tiles / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
             "sample": f"oracle/bt_oracle.c (OpenMP over the tasks of a phase) on {what}, lod_count {lods}: "
-                      f"{tiles} tiles of 512^2 in {dt:.2f} s"}, a, (sample, lods)
+                      f"{tiles} tiles of 512^2 in {dt:.2f} s",
+            "files_written": {"value": tiles / (dt + dt_files), "unit": "tiles/s", "cores": cores,
+                              "sample": f"the same run + its {tiles} .bin files and config.tc written to a temporary "
+                                        f"directory ({dt_files:.2f} s, one thread)"},
+            "one_thread": {"value": tiles1 / dt1, "unit": "tiles/s", "cores": 1,
+                           "sample": f"the top-left 4096x4096 window, lod_count 4: {tiles1} tiles in {dt1:.2f} s"}}, a, (sample, lods)
+
+
+def end_to_end(device, src_ptr):
+    """The reference's own timing span (preprocessor.rs:363,419: all sources loaded -> all saves done) for the
+    product: source raster in ordinary host memory -> H2D -> kernels -> D2H -> every .bin tile file + config.tc
+    written.  Not part of `value` (that is device-resident); reported so that the PCIe / file-system side is measured
+    rather than estimated."""
+    import shutil
+    import tempfile
+
+    import numpy as np
+
+    import bevy_terrain_amd as bt
+
+    host = device.download(src_ptr, (SIZE, SIZE), np.uint16)  # the "loaded source image" the span starts from
+    cfg = bt.TerrainConfig(lod_count=LOD_COUNT, atlas_size=ATLAS_SIZE, path="terrains/bench16k_e2e",
+                           model=bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=TEXTURE_SIZE, border_size=BORDER,
+                                           format=bt.AttachmentFormat.R16))
+    atlas = bt.TileAtlas.new(cfg, device)
+    device.synchronize()
+    root = tempfile.mkdtemp(prefix="bt_e2e_")
+    results = []
+    for _ in range(2):  # the first pass warms the page cache / allocators, the second is reported
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas, root)
+        t0 = time.perf_counter()
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="host", lod_range=range(0, LOD_COUNT)),
+                            bt.AssetServer().insert("host", host), atlas)
+        t1 = time.perf_counter()
+        pre.run(atlas)
+        t2 = time.perf_counter()
+        pre.save(atlas, root)
+        t3 = time.perf_counter()
+        results.append((t1 - t0, t2 - t1, t3 - t2))
+        pre.close()
+    files = [f for f in os.listdir(atlas.attachment_directory(root, 0)) if f.endswith(".bin")]
+    written = sum(os.path.getsize(os.path.join(atlas.attachment_directory(root, 0), f)) for f in files)
+    fs = "?"
+    try:
+        best = ""
+        for line in open("/proc/mounts"):
+            dev, mnt, typ = line.split()[:3]
+            if root.startswith(mnt) and len(mnt) > len(best):
+                best, fs = mnt, typ
+    except OSError:
+        pass
+    shutil.rmtree(root, ignore_errors=True)
+    up, run, save = results[-1]
+    total = up + run + save
+    return {"ms": total * 1e3, "tiles_per_s": len(files) / total,
+            "upload_ms": up * 1e3, "upload_GBps": host.nbytes / up / 1e9,
+            "kernels_ms": run * 1e3,
+            "save_ms": save * 1e3, "save_GBps": written / save / 1e9, "files": len(files), "bytes_written": written,
+            "filesystem": fs, "first_pass_ms": sum(results[0]) * 1e3,
+            "span": "source raster in pageable host memory -> hipMalloc + H2D -> 3 kernels -> D2H through 3 pinned "
+                    "buffers + writer threads -> 1365 .bin files + config.tc (preprocessor.rs:363,419)"}
 
 
 def verify_against(atlas, oracle, shape):
@@ -80,6 +160,7 @@ def main():
                     help="untimed spin-up before the W warm-up steps: the GPU needs ~100 ms of load to reach its sustained clock")
     ap.add_argument("--generic", action="store_true", help="force the reference-shaped batched kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host raster -> files on disk measurement")
     ap.add_argument("--verify", action="store_true", help="byte-compare all tiles with the oracle run of cpu_baseline")
     args = ap.parse_args()
 
@@ -197,7 +278,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak",
+        "scaling": "strong",  # the 16k job is fixed: N ranks share it (column strips), per-GPU work shrinks with N
         "collective_backend": backend if world > 1 else None,
         "vs_baseline": None,
         "dtype": "f32",  # IEEE binary32 arithmetic on u16 texels, results bit-exact vs the oracle
@@ -205,7 +286,7 @@ def main():
         "config": {"workload": f"synthetic {SIZE}x{SIZE} fBm R16 heightmap (seed {SEED}), T={TEXTURE_SIZE}, b={BORDER}, "
                                f"lod_count={LOD_COUNT}: split + pyramid + stitch into {tiles} tiles",
                    "path": "generic (batched split/downsample/stitch)" if stats["fused_jobs"] == 0 else "fused",
-                   "plan_launches_per_step": stats["kernel_launches"],  # fused_main (+ fused_todo) and fused_tail
+                   "kernels_per_step": stats["kernel_launches"],  # fused_main, fused_todo, fused_tail: what rocprofv3 --stats counts
                    "algorithmic_bytes_per_step": stats["algorithmic_bytes"],
                    "whole_step_GBps": stats["algorithmic_bytes"] / (ms_per_step / 1e3) / 1e9,
                    "host_wall_ms_per_step": wall_ms / args.steps,
@@ -224,7 +305,9 @@ def main():
             try:
                 summary = json.load(open(path))
                 traffic = summary[dominant["kind"]]["hbm_traffic_bytes"]["total"]
-                traffic_source = os.path.relpath(path, ROOT)
+                traffic_source = {"file": os.path.relpath(path, ROOT), "git": summary.get("_git"), "workload": summary.get("_workload"),
+                                  "note": "rocprofv3 --pmc passes of this same command (tools/profile_round.sh); PMC collection "
+                                          "cannot run inside the timed process"}
                 break
             except (KeyError, ValueError, OSError):
                 continue
@@ -240,6 +323,11 @@ def main():
             line["verify_vs_oracle"] = verify_against(atlas, oracle, shape)
     if world > 1:
         dist.barrier()  # the other ranks wait for rank 0's oracle run before tearing the group down
+    if rank == 0 and world == 1 and not args.no_end_to_end:
+        try:
+            line["end_to_end"] = end_to_end(device, src_ptr)
+        except Exception as e:  # never lose the headline line over a side measurement
+            line["end_to_end"] = {"error": repr(e)}
     if rank == 0 and world == 1:
         # the other half of the hot path, for the record: the per-frame tiling prepass on scripted camera paths
         # (latency-bound, one launch per frame; not part of `value`)

@@ -1307,6 +1307,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         }
         Launch lm{};
         lm.kind = kLaunchFusedMain;
+        lm.kernels = 2;  // fused_main + fused_todo (or fused_corner + fused_main)
         lm.attachment = ai;
         lm.task_count = uint32_t(items.size());
         lm.aux0 = uint32_t(jobs.size());

@@ -3,6 +3,7 @@
 // Mirrors the reference's CPU-side behaviour (file:line citations relative to the reference checkout);
 // the arithmetic on texels lives in bt_kernels.hip and bt_fused.hip.
 #include <dirent.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -153,6 +154,18 @@ static bt_status make_dirs(const std::string& dir) {
     return BT_OK;
 }
 
+bt_status ctx_staging(bt_ctx* ctx, size_t bytes) {
+    if (ctx->staging_bytes >= bytes && ctx->staging[0]) return BT_OK;
+    for (void*& p : ctx->staging) {
+        if (p) hipHostFree(p);
+        p = nullptr;
+    }
+    ctx->staging_bytes = 0;
+    for (void*& p : ctx->staging) BT_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    ctx->staging_bytes = bytes;
+    return BT_OK;
+}
+
 }  // namespace bt
 
 using namespace bt;
@@ -195,6 +208,8 @@ bt_status bt_ctx_create(int32_t device, void* stream, bt_ctx** out) {
 void bt_ctx_destroy(bt_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    for (void* p : ctx->staging)
+        if (p) hipHostFree(p);
     if (ctx->ev_begin) hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) hipEventDestroy(ctx->ev_end);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -526,9 +541,16 @@ class FileWriters {
             }
             bool ok = false;
             std::string why;
-            if (FILE* f = fopen(j.path.c_str(), "wb")) {
-                ok = fwrite(j.data, 1, j.bytes, f) == j.bytes;
-                ok = (fclose(f) == 0) && ok;
+            const int fd = open(j.path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+            if (fd >= 0) {
+                size_t done = 0;
+                while (done < j.bytes) {
+                    const ssize_t w = write(fd, j.data + done, j.bytes - done);
+                    if (w <= 0) break;
+                    done += size_t(w);
+                }
+                ok = done == j.bytes;
+                ok = (close(fd) == 0) && ok;
                 if (!ok) why = "short write to " + j.path;
             } else {
                 why = "cannot open " + j.path + ": " + strerror(errno);
@@ -563,18 +585,18 @@ bt_status save_tiles(bt_atlas* a, uint32_t ai, const char* directory, std::vecto
                 tiles.end());
     if (tiles.empty()) return BT_OK;
     BT_HIP(hipSetDevice(a->ctx->device));
-    constexpr uint32_t kBuffers = 3;
+    constexpr uint32_t kBuffers = bt_ctx::kStagingBuffers;
     const uint32_t chunk = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (32ull << 20) / at.tile_bytes)));
-    void* pinned[kBuffers] = {};
+    if (bt_status s = ctx_staging(a->ctx, std::max<size_t>(32ull << 20, at.tile_bytes))) return s;
+    void** pinned = a->ctx->staging;
     hipEvent_t copied[kBuffers] = {};
     bt_status rc = BT_OK;
     for (uint32_t k = 0; k < kBuffers && rc == BT_OK; k++) {
-        hipError_t e = hipHostMalloc(&pinned[k], at.tile_bytes * chunk, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&copied[k], hipEventDisableTiming);
-        if (e != hipSuccess) rc = hip_fail(e, "save buffers");
+        hipError_t e = hipEventCreateWithFlags(&copied[k], hipEventDisableTiming);
+        if (e != hipSuccess) rc = hip_fail(e, "save events");
     }
     if (rc == BT_OK) {
-        const uint32_t threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        const uint32_t threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
         FileWriters writers(threads, kBuffers);
         const size_t n = tiles.size(), chunks = (n + chunk - 1) / chunk;
         auto hand_over = [&](size_t c) -> bt_status {  // chunk c has been enqueued: wait for its copies, queue its files
@@ -613,10 +635,8 @@ bt_status save_tiles(bt_atlas* a, uint32_t ai, const char* directory, std::vecto
         for (uint32_t k = 0; k < kBuffers; k++) writers.wait_buffer(k);
         if (rc == BT_OK) rc = writers.status();
     }
-    for (uint32_t k = 0; k < kBuffers; k++) {
+    for (uint32_t k = 0; k < kBuffers; k++)
         if (copied[k]) hipEventDestroy(copied[k]);
-        if (pinned[k]) hipHostFree(pinned[k]);
-    }
     return rc;
 }
 
@@ -771,9 +791,9 @@ bt_status bt_atlas_load_tiles(bt_atlas* a, uint32_t ai, const char* directory, c
     }
     if (!count) return BT_OK;
     BT_HIP(hipSetDevice(a->ctx->device));
-    const uint32_t chunk = 64;
-    void* pinned = nullptr;
-    BT_HIP(hipHostMalloc(&pinned, at.tile_bytes * chunk, hipHostMallocDefault));
+    const uint32_t chunk = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (32ull << 20) / at.tile_bytes)));
+    if (bt_status s = ctx_staging(a->ctx, std::max<size_t>(32ull << 20, at.tile_bytes))) return s;
+    void* pinned = a->ctx->staging[0];
     std::vector<uint32_t> layers;
     bt_status rc = BT_OK;
     for (uint32_t i = 0; i < count && rc == BT_OK; i += chunk) {
@@ -812,7 +832,6 @@ bt_status bt_atlas_load_tiles(bt_atlas* a, uint32_t ai, const char* directory, c
             if (e != hipSuccess) rc = hip_fail(e, "tile upload");
         }
     }
-    hipHostFree(pinned);
     if (rc || at.mips.size() <= 1) return rc;
     std::sort(layers.begin(), layers.end());
     for (size_t i = 0; i < layers.size();) {
@@ -838,8 +857,8 @@ bt_status bt_atlas_update(bt_atlas* a, const char* assets_root, uint32_t max_loa
     uint64_t largest = 0;
     for (const Attachment& at : a->attachments) largest = std::max(largest, at.tile_bytes);
     const uint32_t chunk = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (32ull << 20) / std::max<uint64_t>(largest, 1))));
-    void* pinned = nullptr;
-    BT_HIP(hipHostMalloc(&pinned, largest * chunk, hipHostMallocDefault));
+    if (bt_status s = ctx_staging(a->ctx, std::max<size_t>(32ull << 20, largest))) return s;
+    void* pinned = a->ctx->staging[0];
     std::vector<std::vector<uint32_t>> mip_layers(a->attachments.size());
     uint32_t budget = max_loads ? max_loads : 0xFFFFFFFFu, done = 0, bad = 0;
     bt_status rc = BT_OK;
@@ -890,7 +909,6 @@ bt_status bt_atlas_update(bt_atlas* a, const char* assets_root, uint32_t max_loa
             done++;
         }
     }
-    hipHostFree(pinned);
     for (uint32_t ai = 0; ai < a->attachments.size() && rc == BT_OK; ai++) {
         std::vector<uint32_t>& layers = mip_layers[ai];
         if (layers.empty() || a->attachments[ai].mips.size() <= 1) continue;

@@ -125,7 +125,16 @@ struct bt_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    // pinned staging buffers of the tile save / load paths: allocated on first use (pinning 100 MB costs tens of
+    // milliseconds), kept for the life of the context
+    static constexpr uint32_t kStagingBuffers = 3;
+    void* staging[kStagingBuffers] = {};
+    size_t staging_bytes = 0;
 };
+
+namespace bt {
+bt_status ctx_staging(bt_ctx* ctx, size_t bytes_per_buffer);  // ensures ctx->staging[*] hold at least that much
+}
 
 struct bt_atlas {
     bt_ctx* ctx = nullptr;
@@ -152,6 +161,7 @@ struct Launch {
     uint32_t aux0 = 0, aux1 = 0;
     uint64_t algorithmic_bytes = 0;  // inputs read once + outputs written once
     uint32_t phase = 0;              // sharded runs: 0 = BT_RUN_SHARD_LOCAL part, 2 = BT_RUN_SHARD_FINISH part
+    uint32_t kernels = 1;            // kernels this plan entry launches (fused main: itself + fused_todo / fused_corner)
 };
 
 // host-side launchers implemented in bt_kernels.hip

@@ -145,7 +145,8 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
                 st.algorithmic_bytes += a->attachments[t.attachment_index].tile_bytes;
             }
         }
-        st.kernel_launches = uint32_t(p->plan.size());
+        st.kernel_launches = 0;
+        for (const Launch& l : p->plan) st.kernel_launches += l.kernels;
         st.fused_jobs = fused ? p->jobs : 0;
         st.generic_jobs = fused ? 0 : p->jobs;
         p->stats = st;

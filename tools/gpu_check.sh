@@ -5,7 +5,7 @@ mkdir -p $R/gpurun_out
 cd $R
 timeout 900 python -m pytest tests -m gpu -q -x "$@" > gpurun_out/tests.log 2>&1
 grep -E "passed|failed|error" gpurun_out/tests.log | tail -3
-python bench.py --no-cpu-baseline 2> gpurun_out/bench.err > gpurun_out/bench.json
+python bench.py --no-cpu-baseline --no-end-to-end 2> gpurun_out/bench.err > gpurun_out/bench.json
 python - <<'PY'
 import json
 d = json.load(open("gpurun_out/bench.json"))

@@ -28,7 +28,7 @@ def kind_of(kernel_name):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     summary = collections.defaultdict(dict)
@@ -54,6 +54,12 @@ def main():
     out["_note"] = ("HBM traffic per launch, corrected as MI355X_MICROARCH.md (HBM section) prescribes: rocprofv3 reports "
                     "FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts exactly half the bytes of a wide coalesced "
                     "read stream -> x2; WRITE_SIZE as reported (uncalibrated)")
+    import subprocess
+
+    try:
+        out["_git"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        out["_git"] = None
     out["_command"] = "tools/profile_round.sh (one rocprofv3 --pmc pass per counter group, --kernel-trace only)"
     out["_workload"] = "synthetic 16384x16384 fBm R16, T=512, b=2, lod_count=6 (1365 tiles), fused path, 1x MI355X"
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)

@@ -6,7 +6,7 @@ O=$R/gpurun_out/tcc
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $O/counters.txt 2>&1
-B="python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 --spinup-ms 0"
+B="python $R/bench.py --no-cpu-baseline --no-end-to-end --steps 3 --warmup 1 --spinup-ms 0"
 python - "$O" <<'PY' > $O/groups.txt
 import re, sys
 txt = open(sys.argv[1] + "/counters.txt").read()

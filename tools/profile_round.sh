@@ -4,12 +4,12 @@
 # writes gpurun_out/<tag>/...; tools/pmc_summary.py then condenses them into profiles/<tag>_*.
 # Counters are collected in their own passes (one --pmc group per run, kernel trace only).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline"
+B="python $R/bench.py --no-cpu-baseline --no-end-to-end"
 
 python $R/bench.py --verify > $O/bench_n1_verified.json 2> $O/bench.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $B > $O/bench_under_rocprofv3.json 2> $O/stats.log
