@@ -159,6 +159,12 @@ def main():
     ap.add_argument("--spinup-ms", type=float, default=150.0,
                     help="untimed spin-up before the W warm-up steps: the GPU needs ~100 ms of load to reach its sustained clock")
     ap.add_argument("--generic", action="store_true", help="force the reference-shaped batched kernels")
+    ap.add_argument("--config", choices=["planar16k", "cube"], default="planar16k",
+                    help="planar16k: BASELINE configs 3 / 4, the headline metric (default); cube: config 5's shape, six "
+                         "8192^2 faces, lod_count 5, 2046 tiles (a parity / scaling case, not the headline)")
+    ap.add_argument("--collective", choices=["library", "torch"], default=None,
+                    help="N > 1: who issues the exchange — the library's own RCCL communicator, one grouped collective per "
+                         "step (default with the nccl backend), or torch.distributed (gloo test hook)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host raster -> files on disk measurement")
     ap.add_argument("--verify", action="store_true", help="byte-compare all tiles with the oracle run of cpu_baseline")
@@ -187,22 +193,38 @@ def main():
     import bevy_terrain_amd as bt
 
     device = bt.Device(local_rank)
-    src_ptr = device.synth_fbm_r16(SIZE, SIZE, SEED)
-
-    cfg = bt.TerrainConfig(lod_count=LOD_COUNT, atlas_size=ATLAS_SIZE, path="terrains/bench16k",
-                           model=bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 1.0))
+    cube = args.config == "cube"
+    collective = args.collective or ("library" if backend == "nccl" else "torch")
+    if cube:
+        size, lod_count, paths = 8192, 5, [f"synthetic/face{f}" for f in range(6)]
+        faces = [device.synth_fbm_r16(size, size, 7 + f) for f in range(6)]
+        src_ptr = faces[0]
+        cfg = bt.TerrainConfig(lod_count=lod_count, atlas_size=ATLAS_SIZE, path="terrains/bench_cube",
+                               model=bt.TerrainModel.sphere((0.0, 0.0, 0.0), 6371000.0, -12000.0, 9000.0))
+    else:
+        size, lod_count, paths = SIZE, LOD_COUNT, "synthetic/fbm16k"
+        src_ptr = device.synth_fbm_r16(SIZE, SIZE, SEED)
+        cfg = bt.TerrainConfig(lod_count=LOD_COUNT, atlas_size=ATLAS_SIZE, path="terrains/bench16k",
+                               model=bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 1.0))
     cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=TEXTURE_SIZE, border_size=BORDER,
                                            format=bt.AttachmentFormat.R16))
     atlas = bt.TileAtlas.new(cfg, device)
-    server = bt.AssetServer().insert("synthetic/fbm16k", (src_ptr, SIZE, SIZE))
+    server = bt.AssetServer()
+    if cube:
+        for p, f in zip(paths, faces):
+            server.insert(p, (f, size, size))
+    else:
+        server.insert(paths, (src_ptr, SIZE, SIZE))
     pre = bt.Preprocessor.new().clear_attachment(0, atlas)
     if world > 1:
         from bevy_terrain_amd.shard import ShardedPreprocess
 
-        job = ShardedPreprocess(pre, atlas, server, "synthetic/fbm16k", range(0, LOD_COUNT), rank, world, generic=args.generic)
+        job = ShardedPreprocess(pre, atlas, server, paths, range(0, lod_count), rank, world, generic=args.generic, collective=collective)
     else:
-        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="synthetic/fbm16k", lod_range=range(0, LOD_COUNT)),
-                            server, atlas)
+        if cube:
+            pre.preprocess_spherical(bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lod_count)), server, atlas)
+        else:
+            pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path=paths, lod_range=range(0, lod_count)), server, atlas)
         job = None
 
     def step(profile=False):
@@ -279,12 +301,15 @@ def main():
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
         "scaling": "strong",  # the 16k job is fixed: N ranks share it (column strips), per-GPU work shrinks with N
-        "collective_backend": backend if world > 1 else None,
+        "collective_backend": (backend if collective == "torch" else "rccl (library-issued, one grouped collective per step)") if world > 1 else None,
         "vs_baseline": None,
         "dtype": "f32",  # IEEE binary32 arithmetic on u16 texels, results bit-exact vs the oracle
         "data": "synthetic",
-        "config": {"workload": f"synthetic {SIZE}x{SIZE} fBm R16 heightmap (seed {SEED}), T={TEXTURE_SIZE}, b={BORDER}, "
-                               f"lod_count={LOD_COUNT}: split + pyramid + stitch into {tiles} tiles",
+        "config": {"workload": (f"synthetic cube: 6 faces of {size}x{size} fBm R16 (seeds 7..12), T={TEXTURE_SIZE}, b={BORDER}, "
+                                f"lod_count={lod_count}: split + pyramid + stitch (cube seams) into {tiles} tiles [BASELINE config 5's shape]"
+                                if cube else
+                                f"synthetic {SIZE}x{SIZE} fBm R16 heightmap (seed {SEED}), T={TEXTURE_SIZE}, b={BORDER}, "
+                                f"lod_count={LOD_COUNT}: split + pyramid + stitch into {tiles} tiles"),
                    "path": "generic (batched split/downsample/stitch)" if stats["fused_jobs"] == 0 else "fused",
                    "kernels_per_step": stats["kernel_launches"],  # fused_main, fused_todo, fused_tail: what rocprofv3 --stats counts
                    "algorithmic_bytes_per_step": stats["algorithmic_bytes"],
@@ -315,6 +340,9 @@ def main():
                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                             "traffic_source": traffic_source,
                             "avg_launch_ms": dominant["avg_ms"], "algorithmic_bytes_per_launch": dominant["algorithmic_bytes"]}
+    if cube:
+        args.no_cpu_baseline = args.no_end_to_end = True  # the side measurements belong to the headline workload
+        args.verify = False
     if rank == 0 and ((world == 1 and not args.no_cpu_baseline) or args.verify):
         baseline, oracle, shape = cpu_baseline(device, src_ptr)
         if world == 1:

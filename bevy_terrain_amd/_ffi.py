@@ -68,6 +68,11 @@ class ShardRangeC(C.Structure):
                 ("layers_per_rank", C.c_uint32)]
 
 
+class ShardPieceC(C.Structure):
+    _fields_ = [("attachment_index", C.c_uint32), ("side", C.c_uint32), ("lod", C.c_uint32), ("first_layer", C.c_uint32),
+                ("layers", C.c_uint32), ("owner_rank", C.c_uint32)]
+
+
 class LaunchProfileC(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("tasks", C.c_uint32), ("algorithmic_bytes", C.c_uint64), ("avg_ms", C.c_float),
                 ("samples", C.c_uint32)]
@@ -162,6 +167,13 @@ PROTOTYPES = {
     "bt_preprocessor_last_run_stats": (_i32, [_vp, _P(RunStatsC)]),
     "bt_preprocessor_set_shard": (_i32, [_vp, _u32, _u32]),
     "bt_preprocessor_shard_ranges": (_i32, [_vp, _P(ShardRangeC), _u32, _P(_u32)]),
+    "bt_preprocessor_shard_pieces": (_i32, [_vp, _P(ShardPieceC), _u32, _P(_u32)]),
+    "bt_comm_unique_id": (_i32, [_P(C.c_uint8)]),
+    "bt_comm_create": (_i32, [_vp, _u32, _u32, _P(C.c_uint8), _P(_vp)]),
+    "bt_comm_adopt": (_i32, [_vp, _vp, _u32, _u32, _P(_vp)]),
+    "bt_comm_destroy": (None, [_vp]),
+    "bt_comm_check": (_i32, [_vp]),
+    "bt_preprocessor_run_sharded": (_i32, [_vp, _vp, _vp, _u32]),
     "bt_preprocessor_profile": (_i32, [_vp, _P(LaunchProfileC), _u32, _P(_u32)]),
     "bt_tiling_prepass_create": (_i32, [_vp, _u32, _P(_vp)]),
     "bt_tiling_prepass_destroy": (None, [_vp]),

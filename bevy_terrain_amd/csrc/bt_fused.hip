@@ -1153,13 +1153,18 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             if (t->tl[0] != splits[0]->tl[0] || t->tl[1] != splits[0]->tl[1] || t->br[0] != splits[0]->br[0] || t->br[1] != splits[0]->br[1])
                 return false;
 
-        // ---- sharding (multi-GPU): rank r owns the columns [r * n / world, (r + 1) * n / world) of every LOD the
-        // main kernel produces; those tiles are contiguous atlas layers (x-major allocation order)
+        // ---- sharding (multi-GPU).  Unit = one column strip of one side at the granularity of the coarsest LOD the main
+        // kernel produces (a strip = 2^(levels-1) finest columns = one column of that LOD), units numbered side-major;
+        // rank r owns the units [r * U / world, (r + 1) * U / world).  A unit's tiles of a LOD are contiguous atlas layers
+        // (x-major allocation order), so the exchange is a list of contiguous layer runs, each with its owning rank.
         const uint32_t world = p->shard_world, rank = p->shard_rank;
         const uint32_t nlods_all = lod_hi - lod_lo + 1, main_levels_all = std::min(3u, nlods_all);
-        bool shard = world > 1 && ((1u << (lod_hi - (main_levels_all - 1))) % world) == 0;
+        const uint32_t strips = 1u << (lod_hi - (main_levels_all - 1)), units = sides * strips;
+        bool shard = world > 1 && units % world == 0;
         std::vector<bt_shard_range> ranges;
+        std::vector<bt_shard_piece> pieces;
         if (shard) {
+            const uint32_t units_per_rank = units / world;
             for (uint32_t side = 0; side < sides && shard; side++)
                 for (uint32_t k = 0; k < main_levels_all && shard; k++) {
                     const uint32_t lod = lod_hi - k, n = 1u << lod;
@@ -1167,16 +1172,29 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                     const uint32_t base = grids[off];
                     for (size_t i = 0; i < size_t(n) * n; i++)
                         if (base == kInvalid || grids[off + i] != base + i) shard = false;  // not the fresh x-major layout
-                    ranges.push_back({ai, side, lod, base, n / world * n});
+                    const uint32_t cols_per_strip = n / strips;
+                    // maximal runs of strips with one owner
+                    for (uint32_t strip = 0; strip < strips;) {
+                        const uint32_t owner = (side * strips + strip) / units_per_rank;
+                        uint32_t end = strip + 1;
+                        while (end < strips && (side * strips + end) / units_per_rank == owner) end++;
+                        pieces.push_back({ai, side, lod, base + strip * cols_per_strip * n, (end - strip) * cols_per_strip * n, owner});
+                        strip = end;
+                    }
+                    // the regular case (one side, every rank an equal run): also expressible as ONE in-place all-gather
+                    if (sides == 1) ranges.push_back({ai, side, lod, base, n / world * n});
                 }
         }
-        if (world > 1 && !shard) ranges.clear();
+        if (world > 1 && !shard) {
+            ranges.clear();
+            pieces.clear();
+        }
 
         std::vector<MainItem> items;
         for (const Task* t : splits) {
             if (shard) {
-                const uint32_t per = (1u << lod_hi) / world;
-                if (t->coord.x / per != rank) continue;
+                const uint32_t unit = t->coord.side * strips + (t->coord.x >> (main_levels_all - 1));
+                if (unit / (units / world) != rank) continue;
             }
             items.push_back({t->coord.side, t->coord.x, t->coord.y, t->atlas_index, uint32_t(t->raster)});
         }
@@ -1189,7 +1207,10 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             std::stable_sort(items.begin(), items.end(), [](const MainItem& a, const MainItem& b2) {
                 return a.side != b2.side ? a.side < b2.side : (a.y != b2.y ? a.y < b2.y : a.x < b2.x);
             });
-        if (shard) p->shard_ranges.insert(p->shard_ranges.end(), ranges.begin(), ranges.end());
+        if (shard) {
+            p->shard_ranges.insert(p->shard_ranges.end(), ranges.begin(), ranges.end());
+            p->shard_pieces.insert(p->shard_pieces.end(), pieces.begin(), pieces.end());
+        }
 
         FusedArgs args{};
         args.m = m;

@@ -181,6 +181,8 @@ bt_status launch_synth_fbm(bt_ctx* ctx, void* dst, uint32_t w, uint32_t h, uint6
 struct FusedState;
 void fused_release(struct ::bt_preprocessor* p);
 
+bt_status release_queue(struct ::bt_preprocessor* p);  // bt_run.cpp
+
 // coordinate math (bt_host.cpp)
 void tile_children(bt_tile_coordinate c, bt_tile_coordinate out[4]);
 void tile_neighbours(bt_tile_coordinate c, bool spherical, bt_tile_coordinate out[8]);
@@ -194,6 +196,7 @@ struct bt_preprocessor {
     uint32_t jobs = 0;
     uint32_t shard_rank = 0, shard_world = 1;
     std::vector<bt_shard_range> shard_ranges;
+    std::vector<bt_shard_piece> shard_pieces;
     // compiled plan (rebuilt when the queue changes)
     bool compiled = false;
     bool saves_recorded = false;  // the kept queue's Save tasks are already in the atlas's to_save list

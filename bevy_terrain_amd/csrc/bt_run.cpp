@@ -116,6 +116,7 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
         std::vector<TaskDev> tasks;
         p->plan.clear();
         p->shard_ranges.clear();
+        p->shard_pieces.clear();
         bool fused = false;
         if (!mode) fused = fused_plan(p, a, tasks, p->plan);
         if (!fused) {
@@ -207,18 +208,24 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
             if (t.type == kSave) a->to_save.push_back({t.coord, t.atlas_index, t.attachment_index});
         p->saves_recorded = true;
     }
-    if (!(flags & BT_RUN_KEEP_QUEUE)) {
-        BT_HIP(hipStreamSynchronize(p->ctx->stream));  // borrowed rasters may be released by the caller afterwards
-        p->queue.clear();
-        for (Raster& r : p->rasters)
-            if (r.owned && r.dev.data) hipFree((void*)r.dev.data);
-        p->rasters.clear();
-        p->jobs = 0;
-        p->compiled = false;
-        p->saves_recorded = false;
-    }
+    if (!(flags & BT_RUN_KEEP_QUEUE)) return release_queue(p);
     return BT_OK;
 }
+
+namespace bt {
+// the queue has run: drop it (and the rasters it uploaded) so that the next preprocess_* call starts afresh
+bt_status release_queue(bt_preprocessor* p) {
+    BT_HIP(hipStreamSynchronize(p->ctx->stream));  // borrowed rasters may be released by the caller afterwards
+    p->queue.clear();
+    for (Raster& r : p->rasters)
+        if (r.owned && r.dev.data) hipFree((void*)r.dev.data);
+    p->rasters.clear();
+    p->jobs = 0;
+    p->compiled = false;
+    p->saves_recorded = false;
+    return BT_OK;
+}
+}  // namespace bt
 
 extern "C" bt_status bt_preprocessor_profile(bt_preprocessor* p, bt_launch_profile* out, uint32_t cap, uint32_t* count) {
     if (!p || !count) return BT_ERR_INVALID_ARGUMENT;

@@ -12,8 +12,12 @@ New design — the reference is single-process, single-GPU (SURVEY.md §2 "Paral
   4. every rank finishes redundantly: the cross-strip aprons of the gathered parent LODs and the few top
      LODs (< 2 % of the work).
 
-The collective is torch.distributed (backend "nccl" = RCCL over xGMI on ROCm, "gloo" in the CPU tests)
-issued on the same stream the kernels run on.
+Ownership goes by units (one column strip of one cube side at the granularity of the coarsest LOD the main kernel
+produces): planar jobs shard into `world` equal column blocks (one in-place all-gather per LOD), the 6-face cube job
+into 24 units, 24 / world per rank (one in-place broadcast per contiguous piece).  Either way the exchange of a step
+is ONE grouped collective issued by the library on the kernels' stream through its own RCCL communicator
+(bt_preprocessor_run_sharded, `collective="library"`); `collective="torch"` issues the same pieces through
+torch.distributed instead (backend "nccl" = RCCL, or "gloo" in the CPU / single-GPU tests).
 """
 from __future__ import annotations
 
@@ -40,6 +44,22 @@ def shard_ranges(pre: Preprocessor) -> List[dict]:
                  first_layer=out[i].first_layer, layers_per_rank=out[i].layers_per_rank) for i in range(min(n.value, 64))]
 
 
+def shard_pieces(pre: Preprocessor) -> List[dict]:
+    n = C.c_uint32()
+    _ffi.check(_ffi.lib().bt_preprocessor_shard_pieces(pre._h, None, 0, C.byref(n)))
+    out = (_ffi.ShardPieceC * max(n.value, 1))()
+    _ffi.check(_ffi.lib().bt_preprocessor_shard_pieces(pre._h, out, n.value, C.byref(n)))
+    return [dict(attachment_index=out[i].attachment_index, side=out[i].side, lod=out[i].lod, first_layer=out[i].first_layer,
+                 layers=out[i].layers, owner_rank=out[i].owner_rank) for i in range(n.value)]
+
+
+def broadcast_pieces(storage, tile_bytes: int, pieces: List[dict], dist, group=None):
+    """In-place broadcast of every piece from its owner over `storage` (a flat uint8 torch tensor, CPU or GPU)."""
+    for p in pieces:
+        first = p["first_layer"] * tile_bytes
+        dist.broadcast(storage[first:first + p["layers"] * tile_bytes], src=p["owner_rank"], group=group)
+
+
 def all_gather_ranges(storage, tile_bytes: int, ranges: List[dict], rank: int, world: int, dist, group=None):
     """In-place all-gather of every range over `storage` (a flat uint8 torch tensor, CPU or GPU)."""
     for r in ranges:
@@ -51,41 +71,77 @@ def all_gather_ranges(storage, tile_bytes: int, ranges: List[dict], rank: int, w
 
 
 class ShardedPreprocess:
-    """One sharded preprocess job: `step()` = local kernels -> all-gathers -> finishing kernels."""
+    """One sharded preprocess job: `step()` = local kernels -> the exchange -> finishing kernels.
+    `path`: a source path (planar, preprocess_tile) or a list of six (cube, preprocess_spherical)."""
 
-    def __init__(self, pre: Preprocessor, tile_atlas: TileAtlas, asset_server: AssetServer, path: str, lod_range: range,
-                 rank: int, world: int, *, attachment_index: int = 0, generic: bool = False):
+    def __init__(self, pre: Preprocessor, tile_atlas: TileAtlas, asset_server: AssetServer, path, lod_range: range,
+                 rank: int, world: int, *, attachment_index: int = 0, generic: bool = False, collective: str = "torch"):
         import torch
         import torch.distributed as dist
 
+        from .preprocess import SphericalDataset
+
         self.pre, self.atlas, self.rank, self.world = pre, tile_atlas, rank, world
         self.dist = dist
+        self.collective = collective
         self.flags = (_ffi.RUN_GENERIC if generic else 0) | _ffi.RUN_KEEP_QUEUE
-        pre.preprocess_tile(PreprocessDataset(attachment_index=attachment_index, path=path, lod_range=lod_range),
-                            asset_server, tile_atlas)
+        if isinstance(path, (list, tuple)):
+            pre.preprocess_spherical(SphericalDataset(attachment_index=attachment_index, paths=list(path), lod_range=lod_range),
+                                     asset_server, tile_atlas)
+        else:
+            pre.preprocess_tile(PreprocessDataset(attachment_index=attachment_index, path=path, lod_range=lod_range),
+                                asset_server, tile_atlas)
         _ffi.check(_ffi.lib().bt_preprocessor_set_shard(pre._handle(tile_atlas), rank, world))
         ptr, tile_bytes, layers = tile_atlas.attachment_storage(attachment_index)
         self.tile_bytes = tile_bytes
         self.storage = torch.as_tensor(_DeviceBytes(ptr, tile_bytes * layers), device=f"cuda:{tile_atlas.device.index}")
         self.stream = tile_atlas.device.torch_stream
         self._ranges: Optional[List[dict]] = None
+        self._pieces: Optional[List[dict]] = None
         self.gather_bytes = 0
+        self._comm = None
+        if collective == "library":
+            # the library's own RCCL communicator: rank 0 draws the unique id, torch.distributed only ships it
+            uid = (C.c_uint8 * 128)()
+            if rank == 0:
+                _ffi.check(_ffi.lib().bt_comm_unique_id(uid))
+            box = [bytes(uid)]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            h = C.c_void_p()
+            _ffi.check(_ffi.lib().bt_comm_create(tile_atlas.device._h, world, rank, uid, C.byref(h)))
+            self._comm = h
 
     def _run(self, flags):
         _ffi.check(_ffi.lib().bt_preprocessor_run(self.pre._h, self.atlas._h, self.flags | flags))
+
+    def _layout(self):
+        if self._pieces is None:
+            self._ranges = shard_ranges(self.pre)
+            self._pieces = shard_pieces(self.pre)
+            self.gather_bytes = sum(p["layers"] * self.tile_bytes for p in self._pieces)
 
     def step(self, profile: bool = False, gather: bool = True):
         """gather=False skips the collectives (timing of the kernels alone; the atlas is then incomplete)."""
         import torch
 
         p = _ffi.RUN_PROFILE if profile else 0
+        if self._comm is not None:
+            flags = self.flags | p | (0 if gather else _ffi.RUN_SHARD_LOCAL)
+            _ffi.check(_ffi.lib().bt_preprocessor_run_sharded(self.pre._h, self.atlas._h, self._comm, flags))
+            if not gather and self.world > 1:
+                self._run(_ffi.RUN_SHARD_FINISH)
+            self._layout()
+            return
         self._run(_ffi.RUN_SHARD_LOCAL | p)
-        if self._ranges is None:
-            self._ranges = shard_ranges(self.pre)
-            self.gather_bytes = sum(r["layers_per_rank"] * self.world * self.tile_bytes for r in self._ranges)
+        self._layout()
         if gather:
             with torch.cuda.stream(self.stream):  # same queue as the kernels: ordered without host syncs
-                all_gather_ranges(self.storage, self.tile_bytes, self._ranges, self.rank, self.world, self.dist)
+                if self._ranges:
+                    all_gather_ranges(self.storage, self.tile_bytes, self._ranges, self.rank, self.world, self.dist)
+                else:
+                    broadcast_pieces(self.storage, self.tile_bytes, self._pieces, self.dist)
         self._run(_ffi.RUN_SHARD_FINISH)
 
     def stats(self):
@@ -93,3 +149,8 @@ class ShardedPreprocess:
 
     def profile(self):
         return self.pre.profile()
+
+    def close(self):
+        if self._comm is not None:
+            _ffi.lib().bt_comm_destroy(self._comm)
+            self._comm = None

@@ -272,8 +272,38 @@ typedef struct bt_shard_range {
     uint32_t layers_per_rank; /* contiguous layers owned by each rank */
 } bt_shard_range;
 bt_status bt_preprocessor_set_shard(bt_preprocessor* p, uint32_t rank, uint32_t world);
-/* valid after the first run of the current queue; *count = 0 means "not sharded: every rank computed everything" */
+/* valid after the first run of the current queue; *count = 0 means "not sharded: every rank computed everything"
+ * (or: sharded, but not the regular one-side layout — see bt_preprocessor_shard_pieces) */
 bt_status bt_preprocessor_shard_ranges(const bt_preprocessor* p, bt_shard_range* out, uint32_t cap, uint32_t* count);
+/* The general form of the exchange (planar AND cube jobs): ownership goes by UNITS — one column strip of one cube side
+ * at the granularity of the coarsest LOD the main kernel produces, numbered side-major, `units / world` consecutive
+ * units per rank (a job shards iff world divides the unit count: 16k planar 8 units, the 6-face cube job 24).  Every
+ * piece is a run of consecutive atlas layers computed by `owner_rank` alone; after BT_RUN_SHARD_LOCAL each piece is
+ * broadcast in place from its owner (all pieces inside ONE ncclGroupStart / ncclGroupEnd), then BT_RUN_SHARD_FINISH. */
+typedef struct bt_shard_piece {
+    uint32_t attachment_index, side, lod;
+    uint32_t first_layer, layers;
+    uint32_t owner_rank;
+} bt_shard_piece;
+bt_status bt_preprocessor_shard_pieces(const bt_preprocessor* p, bt_shard_piece* out, uint32_t cap, uint32_t* count);
+
+/* RCCL communicator of the sharded path (new design; `backend "nccl"` IS RCCL on ROCm).  The library resolves the RCCL
+ * entry points at run time (the librccl already in the process, else librccl.so.1) — no link-time dependency, and a
+ * host that owns an ncclComm_t can hand it over with bt_comm_adopt. */
+#define BT_COMM_UNIQUE_ID_BYTES 128
+typedef struct bt_comm bt_comm;
+bt_status bt_comm_unique_id(uint8_t out[BT_COMM_UNIQUE_ID_BYTES]); /* ncclGetUniqueId: call on rank 0, ship to the others */
+bt_status bt_comm_create(bt_ctx* ctx, uint32_t world, uint32_t rank, const uint8_t unique_id[BT_COMM_UNIQUE_ID_BYTES], bt_comm** out);
+bt_status bt_comm_adopt(bt_ctx* ctx, void* nccl_comm, uint32_t world, uint32_t rank, bt_comm** out); /* borrowed ncclComm_t */
+void bt_comm_destroy(bt_comm* comm);
+/* health check: a small grouped in-place all-gather + broadcast through the communicator, verified on the host */
+bt_status bt_comm_check(bt_comm* comm);
+/* One step of a sharded job, entirely on the context's stream and without host synchronisation: this rank's strip
+ * (BT_RUN_SHARD_LOCAL), ONE grouped collective (in-place ncclAllGather per LOD for the regular planar layout, in-place
+ * ncclBroadcast per piece otherwise, between ncclGroupStart and ncclGroupEnd), the finishing kernels
+ * (BT_RUN_SHARD_FINISH).  `flags`: BT_RUN_GENERIC / BT_RUN_KEEP_QUEUE / BT_RUN_PROFILE, and BT_RUN_SHARD_LOCAL alone to
+ * skip the collective and the finish (kernel-only timing).  set_shard(rank, world) must match the communicator. */
+bt_status bt_preprocessor_run_sharded(bt_preprocessor* p, bt_atlas* atlas, bt_comm* comm, uint32_t flags);
 
 /* Per-launch device time of the runs made with BT_RUN_PROFILE since the last call (hipEvents on the
  * context's stream, averaged over those runs).  `kind`: 0 split, 1 downsample, 2 stitch, 3 fused main,

@@ -190,3 +190,196 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["collective_backend"] == "gloo"
     assert line["verify_vs_oracle"] == {"tiles": 1365, "identical": 1365, "index_contract": True}
     assert "cpu_baseline" not in line
+
+
+def _unit_pieces(tiles, sides, lod_hi, world):
+    """The exchange layout from the atlas-index contract alone: units = sides x strips (strip = one column of LOD
+    lod_hi - 2), units / world consecutive units per rank, one piece per maximal run of strips with one owner."""
+    index = {c: i for c, i in tiles}
+    strips = 1 << (lod_hi - 2)
+    per_rank = sides * strips // world
+    pieces = []
+    for side in range(sides):
+        for lod in (lod_hi, lod_hi - 1, lod_hi - 2):
+            n = 1 << lod
+            cols = n // strips
+            strip = 0
+            while strip < strips:
+                owner = (side * strips + strip) // per_rank
+                end = strip + 1
+                while end < strips and (side * strips + end) // per_rank == owner:
+                    end += 1
+                pieces.append(dict(side=side, lod=lod, first_layer=index[(side, lod, strip * cols, 0)], layers=(end - strip) * cols * n, owner_rank=owner))
+                strip = end
+    return pieces
+
+
+def _gloo_broadcast_worker(rank, world, port, tile_bytes, layers, pieces, full, result_queue):
+    import torch
+    import torch.distributed as dist
+
+    from bevy_terrain_amd.shard import broadcast_pieces
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    storage = torch.zeros(layers * tile_bytes, dtype=torch.uint8)
+    full_t = torch.from_numpy(full.reshape(-1))
+    covered = np.zeros(layers, bool)
+    for p in pieces:
+        lo, hi = p["first_layer"] * tile_bytes, (p["first_layer"] + p["layers"]) * tile_bytes
+        covered[p["first_layer"]:p["first_layer"] + p["layers"]] = True
+        if p["owner_rank"] == rank:  # this rank only holds what it computed
+            storage[lo:hi] = full_t[lo:hi]
+    broadcast_pieces(storage, tile_bytes, pieces, dist)
+    ok = all(torch.equal(storage[l * tile_bytes:(l + 1) * tile_bytes], full_t[l * tile_bytes:(l + 1) * tile_bytes]) for l in range(layers) if covered[l])
+    untouched = all(bool((storage[l * tile_bytes:(l + 1) * tile_bytes] == 0).all()) for l in range(layers) if not covered[l])
+    result_queue.put((rank, ok, untouched))
+    dist.destroy_process_group()
+
+
+def test_cube_piece_layout_and_broadcast_gloo_world2():
+    """The cube job's exchange (24 units, irregular: a rank's units span faces) as in-place broadcasts over a gloo
+    group of 2 processes; the layout is derived here from the atlas-index contract (oracle queue), not from the library."""
+    import torch.multiprocessing as mp
+
+    T, b, lod_count, world = 8, 2, 4, 2
+    faces = [K.random_raster(O.FORMAT_R16, 40, 40, seed=80 + s) for s in range(6)]
+    oracle = O.OracleAtlas(lod_count, 6 * 85, True, [(T, b, 1, O.FORMAT_R16)])
+    oracle.preprocess_spherical(0, faces, (0, lod_count)).run(2)
+    tiles = oracle.tiles()
+    layers = len(tiles)
+    full = np.stack([oracle.tile(0, i) for _, i in tiles]).view(np.uint8)
+    pieces = _unit_pieces(tiles, 6, lod_count - 1, world)
+    # every tile of the three finest LODs is in exactly one piece, and a piece's layers are its owner's columns
+    seen = np.zeros(layers, int)
+    for p in pieces:
+        seen[p["first_layer"]:p["first_layer"] + p["layers"]] += 1
+        n, strips = 1 << p["lod"], 1 << (lod_count - 3)
+        for k in range(p["layers"]):
+            side, lod, x, y = tiles[p["first_layer"] + k][0]
+            assert (side, lod) == (p["side"], p["lod"])
+            assert (side * strips + x // (n // strips)) // (6 * strips // world) == p["owner_rank"]
+    assert all(seen[i] == (1 if tiles[i][0][1] >= 1 else 0) for i in range(layers))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_broadcast_worker, args=(rank, world, port, T * T * 2, layers, pieces, full, q)) for rank in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, True, True), (1, True, True)]
+
+
+def _emulate_ranks(device, world, make_job, n_tiles, oracle, lod_hi, T, b, sides=1):
+    """A true multi-rank emulation on one device: every rank gets its OWN atlas and runs BT_RUN_SHARD_LOCAL; rank 0's
+    atlas then receives every piece from its owner's atlas (what the in-place broadcast does) and runs
+    BT_RUN_SHARD_FINISH.  Before the exchange a rank's pieces must already hold finished centres (and, at the finest
+    LOD, finished tiles): nobody else computes them."""
+    import bevy_terrain_amd as bt
+    from bevy_terrain_amd import _ffi
+    from bevy_terrain_amd.shard import shard_pieces
+
+    L = _ffi.lib()
+    jobs = []
+    for rank in range(world):
+        atlas, pre = make_job()
+        _ffi.check(L.bt_preprocessor_set_shard(pre._h, rank, world))
+        _ffi.check(L.bt_preprocessor_run(pre._h, atlas._h, _ffi.RUN_KEEP_QUEUE | _ffi.RUN_SHARD_LOCAL))
+        jobs.append((atlas, pre))
+    device.synchronize()
+    pieces = shard_pieces(jobs[0][1])
+    assert pieces and all(shard_pieces(pre) == pieces for _, pre in jobs)
+    coords = {i: c for c, i in oracle.tiles()}
+    c = T - 2 * b
+    for p in pieces:
+        data = jobs[p["owner_rank"]][0].download_tiles(0, p["first_layer"], p["layers"])
+        for k in range(0, p["layers"], max(1, p["layers"] // 9)):
+            exp = oracle.tile(0, p["first_layer"] + k)
+            side, lod, x, y = coords[p["first_layer"] + k]
+            on_face_edge = x in (0, (1 << lod) - 1) or y in (0, (1 << lod) - 1)
+            if p["lod"] == lod_hi and not (sides == 6 and on_face_edge):  # (cube seams are stitched after the exchange)
+                assert np.array_equal(data[k], exp), (p, coords[p["first_layer"] + k])
+            else:
+                assert np.array_equal(data[k][b:b + c, b:b + c], exp[b:b + c, b:b + c]), (p, coords[p["first_layer"] + k])
+        if p["owner_rank"] != 0:  # the broadcast, by hand
+            for k in range(p["layers"]):
+                jobs[0][0].upload_tile(0, p["first_layer"] + k, data[k])
+    atlas0, pre0 = jobs[0]
+    _ffi.check(L.bt_preprocessor_run(pre0._h, atlas0._h, _ffi.RUN_KEEP_QUEUE | _ffi.RUN_SHARD_FINISH))
+    device.synchronize()
+    assert K.assert_atlas_equal(atlas0, oracle) == n_tiles
+    return pieces
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_cube_job_sharded_over_emulated_ranks(world):
+    """BASELINE config 5's shape (6 faces, lod_count 5 -> 2046 tiles) at T = 32: 24 units, 24 / world per rank."""
+    import bevy_terrain_amd as bt
+
+    device = bt.Device(0)
+    T, b, lods, W = 32, 2, 5, 470
+    faces = [K.random_raster(O.FORMAT_R16, W, W, seed=90 + s, holes=0.003) for s in range(6)]
+    paths = [f"face{s}" for s in range(6)]
+
+    def make_job():
+        cfg = bt.TerrainConfig(lod_count=lods, atlas_size=2048, path="terrains/spherical")
+        cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=T, border_size=b, format=bt.AttachmentFormat.R16))
+        atlas = bt.TileAtlas.new(cfg, device)
+        server = bt.AssetServer()
+        for p, f in zip(paths, faces):
+            server.insert(p, f)
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_spherical(
+            bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lods)), server, atlas)
+        return atlas, pre
+
+    oracle = O.OracleAtlas(lods, 2048, True, [(T, b, 1, O.FORMAT_R16)])
+    oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(os.cpu_count() or 8)
+    pieces = _emulate_ranks(device, world, make_job, 2046, oracle, lods - 1, T, b, sides=6)
+    assert pieces == [dict(p, attachment_index=0) for p in _unit_pieces(oracle.tiles(), 6, lods - 1, world)]
+    assert len({p["owner_rank"] for p in pieces}) == world
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_planar_job_sharded_over_emulated_ranks(world):
+    import bevy_terrain_amd as bt
+
+    device = bt.Device(0)
+    T, b, lods = 64, 2, 6
+    src = K.random_raster(O.FORMAT_R16, 1100, 1100, seed=35, holes=0.01)
+
+    def make_job():
+        cfg = bt.TerrainConfig(lod_count=lods, atlas_size=2048, path="t", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+        cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=T, border_size=b))
+        atlas = bt.TileAtlas.new(cfg, device)
+        pre = bt.Preprocessor.new().preprocess_tile(bt.PreprocessDataset(path="s", lod_range=range(0, lods)), bt.AssetServer().insert("s", src), atlas)
+        return atlas, pre
+
+    oracle = K.oracle_planar(src, lods, T, b, O.FORMAT_R16, atlas_size=2048)
+    pieces = _emulate_ranks(device, world, make_job, 1365, oracle, lods - 1, T, b)
+    assert len(pieces) == 3 * world
+
+
+@pytest.mark.gpu
+def test_library_issued_collective_single_rank():
+    """bt_preprocessor_run_sharded through the library's own RCCL communicator (bt_comm_unique_id / bt_comm_create): a
+    world of one rank is all a 1-GPU box can form, but it is the code path bench.py --gpus N drives on 8."""
+    import bevy_terrain_amd as bt
+    from bevy_terrain_amd.shard import ShardedPreprocess
+
+    device = bt.Device(0)
+    src = K.random_raster(O.FORMAT_R16, 1100, 1100, seed=36)
+    cfg = bt.TerrainConfig(lod_count=4, atlas_size=128, path="t", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=128, border_size=2))
+    atlas = bt.TileAtlas.new(cfg, device)
+    job = ShardedPreprocess(bt.Preprocessor.new(), atlas, bt.AssetServer().insert("s", src), "s", range(0, 4), 0, 1, collective="library")
+    bt._ffi.check(bt._ffi.lib().bt_comm_check(job._comm))  # grouped ncclAllGather + ncclBroadcast through the communicator
+    job.step()
+    job.step(profile=True)
+    device.synchronize()
+    job.close()
+    assert K.assert_atlas_equal(atlas, K.oracle_planar(src, 4, 128, 2, O.FORMAT_R16, atlas_size=128)) == 85
