@@ -25,6 +25,7 @@
 // r = RN(1/65535) (Markstein's correctly rounded division); equality with `/` for all 65536 inputs is
 // checked on the device by bt_selftest() and on the CPU by tests/test_oracle_preprocess.py.
 #include <cstdlib>
+#include <type_traits>
 
 #include "bt_internal.hpp"
 
@@ -139,13 +140,13 @@ __device__ __forceinline__ TileNb load_tile_nb(const FusedArgs& A, uint32_t side
 //  - the tile's own apron where the neighbour on that side is absent (repeat_data clamps into the centre),
 //  - the facing apron of each existing neighbour whose b-wide strip contains the pixel.
 // Neighbours are looked up only for the few pixels within b of a tile edge.
-template <bool kCentre = true>
+template <bool kCentre = true, typename TT = uint16_t>
 __device__ __forceinline__ void push_pixel(const FusedArgs& A, uint32_t side, uint32_t lod, uint32_t tx, uint32_t ty,
-                                           uint32_t self_index, uint32_t cx, uint32_t cy, uint16_t v) {
+                                           uint32_t self_index, uint32_t cx, uint32_t cy, TT v) {
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
     const uint64_t tile_texels = uint64_t(T) * T;
-    uint16_t* atlas = A.atlas;
-    uint16_t* self = atlas + uint64_t(self_index) * tile_texels;
+    TT* atlas = reinterpret_cast<TT*>(A.atlas);
+    TT* self = atlas + uint64_t(self_index) * tile_texels;
     if (kCentre) self[uint64_t(b + cy) * T + b + cx] = v;  // (false: the caller stored the centre texel, e.g. as half of a pair)
     const int ex = cx < b ? -1 : (cx >= c - b ? 1 : 0);
     const int ey = cy < b ? -1 : (cy >= c - b ? 1 : 0);
@@ -198,6 +199,47 @@ __device__ __forceinline__ uint32_t downsample4(uint32_t t00, uint32_t t01, uint
     if (t11 != 0) { value += unorm16_to_float(t11); count += 1.0f; }
     if (count == 0.0f) return 0;
     return float_to_unorm16(value / count);
+}
+
+// the same for packed Rgba8 texels: a texel counts when any of r, g, b is non-zero (downsample.wgsl:31), all four
+// channels are averaged; operation order of bt_kernels.hip downsample_texel<BT_FORMAT_RGBA8>
+__device__ __forceinline__ float unorm8_to_float(uint32_t t) {
+    const float x = float(t), r = 1.0f / 255.0f;
+    const float q0 = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-q0, 255.0f, x), r, q0);
+}
+__device__ __forceinline__ uint32_t downsample4_rgba8(uint32_t t00, uint32_t t01, uint32_t t10, uint32_t t11) {
+    const uint32_t t[4] = {t00, t01, t10, t11};
+    if ((t00 & 0x00FFFFFFu) != 0 && (t01 & 0x00FFFFFFu) != 0 && (t10 & 0x00FFFFFFu) != 0 && (t11 & 0x00FFFFFFu) != 0) {
+        // all four count (the common case): ((((0 + a) + b) + c) + d) / 4, and x / 4 == x * 0.25 exactly; the sum of four
+        // values in [0, 1] stays in [0, 4], so the clamp of pack4x8unorm is a no-op
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t sh = 8 * k;
+            const float sum = ((unorm8_to_float((t00 >> sh) & 0xFFu) + unorm8_to_float((t01 >> sh) & 0xFFu)) + unorm8_to_float((t10 >> sh) & 0xFFu)) +
+                              unorm8_to_float((t11 >> sh) & 0xFFu);
+            out |= uint32_t(0.5f + 255.0f * (sum * 0.25f)) << sh;
+        }
+        return out;
+    }
+    float value[4] = {0.0f, 0.0f, 0.0f, 0.0f}, count = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if ((t[i] & 0x00FFFFFFu) != 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) value[k] += unorm8_to_float((t[i] >> (8 * k)) & 0xFFu);
+            count += 1.0f;
+        }
+    if (count == 0.0f) return 0;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float e = value[k] / count;
+        const float cl = e < 0.0f ? 0.0f : (e > 1.0f ? 1.0f : e);
+        out |= uint32_t(floorf(0.5f + 255.0f * cl)) << (8 * k);
+    }
+    return out;
 }
 
 // general (slow) evaluation of the finest-LOD mosaic pixel (tile, r) from the source; used for the
@@ -924,8 +966,11 @@ __device__ __forceinline__ void tail_apron_rows(const FusedArgs& A, uint32_t sid
     }
 }
 
+template <uint32_t kFormat>
 __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
-    {
+    constexpr bool kR16 = kFormat == BT_FORMAT_R16;
+    using TT = typename std::conditional<kR16, uint16_t, uint32_t>::type;  // texel
+    if constexpr (kR16) {
         const uint32_t extent = (1u << A.lod) * A.m.center_size, ny = (extent + 63u) / 64u;
         if (blockIdx.y >= ny) {  // workgroups past the mosaic: apron rows
             tail_apron_rows(A, blockIdx.z, (blockIdx.y - ny) * gridDim.x + blockIdx.x);
@@ -939,6 +984,11 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
     const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
     const uint32_t gx = blockIdx.x * 64u + 4u * tx, gy = blockIdx.y * 64u + 4u * ty;  // first input pixel
     const bool active = gx < size && gy < size;
+    TT* atlas = reinterpret_cast<TT*>(A.atlas);
+    auto down = [](uint32_t t00, uint32_t t01, uint32_t t10, uint32_t t11) -> uint32_t {
+        if constexpr (kR16) return downsample4(t00, t01, t10, t11);
+        else return downsample4_rgba8(t00, t01, t10, t11);
+    };
 
     uint32_t t[4][4];  // [row][col]
 #pragma unroll
@@ -955,14 +1005,27 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
     }
     if (active) {
         if (idx != kInvalid) {  // an absent tile reads as no data
-            const uint16_t* p = A.atlas + uint64_t(idx) * tile_texels + (b + gy % c) * T + b + gx % c;  // 4-byte aligned (b even)
+            const TT* p = atlas + uint64_t(idx) * tile_texels + (b + gy % c) * T + b + gx % c;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint32_t lo = *reinterpret_cast<const uint32_t*>(p + r * T), hi = *reinterpret_cast<const uint32_t*>(p + r * T + 2);
-                t[r][0] = lo & 0xFFFFu;
-                t[r][1] = lo >> 16;
-                t[r][2] = hi & 0xFFFFu;
-                t[r][3] = hi >> 16;
+                if constexpr (kR16) {  // 4-byte aligned (b even)
+                    const uint32_t lo = *reinterpret_cast<const uint32_t*>(p + r * T), hi = *reinterpret_cast<const uint32_t*>(p + r * T + 2);
+                    t[r][0] = lo & 0xFFFFu;
+                    t[r][1] = lo >> 16;
+                    t[r][2] = hi & 0xFFFFu;
+                    t[r][3] = hi >> 16;
+                } else {  // 8-byte aligned (b even or not: (b + 4k) texels of 4 bytes; pairs need b even) — two texels per load
+                    if ((b & 1u) == 0) {
+                        const uint2 lo = *reinterpret_cast<const uint2*>(p + r * T), hi = *reinterpret_cast<const uint2*>(p + r * T + 2);
+                        t[r][0] = lo.x;
+                        t[r][1] = lo.y;
+                        t[r][2] = hi.x;
+                        t[r][3] = hi.y;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) t[r][k] = p[r * T + k];
+                    }
+                }
             }
         }
     }
@@ -971,36 +1034,41 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
 #pragma unroll
     for (int r = 0; r < 2; r++)
 #pragma unroll
-        for (int k = 0; k < 2; k++) q[r][k] = downsample4(t[2 * r][2 * k], t[2 * r + 1][2 * k], t[2 * r][2 * k + 1], t[2 * r + 1][2 * k + 1]);
+        for (int k = 0; k < 2; k++) q[r][k] = down(t[2 * r][2 * k], t[2 * r + 1][2 * k], t[2 * r][2 * k + 1], t[2 * r + 1][2 * k + 1]);
     if (active) {
         const uint32_t x1 = gx >> 1, y1 = gy >> 1;
         const uint32_t self = self1;
         if (self != kInvalid) {
-            // the two pixels of a row are one aligned dword of the tile (x1, b, c even); aprons per pixel, edge pixels only
-            uint16_t* centre = A.atlas + uint64_t(self) * tile_texels + (b + y1 % c) * T + b + x1 % c;
+            // R16: the two pixels of a row are one aligned dword of the tile (x1, b, c even); aprons per pixel, edge pixels only
+            TT* centre = atlas + uint64_t(self) * tile_texels + (b + y1 % c) * T + b + x1 % c;
 #pragma unroll
             for (int r = 0; r < 2; r++) {
-                *reinterpret_cast<uint32_t*>(centre + r * T) = q[r][0] | (q[r][1] << 16);
+                if constexpr (kR16) {
+                    *reinterpret_cast<uint32_t*>(centre + r * T) = q[r][0] | (q[r][1] << 16);
+                } else {
+                    centre[r * T] = q[r][0];
+                    centre[r * T + 1] = q[r][1];
+                }
 #pragma unroll
-                for (int k = 0; k < 2; k++) push_pixel<false>(A, side, A.lod - 1, x1 / c, y1 / c, self, x1 % c + k, y1 % c + r, uint16_t(q[r][k]));
+                for (int k = 0; k < 2; k++) push_pixel<false, TT>(A, side, A.lod - 1, x1 / c, y1 / c, self, x1 % c + k, y1 % c + r, TT(q[r][k]));
             }
         }
     }
     if (A.levels < 2) return;
-    const uint32_t v2 = downsample4(q[0][0], q[1][0], q[0][1], q[1][1]);
+    const uint32_t v2 = down(q[0][0], q[1][0], q[0][1], q[1][1]);
     if (active) {
         const uint32_t x2 = gx >> 2, y2 = gy >> 2;
         const uint32_t self = self2;
-        if (self != kInvalid) push_pixel(A, side, A.lod - 2, x2 / c, y2 / c, self, x2 % c, y2 % c, uint16_t(v2));
+        if (self != kInvalid) push_pixel<true, TT>(A, side, A.lod - 2, x2 / c, y2 / c, self, x2 % c, y2 % c, TT(v2));
     }
     if (A.levels < 3) return;
     // lod-3: threads (tx, ty) with both even own the pixel; partners are lanes +1 (dx), +16 (dy), +17
     const uint32_t right = __shfl_down(v2, 1), below = __shfl_down(v2, 16), diag = __shfl_down(v2, 17);
     if (active && ((tx | ty) & 1u) == 0) {
-        const uint32_t v3 = downsample4(v2, below, right, diag);
+        const uint32_t v3 = down(v2, below, right, diag);
         const uint32_t x3 = gx >> 3, y3 = gy >> 3;
         const uint32_t self = self3;
-        if (self != kInvalid) push_pixel(A, side, A.lod - 3, x3 / c, y3 / c, self, x3 % c, y3 % c, uint16_t(v3));
+        if (self != kInvalid) push_pixel<true, TT>(A, side, A.lod - 3, x3 / c, y3 / c, self, x3 % c, y3 % c, TT(v3));
     }
 }
 
@@ -1091,9 +1159,14 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         const uint32_t ai = splits[0]->attachment_index;
         const Attachment& at = a->attachments[ai];
         const AttachmentMeta& m = at.meta;
-        if (m.format != BT_FORMAT_R16 || m.texture_size > 512 || (m.border_size & 1u) || (m.center_size & 3u) ||
-            m.center_size < 2 * m.border_size || m.border_size == 0 || m.border_size > 8)
-            return false;
+        // fused_main: R16, T <= 512, even b <= 8.  Otherwise (Rgba8, large tiles, odd borders) the HYBRID plan: the batched
+        // split + stitch kernels produce the finest LOD, fused_tail (format-generic) everything below it, three LODs per
+        // launch, aprons pushed — instead of one downsample launch per LOD and a stitch over every tile.
+        const bool tail_ok = (m.format == BT_FORMAT_R16 || m.format == BT_FORMAT_RGBA8) && (m.center_size & 3u) == 0 &&
+                             m.center_size >= 2 * m.border_size && m.border_size != 0 && (m.format != BT_FORMAT_R16 || (m.border_size & 1u) == 0);
+        const bool main_ok = tail_ok && m.format == BT_FORMAT_R16 && m.texture_size <= 512 && m.border_size <= 8;
+        if (!tail_ok) return false;
+        const bool hybrid = !main_ok;
         // the kernels keep texel offsets into the atlas in 32 bits
         if (uint64_t(a->config.atlas_size) * m.texture_size * m.texture_size >= (1ull << 32)) return false;
         const uint32_t lod_hi = splits[0]->coord.lod;
@@ -1160,7 +1233,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         const uint32_t world = p->shard_world, rank = p->shard_rank;
         const uint32_t nlods_all = lod_hi - lod_lo + 1, main_levels_all = std::min(3u, nlods_all);
         const uint32_t strips = 1u << (lod_hi - (main_levels_all - 1)), units = sides * strips;
-        bool shard = world > 1 && units % world == 0;
+        bool shard = world > 1 && units % world == 0 && !hybrid;
         std::vector<bt_shard_range> ranges;
         std::vector<bt_shard_piece> pieces;
         if (shard) {
@@ -1236,7 +1309,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         if (upload_vector(p, items, &args.items) || upload_vector(p, grids, &args.grids) || upload_vector(p, grid_offsets, &args.grid_offsets))
             return false;
 
-        const uint64_t bpp = 2, Tt = m.texture_size, cc = m.center_size;
+        const uint64_t bpp = m.pixel_size, Tt = m.texture_size, cc = m.center_size;
         uint64_t source_bytes = 0;
         {
             std::vector<bool> seen(p->rasters.size(), false);
@@ -1257,7 +1330,44 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
 
         // main launch: finest LOD + up to two more
         const uint32_t nlods = lod_hi - lod_lo + 1;
-        const uint32_t main_levels = std::min(3u, nlods);
+        const uint32_t main_levels = hybrid ? 1u : std::min(3u, nlods);
+        auto device_task = [](const Task& t) {
+            TaskDev d{};
+            d.atlas_index = t.atlas_index;
+            d.side = t.coord.side;
+            d.lod = t.coord.lod;
+            d.x = t.coord.x;
+            d.y = t.coord.y;
+            d.tlx = t.tl[0];
+            d.tly = t.tl[1];
+            d.brx = t.br[0];
+            d.bry = t.br[1];
+            d.raster = t.raster < 0 ? 0u : uint32_t(t.raster);
+            for (int i = 0; i < 8; i++) {
+                d.rel_index[i] = t.rel[i].atlas_index;
+                d.rel_side[i] = t.rel[i].coordinate.side;
+            }
+            return d;
+        };
+        if (hybrid) {
+            Launch ls{};
+            ls.kind = kLaunchSplit;
+            ls.attachment = ai;
+            ls.first_task = uint32_t(tasks.size());
+            for (const Task* t : splits) tasks.push_back(device_task(*t));
+            ls.task_count = uint32_t(splits.size());
+            ls.algorithmic_bytes = source_bytes + uint64_t(splits.size()) * Tt * Tt * bpp;
+            plan.push_back(ls);
+            Launch lt{};
+            lt.kind = kLaunchStitch;
+            lt.attachment = ai;
+            lt.first_task = uint32_t(tasks.size());
+            for (const Task* t : stitches)
+                if (t->coord.lod == lod_hi) tasks.push_back(device_task(*t));
+            lt.task_count = uint32_t(tasks.size()) - lt.first_task;
+            lt.algorithmic_bytes = uint64_t(lt.task_count) * 2 * (2 * m.border_size * (Tt + cc)) * bpp;
+            if (lt.task_count) plan.push_back(lt);
+        } else {
         FusedJobDev main_job{args, ai};
 #ifdef BT_DEBUG_HOOKS
         if (const char* e = getenv("BT_FUSED_LDS_PAD")) main_job.lds_pad = uint32_t(atoi(e));
@@ -1336,6 +1446,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         for (uint32_t k = 0; k < main_levels; k++) lm.algorithmic_bytes += tiles_at(lod_hi - k) * Tt * Tt * bpp;
         jobs.push_back(main_job);
         plan.push_back(lm);
+        }
 
         const bool tail_follows = lod_hi - (main_levels - 1) > lod_lo;
         const bool rows_in_tail = !shard && tail_follows && main_levels > 1 && m.border_size % 2u == 0;
@@ -1405,6 +1516,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             for (const Task* t : stitches) {
                 const uint32_t n = 1u << t->coord.lod;
                 if (t->coord.x != 0 && t->coord.y != 0 && t->coord.x != n - 1 && t->coord.y != n - 1) continue;
+                if (hybrid && t->coord.lod == lod_hi) continue;  // stitched completely by the batched kernel above
                 TaskDev d{};
                 d.atlas_index = t->atlas_index;
                 d.side = t->coord.side;
@@ -1467,7 +1579,8 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
             for (uint32_t k = 0; k < job.args.apron_lods; k++) extra += (1ull << (2 * (job.args.lod + k))) * blocks_per_tile;
             grid.y += uint32_t((extra + grid.x - 1) / grid.x);
         }
-        fused_tail_kernel<<<grid, 256, 0, p->ctx->stream>>>(job.args);
+        if (job.args.m.format == BT_FORMAT_R16) fused_tail_kernel<BT_FORMAT_R16><<<grid, 256, 0, p->ctx->stream>>>(job.args);
+        else fused_tail_kernel<BT_FORMAT_RGBA8><<<grid, 256, 0, p->ctx->stream>>>(job.args);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "fused kernel launch");

@@ -88,32 +88,53 @@ __device__ __forceinline__ bool is_border(uint32_t px, uint32_t py, uint32_t b, 
 
 // ------------------------------------------------------------------------------------------ split
 
-// value of one centre pixel as a texel (u16 or packed rgba8); `previous` = the atlas texel before the task
-template <uint32_t FORMAT, typename P>
-__device__ __forceinline__ uint32_t split_texel(const RasterDev& r, const Axis& ax, const Axis& ay, const P* previous) {
-    const uint8_t* row0 = (const uint8_t*)r.data + uint64_t(ay.i0) * r.pitch;
-    const uint8_t* row1 = (const uint8_t*)r.data + uint64_t(ay.i1) * r.pitch;
+// The horizontal half of the bilinear filter for one column and one source row: mix(t(i0), t(i1), fx) per channel, and
+// whether both texels carry data (textureGather(0, ..) != 0 on channel 0, split.wgsl:34).  A source row is shared by two
+// consecutive output rows (its i1 is the next row's i0), so the sweep down a column keeps the last one.
+template <uint32_t FORMAT>
+struct HRow {
+    float h[FORMAT == BT_FORMAT_R16 ? 1 : 4];
+    bool valid;
+};
+
+// the two raw texels of a column in one source row (global address space: plain global_load, not flat)
+template <uint32_t FORMAT>
+__device__ __forceinline__ uint2 split_fetch(const RasterDev& r, const Axis& ax, int y) {
+    typedef const uint8_t __attribute__((address_space(1))) * global_bytes;
+    const global_bytes row = (global_bytes)r.data + uint64_t(y) * r.pitch;
     if constexpr (FORMAT == BT_FORMAT_R16) {
-        const uint32_t t00 = ((const uint16_t*)row0)[ax.i0], t10 = ((const uint16_t*)row0)[ax.i1];
-        const uint32_t t01 = ((const uint16_t*)row1)[ax.i0], t11 = ((const uint16_t*)row1)[ax.i1];
-        const bool valid = t00 != 0 && t10 != 0 && t01 != 0 && t11 != 0;  // textureGather(0, ..) != 0
-        if (!valid) return *previous;  // keep what the atlas holds (read only in this case)
-        const float top = mixf(unorm16_to_float(t00), unorm16_to_float(t10), ax.fr);
-        const float bot = mixf(unorm16_to_float(t01), unorm16_to_float(t11), ax.fr);
-        return float_to_unorm(mixf(top, bot, ay.fr), 65535.0f);
+        typedef const uint16_t __attribute__((address_space(1))) * global_u16;
+        return make_uint2(((global_u16)row)[ax.i0], ((global_u16)row)[ax.i1]);
     } else {
-        const uint32_t t00 = ((const uint32_t*)row0)[ax.i0], t10 = ((const uint32_t*)row0)[ax.i1];
-        const uint32_t t01 = ((const uint32_t*)row1)[ax.i0], t11 = ((const uint32_t*)row1)[ax.i1];
-        const bool valid = (t00 & 0xFFu) != 0 && (t10 & 0xFFu) != 0 && (t01 & 0xFFu) != 0 && (t11 & 0xFFu) != 0;
-        if (!valid) return *previous;  // keep what the atlas holds (read only in this case)
+        typedef const uint32_t __attribute__((address_space(1))) * global_u32;
+        return make_uint2(((global_u32)row)[ax.i0], ((global_u32)row)[ax.i1]);
+    }
+}
+
+template <uint32_t FORMAT>
+__device__ __forceinline__ HRow<FORMAT> split_hrow(uint2 t, float fx) {
+    HRow<FORMAT> o;
+    if constexpr (FORMAT == BT_FORMAT_R16) {
+        o.valid = t.x != 0 && t.y != 0;
+        o.h[0] = mixf(unorm16_to_float(t.x), unorm16_to_float(t.y), fx);
+    } else {
+        o.valid = (t.x & 0xFFu) != 0 && (t.y & 0xFFu) != 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) o.h[k] = mixf(unorm8_to_float((t.x >> (8 * k)) & 0xFFu), unorm8_to_float((t.y >> (8 * k)) & 0xFFu), fx);
+    }
+    return o;
+}
+
+// value of one centre pixel as a texel (u16 or packed rgba8) from its two filtered source rows.  Where the footprint
+// has no data the pixel keeps what the atlas holds (split.wgsl:37-42): the caller simply does not store it.
+template <uint32_t FORMAT>
+__device__ __forceinline__ uint32_t split_texel(const HRow<FORMAT>& top, const HRow<FORMAT>& bot, float fy) {
+    if constexpr (FORMAT == BT_FORMAT_R16) {
+        return float_to_unorm(mixf(top.h[0], bot.h[0], fy), 65535.0f);
+    } else {
         uint32_t out = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-            const uint32_t sh = 8 * k;
-            const float top = mixf(unorm8_to_float((t00 >> sh) & 0xFFu), unorm8_to_float((t10 >> sh) & 0xFFu), ax.fr);
-            const float bot = mixf(unorm8_to_float((t01 >> sh) & 0xFFu), unorm8_to_float((t11 >> sh) & 0xFFu), ax.fr);
-            out |= float_to_unorm(mixf(top, bot, ay.fr), 255.0f) << sh;
-        }
+        for (uint32_t k = 0; k < 4; k++) out |= float_to_unorm(mixf(top.h[k], bot.h[k], fy), 255.0f) << (8 * k);
         return out;
     }
 }
@@ -143,11 +164,29 @@ __global__ __launch_bounds__(256) void split_kernel(AttachmentMeta m, void* __re
     const uint32_t rows = min(kRows, Tsz - row0);
     // y parameters once per row (threads 0..rows-1), x parameters once per thread and column: the only divisions
     __shared__ Axis s_ay[kRows];
+    __shared__ int s_consecutive;  // all kRows rows are centre rows and step through the source one row at a time
     if (threadIdx.x < rows) {
         const uint32_t py = row0 + threadIdx.x;
         if (py >= b && py < b + c) s_ay[threadIdx.x] = split_axis(py, b, c, task.y, scale, task.tly, task.bry, raster.height);
     }
     __syncthreads();
+    if (threadIdx.x == 0) {
+        bool ok = rows == kRows && row0 >= b && row0 + kRows <= b + c;
+        for (uint32_t r = 0; ok && r < kRows; r++) ok = s_ay[r].i0 == s_ay[0].i0 + int(r) && s_ay[r].i1 == s_ay[r].i0 + 1;
+        s_consecutive = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const bool consecutive = __builtin_amdgcn_readfirstlane(s_consecutive) != 0;
+    auto store = [&](uint32_t py, uint32_t ex, const uint32_t (&texels)[kPer], const bool (&keep)[kPer]) {
+        // a pixel whose footprint has no data keeps what the atlas holds (split.wgsl:37-42): it is not stored
+        if constexpr (FORMAT == BT_FORMAT_R16) {
+            if (!keep[0] && !keep[1]) ((uint32_t*)tile)[(uint64_t(py) * Tsz) / 2 + ex] = texels[0] | (texels[1] << 16);
+            else if (!keep[0]) tile[uint64_t(py) * Tsz + 2 * ex] = T(texels[0]);
+            else if (!keep[1]) tile[uint64_t(py) * Tsz + 2 * ex + 1] = T(texels[1]);
+        } else {
+            if (!keep[0]) tile[uint64_t(py) * Tsz + ex] = texels[0];
+        }
+    };
     for (uint32_t ex = threadIdx.x; ex < entries_per_row; ex += blockDim.x) {
         Axis ax[kPer];
         bool col_is_centre[kPer];
@@ -157,20 +196,53 @@ __global__ __launch_bounds__(256) void split_kernel(AttachmentMeta m, void* __re
             col_is_centre[k] = px >= b && px < b + c;
             ax[k] = col_is_centre[k] ? split_axis(px, b, c, task.x, scale, task.tlx, task.brx, raster.width) : Axis{};
         }
+        if (consecutive) {
+            // the common case: kRows + 1 consecutive source rows feed the kRows output rows.  All their texels are
+            // requested up front (one round of memory latency per column instead of one per row); every source row is
+            // filtered horizontally once and used by two output rows.
+            const int y_first = __builtin_amdgcn_readfirstlane(s_ay[0].i0);
+            uint2 raw[kRows + 1][kPer];
+#pragma unroll
+            for (uint32_t j = 0; j <= kRows; j++)
+#pragma unroll
+                for (uint32_t k = 0; k < kPer; k++) raw[j][k] = col_is_centre[k] ? split_fetch<FORMAT>(raster, ax[k], y_first + int(j)) : make_uint2(1u, 1u);
+            HRow<FORMAT> top[kPer];
+#pragma unroll
+            for (uint32_t k = 0; k < kPer; k++) top[k] = split_hrow<FORMAT>(raw[0][k], ax[k].fr);
+#pragma unroll
+            for (uint32_t r = 0; r < kRows; r++) {
+                const float fy = s_ay[r].fr;
+                uint32_t texels[kPer];
+                bool keep[kPer];
+#pragma unroll
+                for (uint32_t k = 0; k < kPer; k++) {
+                    const HRow<FORMAT> bot = split_hrow<FORMAT>(raw[r + 1][k], ax[k].fr);
+                    keep[k] = col_is_centre[k] && !(top[k].valid && bot.valid);
+                    texels[k] = col_is_centre[k] ? split_texel<FORMAT>(top[k], bot, fy) : 0u;  // apron columns: zero until stitch
+                    top[k] = bot;
+                }
+                store(row0 + r, ex, texels, keep);
+            }
+            continue;
+        }
         for (uint32_t r = 0; r < rows; r++) {
             const uint32_t py = row0 + r;
             const bool row_is_centre = py >= b && py < b + c;
             uint32_t texels[kPer];
+            bool keep[kPer];
 #pragma unroll
             for (uint32_t k = 0; k < kPer; k++) {
-                const uint32_t px = ex * kPer + k;
-                // split.wgsl:19-21: border pixels are zero until stitch fills them
-                texels[k] = (row_is_centre && col_is_centre[k]) ? split_texel<FORMAT>(raster, ax[k], s_ay[r], tile + uint64_t(py) * Tsz + px) : 0u;
+                keep[k] = false;
+                texels[k] = 0u;  // split.wgsl:19-21: border pixels are zero until stitch fills them
+                if (row_is_centre && col_is_centre[k]) {
+                    const Axis ay = s_ay[r];
+                    const uint2 t0 = split_fetch<FORMAT>(raster, ax[k], ay.i0), t1 = split_fetch<FORMAT>(raster, ax[k], ay.i1);
+                    const HRow<FORMAT> top = split_hrow<FORMAT>(t0, ax[k].fr), bot = split_hrow<FORMAT>(t1, ax[k].fr);
+                    keep[k] = !(top.valid && bot.valid);
+                    texels[k] = split_texel<FORMAT>(top, bot, ay.fr);
+                }
             }
-            if constexpr (FORMAT == BT_FORMAT_R16)
-                ((uint32_t*)tile)[(uint64_t(py) * Tsz) / 2 + ex] = texels[0] | (texels[1] << 16);
-            else
-                tile[uint64_t(py) * Tsz + ex] = texels[0];
+            store(py, ex, texels, keep);
         }
     }
 }
