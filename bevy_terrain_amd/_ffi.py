@@ -49,6 +49,11 @@ class RasterC(C.Structure):
                 ("format", C.c_uint32), ("on_device", C.c_uint32)]
 
 
+class ImageC(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32),
+                ("row_pitch", C.c_uint64)]
+
+
 class PreprocessDatasetC(C.Structure):
     _fields_ = [("attachment_index", C.c_uint32), ("side", C.c_uint32), ("top_left", C.c_float * 2),
                 ("bottom_right", C.c_float * 2), ("lod_begin", C.c_uint32), ("lod_end", C.c_uint32)]
@@ -156,6 +161,9 @@ PROTOTYPES = {
     "bt_generate_mipmaps": (_i32, [_vp, _u32, _u32, _u32, _vp, _vp, _u64]),
     "bt_atlas_generate_mipmaps": (_i32, [_vp, _u32, _u32, _u32]),
     "bt_atlas_mip_storage": (_i32, [_vp, _u32, _u32, _P(_vp), _P(_u64)]),
+    "bt_image_load": (_i32, [C.c_char_p, _u32, _P(ImageC)]),
+    "bt_image_decode": (_i32, [_vp, C.c_size_t, _u32, _P(ImageC)]),
+    "bt_image_free": (None, [_P(ImageC)]),
     "bt_preprocessor_create": (_i32, [_vp, _P(_vp)]),
     "bt_preprocessor_destroy": (None, [_vp]),
     "bt_preprocessor_clear_attachment": (_i32, [_vp, _vp, _u32, C.c_char_p]),

@@ -22,7 +22,8 @@ from .tile_atlas import TileAtlas
 class AssetServer:
     """Stands in for Bevy's AssetServer: `load(path)` returns the source raster registered under `path`
     (numpy array, torch CUDA tensor, or a (device_ptr, width, height, format) tuple) or decodes an image
-    file below `root` (16-bit PNG / TIFF via Pillow — formats/tiff.rs forces R16Unorm the same way)."""
+    file below `root` with the library's PNG / TIFF decoder (bt_image_load; formats/tiff.rs forces R16Unorm the
+    same way)."""
 
     def __init__(self, root: str = "assets"):
         self.root = root
@@ -32,7 +33,7 @@ class AssetServer:
         self._rasters[path] = raster
         return self
 
-    def load(self, path: str):
+    def load(self, path: str, fmt: Optional[AttachmentFormat] = None):
         if path in self._rasters:
             return self._rasters[path]
         full = os.path.join(self.root, path)
@@ -40,16 +41,27 @@ class AssetServer:
             raise FileNotFoundError(f"source raster {path!r} neither registered nor found at {full}")
         if full.endswith(".npy"):
             return np.load(full)
-        from PIL import Image
+        # PNG / TIFF: decoded by the library (bt_image_load), into the attachment's processing format
+        return decode_image(full, fmt or AttachmentFormat.R16)
 
-        Image.MAX_IMAGE_PIXELS = None
-        img = Image.open(full)
-        arr = np.array(img)
-        if arr.ndim == 2:
-            return arr.astype(np.uint16) if arr.dtype != np.uint16 else arr
-        if arr.shape[2] == 3:
-            arr = np.concatenate([arr, np.full(arr.shape[:2] + (1,), 255, arr.dtype)], axis=2)
-        return arr.astype(np.uint8)
+
+def decode_image(path_or_bytes, fmt: AttachmentFormat) -> np.ndarray:
+    """bt_image_load / bt_image_decode -> numpy array (H, W) uint16 or (H, W, 4) uint8."""
+    img = _ffi.ImageC()
+    if isinstance(path_or_bytes, (bytes, bytearray)):
+        buf = (C.c_uint8 * len(path_or_bytes)).from_buffer_copy(bytes(path_or_bytes))
+        _ffi.check(_ffi.lib().bt_image_decode(buf, len(path_or_bytes), fmt.id(), C.byref(img)))
+    else:
+        _ffi.check(_ffi.lib().bt_image_load(os.fsencode(path_or_bytes), fmt.id(), C.byref(img)))
+    height, width = img.height, img.width
+    try:
+        nbytes = img.row_pitch * height
+        raw = np.frombuffer((C.c_uint8 * nbytes).from_address(img.data), dtype=np.uint8).copy()
+    finally:
+        _ffi.lib().bt_image_free(C.byref(img))  # (zeroes the struct)
+    if fmt == AttachmentFormat.R16:
+        return raw.view(np.uint16).reshape(height, width)
+    return raw.reshape(height, width, 4)
 
 
 @dataclass
@@ -126,7 +138,7 @@ class Preprocessor:
 
     def preprocess_tile(self, dataset: PreprocessDataset, asset_server: AssetServer, tile_atlas: TileAtlas) -> "Preprocessor":
         fmt = tile_atlas.config.attachments[dataset.attachment_index].format
-        raster = _raster_struct(asset_server.load(dataset.path), fmt, self._keep)
+        raster = _raster_struct(asset_server.load(dataset.path, fmt) if isinstance(asset_server, AssetServer) else asset_server.load(dataset.path), fmt, self._keep)
         d = _ffi.PreprocessDatasetC(dataset.attachment_index, dataset.side, (C.c_float * 2)(*dataset.top_left),
                                     (C.c_float * 2)(*dataset.bottom_right), dataset.lod_range.start, dataset.lod_range.stop)
         _ffi.check(_ffi.lib().bt_preprocessor_preprocess_tile(self._handle(tile_atlas), tile_atlas._h, C.byref(d), C.byref(raster)))
@@ -134,7 +146,7 @@ class Preprocessor:
 
     def preprocess_spherical(self, dataset: SphericalDataset, asset_server: AssetServer, tile_atlas: TileAtlas) -> "Preprocessor":
         fmt = tile_atlas.config.attachments[dataset.attachment_index].format
-        rasters = (_ffi.RasterC * 6)(*[_raster_struct(asset_server.load(p), fmt, self._keep) for p in dataset.paths])
+        rasters = (_ffi.RasterC * 6)(*[_raster_struct(asset_server.load(p, fmt), fmt, self._keep) for p in dataset.paths])
         d = _ffi.SphericalDatasetC(dataset.attachment_index, dataset.lod_range.start, dataset.lod_range.stop)
         _ffi.check(_ffi.lib().bt_preprocessor_preprocess_spherical(self._handle(tile_atlas), tile_atlas._h, C.byref(d), rasters))
         return self

@@ -97,6 +97,22 @@ typedef struct bt_raster {
                             until the preprocessor has run) */
 } bt_raster;
 
+/* A decoded source image in host memory, ready to be handed over as a bt_raster (on_device = 0).  Replaces
+ * `asset_server.load(path)` + preprocessor_load_tile (preprocessor.rs:240, 401-422; formats/tiff.rs:14-62): a 16-bit
+ * grayscale PNG / TIFF decodes to R16 texels (host byte order), an 8-bit gray / RGB / RGBA PNG or TIFF to Rgba8 (alpha
+ * 255 where the file has none, like Bevy's Image::from_dynamic).  PNG: non-interlaced, 8 / 16 bit.  TIFF: classic
+ * (II / MM), strips or tiles, uncompressed / LZW / deflate / PackBits, horizontal predictor.  Anything else:
+ * BT_ERR_UNSUPPORTED.  `data` is owned by the library until bt_image_free. */
+typedef struct bt_image {
+    void* data;
+    uint32_t width, height;
+    uint32_t format;    /* BT_FORMAT_R16 or BT_FORMAT_RGBA8 */
+    uint64_t row_pitch; /* bytes, tightly packed */
+} bt_image;
+bt_status bt_image_load(const char* path, uint32_t format, bt_image* out);
+bt_status bt_image_decode(const void* bytes, size_t size, uint32_t format, bt_image* out);
+void bt_image_free(bt_image* image);
+
 /* PreprocessDataset (preprocessor.rs:35-55). */
 typedef struct bt_preprocess_dataset {
     uint32_t attachment_index;

@@ -473,3 +473,32 @@ def test_raster_pitch_is_validated(device):
     with pytest.raises(bt._ffi.BtError) as e:
         bt.Preprocessor.new().preprocess_tile(bt.PreprocessDataset(path="x"), bt.AssetServer().insert("x", np.ones((8, 8), np.uint16)), bt.TileAtlas.new(cfg2, device))
     assert e.value.status == -5
+
+
+def test_preprocess_from_png_and_tiff_files(device, tmp_path):
+    """examples/preprocess_planar.rs end to end from image FILES: `asset_server.load("terrains/planar/source/height.png")`
+    is the library's PNG decoder here (bt_image_load), a TIFF face like examples/preprocess_spherical.rs' as well."""
+    from PIL import Image
+
+    root = tmp_path / "assets"
+    os.makedirs(root / "terrains/planar/source")
+    height = K.smooth_raster(700, 700, seed=12)
+    albedo = np.random.default_rng(13).integers(1, 256, size=(700, 700, 3), dtype=np.uint8)
+    Image.fromarray(height).save(str(root / "terrains/planar/source/height.png"))
+    Image.fromarray(albedo).save(str(root / "terrains/planar/source/albedo.png"))
+    Image.fromarray(height).save(str(root / "terrains/planar/source/height.tif"), compression="tiff_lzw")
+    cfg = bt.TerrainConfig(lod_count=3, atlas_size=128, path="terrains/planar", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=128, border_size=2, format=bt.AttachmentFormat.R16))
+    cfg.add_attachment(bt.AttachmentConfig(name="albedo", texture_size=128, border_size=2, format=bt.AttachmentFormat.Rgba8))
+    cfg.add_attachment(bt.AttachmentConfig(name="height_tif", texture_size=128, border_size=2, format=bt.AttachmentFormat.R16))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer(str(root))
+    pre = bt.Preprocessor.new()
+    for i, name in enumerate(("height.png", "albedo.png", "height.tif")):
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=i, path=f"terrains/planar/source/{name}", lod_range=range(0, 3)), server, atlas)
+    pre.run(atlas)
+    rgba = np.concatenate([albedo, np.full((700, 700, 1), 255, np.uint8)], axis=2)
+    oracle = O.OracleAtlas(3, 128, False, [(128, 2, 1, O.FORMAT_R16), (128, 2, 1, O.FORMAT_RGBA8), (128, 2, 1, O.FORMAT_R16)])
+    oracle.preprocess_tile(0, height, (0, 3)).preprocess_tile(1, rgba, (0, 3)).preprocess_tile(2, height, (0, 3)).run(8)
+    for i in range(3):
+        assert K.assert_atlas_equal(atlas, oracle, i) == 21

@@ -1,0 +1,180 @@
+"""the library's PNG / TIFF decoder (bt_image_load, host code) against Pillow's decode of the same
+files — the source-image formats of the reference's examples (16-bit height PNG / TIFF, 8-bit albedo PNG)."""
+import io
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import bevy_terrain_amd as bt
+from bevy_terrain_amd.preprocess import decode_image
+
+R16, RGBA8 = bt.AttachmentFormat.R16, bt.AttachmentFormat.Rgba8
+
+
+def height(h=97, w=131, seed=1):
+    rng = np.random.default_rng(seed)
+    smooth = (np.add.outer(np.arange(h) * 311, np.arange(w) * 173) % 65536).astype(np.uint16)
+    noise = rng.integers(0, 65536, size=(h, w), dtype=np.uint16)
+    return np.where(rng.random((h, w)) < 0.5, smooth, noise)  # compressible runs + incompressible noise
+
+
+def colour(h=75, w=90, channels=3, seed=2):
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, size=(h, w, channels), dtype=np.uint8)
+    img[20:40, :, :] = img[20:21, :1, :]  # flat band
+    return img
+
+
+def rgba_of(a):
+    if a.ndim == 2:
+        a = np.repeat(a[..., None], 3, axis=2)
+    if a.shape[2] == 3:
+        a = np.concatenate([a, np.full(a.shape[:2] + (1,), 255, np.uint8)], axis=2)
+    return a
+
+
+@pytest.mark.parametrize("compress_level", [0, 1, 6, 9])
+def test_png_16_bit_gray(tmp_path, compress_level):
+    a = height()
+    p = str(tmp_path / "h.png")
+    Image.fromarray(a).save(p, compress_level=compress_level)  # level 0: stored blocks; others: fixed / dynamic Huffman
+    assert np.array_equal(decode_image(p, R16), a)
+    assert np.array_equal(decode_image(open(p, "rb").read(), R16), a)
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGBA", "L", "P"])
+def test_png_8_bit_colour(tmp_path, mode):
+    if mode == "RGB":
+        src = colour(channels=3)
+        im = Image.fromarray(src)
+    elif mode == "RGBA":
+        src = colour(channels=4)
+        im = Image.fromarray(src)
+    elif mode == "L":
+        src = colour(channels=3)[..., 0]
+        im = Image.fromarray(src)
+    else:
+        im = Image.fromarray(colour(channels=3)).quantize(colors=200)
+        src = np.array(im.convert("RGB"))
+    p = str(tmp_path / f"c_{mode}.png")
+    im.save(p)
+    assert np.array_equal(decode_image(p, RGBA8), rgba_of(src))
+
+
+def test_png_all_filter_types_by_hand(tmp_path):
+    """Pillow picks filters adaptively; this file forces each of the five filter types on its own rows."""
+    import struct
+    import zlib
+
+    a = height(40, 33, seed=9)
+    rows = a.astype(">u2").tobytes()
+    stride, bpp = 33 * 2, 2
+    raw = bytearray()
+    prev = bytes(stride)
+    for y in range(40):
+        cur = rows[y * stride:(y + 1) * stride]
+        f = y % 5
+        out = bytearray(stride)
+        for i in range(stride):
+            A = cur[i - bpp] if i >= bpp else 0
+            B = prev[i]
+            Cc = prev[i - bpp] if i >= bpp else 0
+            if f == 0:
+                pred = 0
+            elif f == 1:
+                pred = A
+            elif f == 2:
+                pred = B
+            elif f == 3:
+                pred = (A + B) >> 1
+            else:
+                pp = A + B - Cc
+                pa, pb, pc = abs(pp - A), abs(pp - B), abs(pp - Cc)
+                pred = A if pa <= pb and pa <= pc else (B if pb <= pc else Cc)
+            out[i] = (cur[i] - pred) & 0xFF
+        raw += bytes([f]) + out
+        prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+
+    z = zlib.compress(bytes(raw), 6)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 33, 40, 16, 0, 0, 0, 0)) + chunk(b"IDAT", z[:100]) + chunk(b"IDAT", z[100:]) + chunk(b"IEND", b"")
+    assert np.array_equal(np.array(Image.open(io.BytesIO(png))), a)  # the hand-made file is a valid PNG
+    assert np.array_equal(decode_image(png, R16), a)
+
+
+@pytest.mark.parametrize("compression", [None, "tiff_lzw", "tiff_adobe_deflate", "packbits"])
+def test_tiff_16_bit_gray(tmp_path, compression):
+    a = height(203, 150, seed=4)
+    p = str(tmp_path / "f.tif")
+    Image.fromarray(a).save(p, **({"compression": compression} if compression else {}))
+    assert np.array_equal(decode_image(p, R16), a)
+
+
+def test_tiff_variants(tmp_path):
+    a = height(130, 140, seed=5)
+    # horizontal predictor + LZW (what GDAL writes for GEBCO-style rasters), several strips
+    p = str(tmp_path / "pred.tif")
+    Image.fromarray(a).save(p, compression="tiff_lzw", tiffinfo={317: 2, 278: 16})
+    assert np.array_equal(np.array(Image.open(p)), a)
+    assert np.array_equal(decode_image(p, R16), a)
+    # 8-bit RGB, deflate
+    c = colour(60, 70, 3)
+    p = str(tmp_path / "rgb.tif")
+    Image.fromarray(c).save(p, compression="tiff_adobe_deflate")
+    assert np.array_equal(decode_image(p, RGBA8), rgba_of(c))
+    # big-endian ("MM"), uncompressed, written by hand: header, image data, IFD
+    import struct
+
+    data = a.astype(">u2").tobytes()
+    tags = [(256, 3, 1, 140), (257, 3, 1, 130), (258, 3, 1, 16), (259, 3, 1, 1), (262, 3, 1, 1), (273, 4, 1, 8), (277, 3, 1, 1), (278, 3, 1, 130), (279, 4, 1, len(data))]
+    ifd = struct.pack(">H", len(tags))
+    for tag, typ, cnt, val in tags:
+        ifd += struct.pack(">HHI", tag, typ, cnt) + (struct.pack(">HH", val, 0) if typ == 3 else struct.pack(">I", val))
+    ifd += struct.pack(">I", 0)
+    mm = b"MM" + struct.pack(">HI", 42, 8 + len(data)) + data + ifd
+    assert np.array_equal(np.array(Image.open(io.BytesIO(mm))), a)
+    assert np.array_equal(decode_image(mm, R16), a)
+    # tiled, little-endian, by hand: 64 x 64 tiles over a 140 x 130 image (edge tiles padded)
+    tw = th = 64
+    across, down = 3, 3
+    blob, offs, cnts = b"", [], []
+    for ty in range(down):
+        for tx in range(across):
+            tile = np.zeros((th, tw), np.uint16)
+            part = a[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw]
+            tile[:part.shape[0], :part.shape[1]] = part
+            offs.append(8 + len(blob))
+            cnts.append(tile.nbytes)
+            blob += tile.astype("<u2").tobytes()
+    extra = b"".join(struct.pack("<I", o) for o in offs) + b"".join(struct.pack("<I", c) for c in cnts)
+    ifd_at = 8 + len(blob) + len(extra)
+    tags = [(256, 3, 1, 140), (257, 3, 1, 130), (258, 3, 1, 16), (259, 3, 1, 1), (262, 3, 1, 1), (277, 3, 1, 1), (322, 3, 1, tw), (323, 3, 1, th),
+            (324, 4, 9, 8 + len(blob)), (325, 4, 9, 8 + len(blob) + 36)]
+    ifd = struct.pack("<H", len(tags))
+    for tag, typ, cnt, val in tags:
+        ifd += struct.pack("<HHI", tag, typ, cnt) + (struct.pack("<HH", val, 0) if typ == 3 else struct.pack("<I", val))
+    ifd += struct.pack("<I", 0)
+    tiled = b"II" + struct.pack("<HI", 42, ifd_at) + blob + extra + ifd
+    assert np.array_equal(np.array(Image.open(io.BytesIO(tiled))), a)
+    assert np.array_equal(decode_image(tiled, R16), a)
+
+
+def test_unsupported_and_corrupt_inputs_are_errors(tmp_path):
+    a = height(20, 20)
+    p = str(tmp_path / "h.png")
+    Image.fromarray(a).save(p)
+    with pytest.raises(bt._ffi.BtError) as e:
+        decode_image(p, RGBA8)  # a 16-bit image is not an Rgba8 raster
+    assert e.value.status == -5
+    with pytest.raises(bt._ffi.BtError):
+        decode_image(open(p, "rb").read()[:60], R16)  # truncated
+    with pytest.raises(bt._ffi.BtError) as e:
+        decode_image(b"GIF89a" + bytes(40), R16)
+    assert e.value.status == -5
+    with pytest.raises(bt._ffi.BtError) as e:
+        decode_image(str(tmp_path / "missing.png"), R16)
+    assert e.value.status == -4
