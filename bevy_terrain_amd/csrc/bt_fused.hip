@@ -55,7 +55,7 @@ struct FusedArgs {
     const RasterDev* rasters;
     const MainItem* items;
     const uint32_t* grids;         // per (side, lod): n x n atlas indices, x-major (x * n + y), INVALID = absent
-    const uint32_t* grid_offsets;  // [side * 32 + lod] -> offset into grids, INVALID = no grid
+    uint32_t grid_lod_lo, grid_lod_hi, grid_sides;  // the grids of (side, lod), lod_lo <= lod <= lod_hi, follow each other side-major, LODs ascending
     float tlx, tly, brx, bry;
     uint32_t lod;         // finest LOD of this launch (fused_main) / input LOD (fused_tail)
     uint32_t levels;      // LODs produced by this launch: main 1..3 (lod, lod-1, lod-2); tail 1..3 below lod
@@ -112,8 +112,11 @@ __host__ __device__ __forceinline__ Axis split_axis(uint32_t r, uint32_t c, uint
 __device__ __forceinline__ uint32_t grid_lookup(const FusedArgs& A, uint32_t side, uint32_t lod, int x, int y) {
     const int n = int(1u << lod);
     if (x < 0 || y < 0 || x >= n || y >= n) return kInvalid;
-    const uint32_t off = A.grid_offsets[side * 32u + lod];
-    if (off == kInvalid) return kInvalid;
+    if (lod < A.grid_lod_lo || lod > A.grid_lod_hi || side >= A.grid_sides) return kInvalid;
+    // offset of the (side, lod) grid: computed, not looked up (one dependent load less in every lookup chain):
+    // sum of 4^l for lod_lo <= l < lod = (4^lod - 4^lod_lo) / 3
+    const uint32_t lo4 = 1u << (2u * A.grid_lod_lo), per_side = ((4u << (2u * A.grid_lod_hi)) - lo4) / 3u;
+    const uint32_t off = side * per_side + ((1u << (2u * lod)) - lo4) / 3u;
     return A.grids[off + uint32_t(x) * uint32_t(n) + uint32_t(y)];
 }
 
@@ -605,7 +608,8 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         }
 
         if (BT_ABLATE(A, 768u) && !is_idle) {  // (ablation 256 / 512, with 16: the chunk's finest / parent stores without any arithmetic — the memory skeleton)
-            uint32_t* dst5 = tile5_u32 + (((b + cr0) * T + px0) >> 1);
+            // (4096: the same bytes with thread t on dword t of the row — what a texture-aligned thread mapping would store)
+            uint32_t* dst5 = BT_ABLATE(A, 4096u) ? tile5_u32 + (((b + cr0) * T) >> 1) + tid : tile5_u32 + (((b + cr0) * T + px0) >> 1);
             if (BT_ABLATE(A, 256u)) {
 #pragma unroll
                 for (uint32_t i = 0; i < kMainRows; i++) dst5[i * (T / 2)] = tid + i;
@@ -1172,7 +1176,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         const uint32_t lod_hi = splits[0]->coord.lod;
         uint32_t lod_lo = lod_hi;
         for (const Task* t : downs) lod_lo = std::min(lod_lo, t->coord.lod);
-        if (lod_hi > 24) return false;
+        if (lod_hi > 13) return false;  // dense per-LOD grids (4^lod entries) and 32-bit grid offsets
         const bool spherical = a->config.spherical != 0;
         const uint32_t sides = spherical ? 6u : 1u;
 
@@ -1306,7 +1310,10 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             args.todo = const_cast<uint32_t*>(dev);
             args.todo_next = args.todo + list;
         }
-        if (upload_vector(p, items, &args.items) || upload_vector(p, grids, &args.grids) || upload_vector(p, grid_offsets, &args.grid_offsets))
+        args.grid_lod_lo = lod_lo;
+        args.grid_lod_hi = lod_hi;
+        args.grid_sides = sides;
+        if (upload_vector(p, items, &args.items) || upload_vector(p, grids, &args.grids))
             return false;
 
         const uint64_t bpp = m.pixel_size, Tt = m.texture_size, cc = m.center_size;

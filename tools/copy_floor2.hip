@@ -38,6 +38,27 @@ __global__ __launch_bounds__(256) void k(const uint8_t* src, uint8_t* tiles, uin
         }
     }
 }
+// fused_main's store shape: one dword per lane, a wave = 256 contiguous bytes of a 1 KB tile row; `shift` = 4 starts the
+// row's centre at byte 4 like the tiles do (b = 2 texels of 2 bytes): every wave store then straddles a 128-byte line
+__global__ __launch_bounds__(256) void kshape(const uint8_t* src, uint8_t* tiles, int shift, int do_read) {
+    const uint32_t total = gridDim.x, q = total / 8, xcd = blockIdx.x % 8, i = blockIdx.x / 8;
+    const uint32_t work = xcd * q + i, ty = work / 32, tx = work % 32;
+    const uint32_t t = threadIdx.x;
+    const uint8_t* s = src + (uint64_t(ty) * 512) * 32768 + uint64_t(tx) * 1024;
+    uint8_t* d = tiles + uint64_t(tx * 32 + ty) * 524288;
+    const uint32_t dword = shift ? (t + 1u) & 255u : t;  // shift: thread t owns dword t + 1 (the last thread wraps to dword 0)
+    for (uint32_t r0 = 0; r0 < 512; r0 += 8) {
+        u32x4 v[2];
+        if (do_read) {  // 8 rows x 1 KB in, 16 bytes per lane and load like fused_main's staging
+            v[0] = *(const u32x4*)(s + uint64_t(r0 + (t >> 6)) * 32768 + (t & 63u) * 16);
+            v[1] = *(const u32x4*)(s + uint64_t(r0 + 4 + (t >> 6)) * 32768 + (t & 63u) * 16);
+        } else {
+            v[0] = v[1] = u32x4{t, t, t, t};
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++) *(uint32_t*)(d + uint64_t(r0 + r) * 1024 + dword * 4) = v[r >> 2][r & 3];
+    }
+}
 __global__ __launch_bounds__(256) void lin3(const uint8_t* src, uint8_t* dst, uint8_t* dst2, int third, int window = 0) {
     const uint32_t total = gridDim.x, q = total / 8, xcd = blockIdx.x % 8, i = blockIdx.x / 8, work = xcd * q + i;
     const uint32_t lane16 = threadIdx.x & 63u, rsub = threadIdx.x >> 6;
@@ -76,6 +97,10 @@ int main(int argc, char** argv) {
         return 0;
     }
     for (int i = 0; i < 300; i++) lin3<<<1024, 256>>>(src, tiles, parents, 0);  // spin-up
+    for (int rd : {0, 1})
+        for (int shift : {0, 4})
+            printf("dword-per-lane tile rows, %s, row start shifted by %d bytes: %.1f us\n", rd ? "reads + writes" : "writes only", shift,
+                   timeit([&] { kshape<<<1024, 256>>>(src, tiles, shift, rd); }));
     printf("linear r + w: %.1f us;  + third linear stream of 1/4: %.1f us\n", timeit([&] { lin3<<<1024, 256>>>(src, tiles, parents, 0); }),
            timeit([&] { lin3<<<1024, 256>>>(src, tiles, parents, 1); }));
     printf("raster-window reads, linear writes: r + w %.1f us;  + third linear stream: %.1f us\n", timeit([&] { lin3<<<1024, 256>>>(src, tiles, parents, 0, 1); }),
