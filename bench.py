@@ -94,20 +94,33 @@ def end_to_end(device, src_ptr):
                                            format=bt.AttachmentFormat.R16))
     atlas = bt.TileAtlas.new(cfg, device)
     device.synchronize()
-    root = tempfile.mkdtemp(prefix="bt_e2e_")
-    results = []
-    for _ in range(2):  # the first pass warms the page cache / allocators, the second is reported
+    # where the files go: a RAM-backed file system when it has room (isolates the library's D2H + write pipeline from
+    # the box's disk: the container's overlay disk sustains ~3 GB/s once the kernel's dirty-page limit is reached, and
+    # how soon that happens depends on what ran before), else the default temporary directory
+    parent = None
+    try:
+        st = os.statvfs("/dev/shm")
+        if st.f_bavail * st.f_frsize > (1 << 30):
+            parent = "/dev/shm"
+    except OSError:
+        pass
+    root = tempfile.mkdtemp(prefix="bt_e2e_", dir=parent)
+
+    def one_pass(window, lods):
         pre = bt.Preprocessor.new().clear_attachment(0, atlas, root)
         t0 = time.perf_counter()
-        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="host", lod_range=range(0, LOD_COUNT)),
-                            bt.AssetServer().insert("host", host), atlas)
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="host", lod_range=range(0, lods)),
+                            bt.AssetServer().insert("host", window), atlas)
         t1 = time.perf_counter()
         pre.run(atlas)
         t2 = time.perf_counter()
         pre.save(atlas, root)
         t3 = time.perf_counter()
-        results.append((t1 - t0, t2 - t1, t3 - t2))
         pre.close()
+        return (t1 - t0, t2 - t1, t3 - t2)
+
+    warm = one_pass(np.ascontiguousarray(host[:2048, :2048]), 3)  # 21 tiles: allocates the pinned staging buffers, warms the paths
+    results = [warm, one_pass(host, LOD_COUNT)]
     files = [f for f in os.listdir(atlas.attachment_directory(root, 0)) if f.endswith(".bin")]
     written = sum(os.path.getsize(os.path.join(atlas.attachment_directory(root, 0), f)) for f in files)
     fs = "?"
@@ -126,7 +139,7 @@ def end_to_end(device, src_ptr):
             "upload_ms": up * 1e3, "upload_GBps": host.nbytes / up / 1e9,
             "kernels_ms": run * 1e3,
             "save_ms": save * 1e3, "save_GBps": written / save / 1e9, "files": len(files), "bytes_written": written,
-            "filesystem": fs, "first_pass_ms": sum(results[0]) * 1e3,
+            "filesystem": fs, "directory": root, "warm_up_pass_ms": sum(results[0]) * 1e3,
             "span": "source raster in pageable host memory -> hipMalloc + H2D -> 3 kernels -> D2H through 3 pinned "
                     "buffers + writer threads -> 1365 .bin files + config.tc (preprocessor.rs:363,419)"}
 
@@ -343,6 +356,11 @@ def main():
     if cube:
         args.no_cpu_baseline = args.no_end_to_end = True  # the side measurements belong to the headline workload
         args.verify = False
+    if rank == 0 and world == 1 and not args.no_end_to_end:
+        try:
+            line["end_to_end"] = end_to_end(device, src_ptr)
+        except Exception as e:  # never lose the headline line over a side measurement
+            line["end_to_end"] = {"error": repr(e)}
     if rank == 0 and ((world == 1 and not args.no_cpu_baseline) or args.verify):
         baseline, oracle, shape = cpu_baseline(device, src_ptr)
         if world == 1:
@@ -351,11 +369,6 @@ def main():
             line["verify_vs_oracle"] = verify_against(atlas, oracle, shape)
     if world > 1:
         dist.barrier()  # the other ranks wait for rank 0's oracle run before tearing the group down
-    if rank == 0 and world == 1 and not args.no_end_to_end:
-        try:
-            line["end_to_end"] = end_to_end(device, src_ptr)
-        except Exception as e:  # never lose the headline line over a side measurement
-            line["end_to_end"] = {"error": repr(e)}
     if rank == 0 and world == 1:
         # the other half of the hot path, for the record: the per-frame tiling prepass on scripted camera paths
         # (latency-bound, one launch per frame; not part of `value`)

@@ -596,7 +596,7 @@ bt_status save_tiles(bt_atlas* a, uint32_t ai, const char* directory, std::vecto
         if (e != hipSuccess) rc = hip_fail(e, "save events");
     }
     if (rc == BT_OK) {
-        const uint32_t threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency() / 2u));
+        const uint32_t threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
         FileWriters writers(threads, kBuffers);
         const size_t n = tiles.size(), chunks = (n + chunk - 1) / chunk;
         auto hand_over = [&](size_t c) -> bt_status {  // chunk c has been enqueued: wait for its copies, queue its files

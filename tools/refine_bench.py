@@ -38,6 +38,24 @@ def measure(device):
             ms.append(device.timer_end())
             tiles, _ = prepass.read()
             counts.append(len(tiles))
+        # the CPU side of the same frame in the reference (TileTree::update over sides x lods x tree_size^2 nodes, f64):
+        # here one launch + the read-back of the request / release lists (host wall time per update, synchronous)
+        lods = 12
+        tcfg = bt.TerrainConfig(lod_count=lods, atlas_size=16, path="terrains/none", model=model)
+        tcfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=16, border_size=2))
+        atlas = bt.TileAtlas.new(tcfg, device)
+        tree = bt.TileTree(atlas, model, lods, cfg)
+        for p in positions[:4]:
+            tree.update(p)
+        tree_us, requests = [], []
+        for p in positions:
+            t0 = time.perf_counter()
+            released, requested = tree.update(p)
+            tree_us.append((time.perf_counter() - t0) * 1e6)
+            requests.append(len(released) + len(requested))
+        tree.close()
+        out[name + "_tile_tree"] = {"nodes": tree.nodes, "lod_count": lods, "us_per_update_avg_host_wall": float(np.mean(tree_us)),
+                                     "us_per_update_max_host_wall": float(np.max(tree_us)), "requests_plus_releases_avg": float(np.mean(requests))}
         out[name] = {"frames": len(views), "us_per_frame_avg": 1e3 * float(np.mean(ms)), "us_per_frame_max": 1e3 * float(np.max(ms)),
                      "final_tiles_avg": float(np.mean(counts)), "final_tiles_max": int(np.max(counts)),
                      "launches_per_frame": 1, "reference_dispatches_per_frame": 2 * cfg.refinement_count + 3}
