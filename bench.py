@@ -232,7 +232,22 @@ def main():
     if world > 1:
         from bevy_terrain_amd.shard import ShardedPreprocess
 
-        job = ShardedPreprocess(pre, atlas, server, paths, range(0, lod_count), rank, world, generic=args.generic, collective=collective)
+        if collective == "library":
+            # every rank must end up on the same path: agree on whether the library's communicator came up everywhere
+            ok = 1
+            try:
+                job = ShardedPreprocess(pre, atlas, server, paths, range(0, lod_count), rank, world, generic=args.generic, collective="library")
+                bt._ffi.check(bt._ffi.lib().bt_comm_check(job._comm))
+            except Exception as e:
+                print(f"[rank {rank}] library-issued collective unavailable ({e!r}); falling back to torch.distributed", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                collective = "torch"
+                pre = bt.Preprocessor.new().clear_attachment(0, atlas)
+        if collective == "torch":
+            job = ShardedPreprocess(pre, atlas, server, paths, range(0, lod_count), rank, world, generic=args.generic, collective="torch")
     else:
         if cube:
             pre.preprocess_spherical(bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lod_count)), server, atlas)
