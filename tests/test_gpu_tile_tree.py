@@ -186,3 +186,38 @@ def test_mips_of_streamed_tiles(device, tmp_path):
     assert atlas.get_best_tile(bt.TileCoordinate(0, 2, 0, 0)) == (0, 0)
     with pytest.raises(bt._ffi.BtError):
         atlas.release_tile(bt.TileCoordinate(0, 2, 1, 1))  # existing, but never requested
+
+
+def test_tile_is_loaded_only_when_all_its_attachments_are(device, tmp_path):
+    """LoadingState::Loading(n) (tile_atlas.rs:347-359): a tile with two attachments becomes usable after BOTH loads."""
+    model, _ = MODELS["planar"]
+    T, lods = 16, 2
+    src_h = K.random_raster(O.FORMAT_R16, 40, 40, seed=1)
+    src_a = K.random_raster(O.FORMAT_RGBA8, 40, 40, seed=2)
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=16, path="terrains/two", model=model)
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=T, border_size=2, format=bt.AttachmentFormat.R16))
+    cfg.add_attachment(bt.AttachmentConfig(name="albedo", texture_size=T, border_size=2, format=bt.AttachmentFormat.Rgba8))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer().insert("h", src_h).insert("a", src_a)
+    pre = (bt.Preprocessor.new().preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="h", lod_range=range(0, lods)), server, atlas)
+           .preprocess_tile(bt.PreprocessDataset(attachment_index=1, path="a", lod_range=range(0, lods)), server, atlas))
+    pre.run(atlas)
+    root = str(tmp_path / "assets")
+    pre.save(atlas, root)
+    originals = {(c.side, c.lod, c.x, c.y): (atlas.download_tile(0, i), atlas.download_tile(1, i)) for c, i in atlas.tiles()}
+    fresh = bt.TileAtlas.new(cfg, device)
+    fresh.load_tile_config(root)
+    stream = O.Stream(16, 2, existing=list(originals))
+    for c in [(0, 0, 0, 0), (0, 1, 1, 0)]:
+        fresh.request_tile(bt.TileCoordinate(*c))
+        stream.request_tile(c)
+    assert fresh.pending_loads() == stream.pending_loads() == 4
+    for k in range(4):  # one attachment at a time
+        assert fresh.update(root, max_loads=1) == (1, 0)
+        stream.finish_loads(1)
+        for c in [(0, 0, 0, 0), (0, 1, 1, 0), (0, 1, 0, 1)]:
+            assert fresh.get_best_tile(bt.TileCoordinate(*c)) == stream.get_best_tile(c), (k, c)
+    idx, lod = fresh.get_best_tile(bt.TileCoordinate(0, 1, 1, 0))
+    assert lod == 1
+    assert np.array_equal(fresh.download_tile(0, idx), originals[(0, 1, 1, 0)][0])
+    assert np.array_equal(fresh.download_tile(1, idx), originals[(0, 1, 1, 0)][1])

@@ -178,3 +178,32 @@ def test_unsupported_and_corrupt_inputs_are_errors(tmp_path):
     with pytest.raises(bt._ffi.BtError) as e:
         decode_image(str(tmp_path / "missing.png"), R16)
     assert e.value.status == -4
+
+
+def test_small_and_odd_images(tmp_path):
+    one = np.array([[54321]], np.uint16)
+    p = str(tmp_path / "one.png")
+    Image.fromarray(one).save(p)
+    assert np.array_equal(decode_image(p, R16), one)
+    gray = np.arange(7 * 3, dtype=np.uint8).reshape(3, 7) * 11
+    p = str(tmp_path / "g.tif")
+    Image.fromarray(gray).save(p)
+    assert np.array_equal(decode_image(p, RGBA8), rgba_of(gray))
+    # a 16-bit RGB image fits neither attachment format
+    import struct
+    import zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+
+    raw = b"".join(b"\x00" + bytes(2 * 6 * 2) for _ in range(2))
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 2, 2, 16, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+    for fmt in (R16, RGBA8):
+        with pytest.raises(bt._ffi.BtError) as e:
+            decode_image(png, fmt)
+        assert e.value.status == -5
+    # an interlaced PNG is refused, not mis-decoded
+    inter = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 2, 2, 8, 0, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(b"\x00" * 12)) + chunk(b"IEND", b"")
+    with pytest.raises(bt._ffi.BtError) as e:
+        decode_image(inter, RGBA8)
+    assert e.value.status == -5

@@ -186,3 +186,26 @@ def test_compute_blend_known_answers():
     assert lod == 2 and ratio == pytest.approx(0.5, abs=1e-5)
     assert tree.compute_blend((10.0 + 1000.0 / 2 ** 2.5, 0.0, 3.0)) == (2, 0.0)
     assert tree.compute_blend((10.0 + 1e-9, 0.0, 3.0))[0] == 4  # capped at lod_count - 0.00001
+
+
+def test_null_and_invalid_arguments_are_status_codes():
+    L = _ffi.lib()
+    v = _ffi.ViewStateC()
+    pos = (C.c_double * 3)(0.0, 1.0, 0.0)
+    model = model_c(bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    vc = view_config_c(bt.TerrainViewConfig())
+    assert L.bt_view_state_from_config(None, C.byref(vc), pos, 0.0, C.byref(v)) == -1
+    assert L.bt_view_state_from_config(C.byref(model), None, pos, 0.0, C.byref(v)) == -1
+    assert L.bt_view_state_from_config(C.byref(model), C.byref(vc), pos, 0.0, None) == -1
+    bad = model_c(bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    bad.kind = 7
+    assert L.bt_view_state_from_config(C.byref(bad), C.byref(vc), pos, 0.0, C.byref(v)) == -1 and b"model" in L.bt_last_error()
+    bad.kind, bad.a = 2, 1.0  # ellipsoid without a minor axis
+    assert L.bt_view_state_from_config(C.byref(bad), C.byref(vc), pos, 0.0, C.byref(v)) == -1
+    assert L.bt_tile_tree_create(None, C.byref(model), 4, C.byref(vc), C.byref(C.c_void_p())) == -1
+    assert L.bt_atlas_request_tile(None, _ffi.TileCoordinateC(0, 0, 0, 0)) == -1
+    assert L.bt_image_decode(None, 0, 1, C.byref(_ffi.ImageC())) == -1
+    d = _ffi.TerrainViewConfigC()
+    L.bt_terrain_view_config_default(C.byref(d))
+    assert (d.tree_size, d.geometry_tile_count, d.refinement_count, d.grid_size, d.origin_lod) == (8, 1000000, 30, 16, 10)
+    assert (d.subdivision_tolerance, d.load_distance, d.morph_distance, d.blend_distance) == (0.1, 2.5, 16.0, 2.0)
