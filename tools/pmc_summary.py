@@ -47,9 +47,13 @@ def main():
                 summary[k][name] = {"avg_per_launch": sum(values) / len(values), "launches": len(values)}
     for k, s in summary.items():
         if "FETCH_SIZE" in s and "WRITE_SIZE" in s:
-            rd = s["FETCH_SIZE"]["avg_per_launch"] * 1024 * 2
             wr = s["WRITE_SIZE"]["avg_per_launch"] * 1024
-            s["hbm_traffic_bytes"] = {"read_corrected_x2": rd, "write": wr, "total": rd + wr}
+            if k == "fused_main":  # 16-byte-per-lane streaming loads: the access width the guide's x2 correction is calibrated for
+                rd = s["FETCH_SIZE"]["avg_per_launch"] * 1024 * 2
+                s["hbm_traffic_bytes"] = {"read_corrected_x2": rd, "write": wr, "total": rd + wr}
+            else:  # narrower loads: FETCH_SIZE is uncalibrated on gfx950 — raw counter only, no traffic claim
+                s["hbm_counters_raw_bytes"] = {"FETCH_SIZE_raw": s["FETCH_SIZE"]["avg_per_launch"] * 1024, "WRITE_SIZE": wr,
+                                               "note": "uncalibrated for this kernel's access widths; not a traffic figure"}
     out = dict(summary)
     out["_note"] = ("HBM traffic per launch, corrected as MI355X_MICROARCH.md (HBM section) prescribes: rocprofv3 reports "
                     "FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts exactly half the bytes of a wide coalesced "
@@ -72,7 +76,7 @@ def main():
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
     for k in sorted(summary):
         t = summary[k].get("hbm_traffic_bytes")
-        print(k, {n: round(v["avg_per_launch"]) for n, v in summary[k].items() if n != "hbm_traffic_bytes"}, t)
+        print(k, {n: round(v["avg_per_launch"]) for n, v in summary[k].items() if isinstance(v, dict) and "avg_per_launch" in v}, t)
 
 
 if __name__ == "__main__":
