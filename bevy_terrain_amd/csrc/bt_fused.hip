@@ -215,14 +215,18 @@ __device__ __forceinline__ uint32_t downsample4_rgba8(uint32_t t00, uint32_t t01
     const uint32_t t[4] = {t00, t01, t10, t11};
     if ((t00 & 0x00FFFFFFu) != 0 && (t01 & 0x00FFFFFFu) != 0 && (t10 & 0x00FFFFFFu) != 0 && (t11 & 0x00FFFFFFu) != 0) {
         // all four count (the common case): ((((0 + a) + b) + c) + d) / 4, and x / 4 == x * 0.25 exactly; the sum of four
-        // values in [0, 1] stays in [0, 4], so the clamp of pack4x8unorm is a no-op
+        // values in [0, 1] stays in [0, 4], so the clamp of pack4x8unorm is a no-op.  Evaluated in the 2^8-scaled domain:
+        // F(t) = fma(x, RN(1 / 255), x) == 256 * RN(t / 255) for all 256 inputs (bt_selftest), additions and the exact
+        // factor 0.25 commute with the power-of-two scale, and 255 * v == (255 / 256) * (256 v) as real numbers, so every
+        // rounding sees the value the unscaled expression sees — the same texel for a third of the conversion work.
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t sh = 8 * k;
-            const float sum = ((unorm8_to_float((t00 >> sh) & 0xFFu) + unorm8_to_float((t01 >> sh) & 0xFFu)) + unorm8_to_float((t10 >> sh) & 0xFFu)) +
-                              unorm8_to_float((t11 >> sh) & 0xFFu);
-            out |= uint32_t(0.5f + 255.0f * (sum * 0.25f)) << sh;
+            const float a = float((t00 >> sh) & 0xFFu), bq = float((t01 >> sh) & 0xFFu), cq = float((t10 >> sh) & 0xFFu), d = float((t11 >> sh) & 0xFFu);
+            const float r = 1.0f / 255.0f;
+            const float sum = ((__builtin_fmaf(a, r, a) + __builtin_fmaf(bq, r, bq)) + __builtin_fmaf(cq, r, cq)) + __builtin_fmaf(d, r, d);
+            out |= uint32_t(0.5f + (255.0f / 256.0f) * (sum * 0.25f)) << sh;
         }
         return out;
     }
@@ -1076,6 +1080,236 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
     }
 }
 
+
+// ---- fused_direct (Rgba8): split + the two parent LODs WITHOUT LDS staging ------------------------------------------
+// Workgroup = 8 centre rows of one finest tile, thread = one centre column (two sweeps of 256).  The 9 source rows x 2
+// texels a column needs are requested up front straight from global memory (a 4-byte texel needs no sub-dword
+// extraction, neighbouring lanes share their texels through L1), filtered horizontally once each; row pairs reduce in
+// registers and lane pairs / quads through DPP to LOD-1 and LOD-2, whose centres are written into the parent tiles (their
+// aprons come from the batched stitch kernel).  Validity is handled in line: a pixel without data is not stored (it keeps the atlas
+// value, split.wgsl:37-42) and its previous value is fetched for the reduction.  The tile's own apron pixels (4 columns
+// per row, whole apron rows in the first / last block) take the general per-pixel path with the neighbour tile's formula.
+__device__ __forceinline__ uint32_t float_to_unorm8(float e) {
+    const float cl = e < 0.0f ? 0.0f : (e > 1.0f ? 1.0f : e);
+    return uint32_t(floorf(0.5f + 255.0f * cl));
+}
+struct H4 {
+    float h[4];
+    bool valid;
+};
+__device__ __forceinline__ H4 hrow_rgba8(uint32_t t0, uint32_t t1, float fx) {
+    H4 o;
+    o.valid = (t0 & 0xFFu) != 0 && (t1 & 0xFFu) != 0;  // textureGather(0, ..): channel 0 of both texels
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) o.h[k] = mixf(unorm8_to_float((t0 >> (8 * k)) & 0xFFu), unorm8_to_float((t1 >> (8 * k)) & 0xFFu), fx);
+    return o;
+}
+__device__ __forceinline__ uint32_t vmix_rgba8(const H4& top, const H4& bot, float fy) {
+    uint32_t out = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) out |= float_to_unorm8(mixf(top.h[k], bot.h[k], fy)) << (8 * k);
+    return out;
+}
+// The same two steps in the 2^8-scaled domain (the 8-bit twin of fused_main's trick, see there): F(t) = fma(x, r, x) with
+// r = RN(1 / 255) equals 256 * RN(t / 255) for all 256 inputs (bt_selftest, tests), every later operation is homogeneous,
+// 255 * v == (255 / 256) * V exactly, and with inputs in [0, 1] and weights in [0, 1] the clamp of pack4x8unorm cannot
+// change the result — bit-identical texels for a third of the conversion work.
+__device__ __forceinline__ H4 hrow_rgba8_scaled(uint32_t t0, uint32_t t1, float fx) {
+    H4 o;
+    o.valid = (t0 & 0xFFu) != 0 && (t1 & 0xFFu) != 0;
+    const float gx = 1.0f - fx;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const float a = float((t0 >> (8 * k)) & 0xFFu), bb = float((t1 >> (8 * k)) & 0xFFu);
+        o.h[k] = __builtin_fmaf(a, 1.0f / 255.0f, a) * gx + __builtin_fmaf(bb, 1.0f / 255.0f, bb) * fx;
+    }
+    return o;
+}
+__device__ __forceinline__ uint32_t vmix_rgba8_scaled(const H4& top, const H4& bot, float fy) {
+    const float gy = 1.0f - fy;
+    uint32_t out = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) out |= uint32_t(0.5f + (255.0f / 256.0f) * (top.h[k] * gy + bot.h[k] * fy)) << (8 * k);
+    return out;
+}
+typedef const uint8_t __attribute__((address_space(1))) * global_bytes_t;
+typedef const uint32_t __attribute__((address_space(1))) * global_u32_t;
+
+// general evaluation of the finest-LOD mosaic pixel (tile (tx, ty), centre coordinate (rx, ry)); `home` = the atlas tile
+// holding that pixel (its previous value is the result where the source has no data)
+__device__ __forceinline__ uint32_t rgba8_value_slow(const FusedArgs& A, const RasterDev& r, uint32_t tx, uint32_t rx, uint32_t ty, uint32_t ry,
+                                                     uint32_t home_index) {
+    const float scale = float(1u << A.lod);
+    const uint32_t c = A.m.center_size, b = A.m.border_size, T = A.m.texture_size;
+    const Axis ax = split_axis(rx, c, tx, scale, A.tlx, A.brx, r.width);
+    const Axis ay = split_axis(ry, c, ty, scale, A.tly, A.bry, r.height);
+    const global_u32_t row0 = (global_u32_t)((global_bytes_t)r.data + uint64_t(ay.i0) * r.pitch);
+    const global_u32_t row1 = (global_u32_t)((global_bytes_t)r.data + uint64_t(ay.i1) * r.pitch);
+    const H4 top = hrow_rgba8(row0[ax.i0], row0[ax.i1], ax.fr), bot = hrow_rgba8(row1[ax.i0], row1[ax.i1], ax.fr);
+    if (!(top.valid && bot.valid)) {
+        if (home_index == kInvalid) return 0;
+        return reinterpret_cast<const uint32_t*>(A.atlas)[uint64_t(home_index) * T * T + uint64_t(b + ry) * T + b + rx];
+    }
+    return vmix_rgba8(top, bot, ay.fr);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_direct_rgba8_kernel(FusedArgs A) {
+    constexpr uint32_t kRows = 8;
+    const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
+    const uint32_t blocks_per_tile = (c + kRows - 1) / kRows;
+    const uint32_t work = xcd_remap(blockIdx.x, gridDim.x);
+    const MainItem it = A.items[work / blocks_per_tile];
+    const uint32_t blk = work % blocks_per_tile, cr0 = blk * kRows, nrows = min(kRows, c - cr0);
+    const RasterDev raster = A.rasters[it.raster];
+    const float scale = float(1u << A.lod);
+    const uint32_t tid = threadIdx.x;
+    uint32_t* atlas = reinterpret_cast<uint32_t*>(A.atlas);
+    const uint32_t tile_texels = T * T;
+    uint32_t* tile = atlas + uint64_t(it.atlas_index) * tile_texels;
+    const uint32_t self4 = A.levels >= 2 ? grid_lookup(A, it.side, A.lod - 1, int(it.x >> 1), int(it.y >> 1)) : kInvalid;
+    const uint32_t self3 = A.levels >= 3 ? grid_lookup(A, it.side, A.lod - 2, int(it.x >> 2), int(it.y >> 2)) : kInvalid;
+
+    __shared__ Axis s_ay[kRows];
+    __shared__ int s_consecutive;
+    if (tid < nrows) s_ay[tid] = split_axis(cr0 + tid, c, it.y, scale, A.tly, A.bry, raster.height);
+    __syncthreads();
+    if (tid == 0) {
+        bool ok = nrows == kRows;
+        for (uint32_t r = 0; ok && r < kRows; r++) ok = s_ay[r].i0 == s_ay[0].i0 + int(r) && s_ay[r].i1 == s_ay[r].i0 + 1;
+        s_consecutive = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const bool consecutive = __builtin_amdgcn_readfirstlane(s_consecutive) != 0;
+    const global_bytes_t data = (global_bytes_t)raster.data;
+
+    const uint32_t c_lanes = (c + 3u) & ~3u;  // whole lane quads take part in the reductions
+    // the 2b apron columns of the block's rows ride in spare lanes of the last sweep when there are enough of them (T = 512,
+    // b = 2: lanes 252..255): same rows, the column axis of the west / east neighbour (or the own edge column clamped)
+    const uint32_t last_cx0 = (c_lanes - 1u) / 256u * 256u;
+    const bool aprons_in_sweep = last_cx0 + 256u >= c + 2u * b;
+    for (uint32_t cx0 = 0; cx0 < c_lanes || (aprons_in_sweep && cx0 <= last_cx0); cx0 += 256u) {
+        const uint32_t cx = cx0 + tid;
+        const bool active = cx < c;
+        const bool apron_lane = aprons_in_sweep && cx0 == last_cx0 && !active && cx - c < 2u * b;
+        uint32_t home = it.atlas_index, home_col = cx, store_px = b + cx;
+        Axis ax = Axis{0, 0, 0.0f};
+        if (active) {
+            ax = split_axis(cx, c, it.x, scale, A.tlx, A.brx, raster.width);
+        } else if (apron_lane) {
+            const uint32_t k = cx - c;
+            const int rx = k < b ? -1 : 1;
+            store_px = k < b ? k : c + k;
+            const uint32_t n = grid_lookup(A, it.side, A.lod, int(it.x) + rx, int(it.y));
+            if (n != kInvalid) {
+                home = n;
+                home_col = uint32_t(int(store_px) - int(b) - rx * int(c));
+                ax = split_axis(home_col, c, uint32_t(int(it.x) + rx), scale, A.tlx, A.brx, raster.width);
+            } else {
+                home_col = k < b ? 0u : c - 1u;
+                ax = split_axis(home_col, c, it.x, scale, A.tlx, A.brx, raster.width);
+            }
+        }
+        uint32_t out[kRows];
+        bool keep[kRows];
+#pragma unroll
+        for (uint32_t r = 0; r < kRows; r++) {
+            out[r] = 0;
+            keep[r] = false;
+        }
+        if (consecutive) {
+            const int y_first = __builtin_amdgcn_readfirstlane(s_ay[0].i0);
+            uint32_t raw0[kRows + 1], raw1[kRows + 1];
+#pragma unroll
+            for (uint32_t j = 0; j <= kRows; j++) {
+                const global_u32_t row = (global_u32_t)(data + uint64_t(y_first + int(j)) * raster.pitch);
+                raw0[j] = row[ax.i0];
+                raw1[j] = row[ax.i1];
+            }
+            H4 top = hrow_rgba8_scaled(raw0[0], raw1[0], ax.fr);
+#pragma unroll
+            for (uint32_t r = 0; r < kRows; r++) {
+                const H4 bot = hrow_rgba8_scaled(raw0[r + 1], raw1[r + 1], ax.fr);
+                keep[r] = !(top.valid && bot.valid);
+                out[r] = vmix_rgba8_scaled(top, bot, s_ay[r].fr);
+                top = bot;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t r = 0; r < kRows; r++) {
+                if (r >= nrows) continue;
+                const Axis ay = s_ay[r];
+                const global_u32_t row0 = (global_u32_t)(data + uint64_t(ay.i0) * raster.pitch), row1 = (global_u32_t)(data + uint64_t(ay.i1) * raster.pitch);
+                const H4 top = hrow_rgba8(row0[ax.i0], row0[ax.i1], ax.fr), bot = hrow_rgba8(row1[ax.i0], row1[ax.i1], ax.fr);
+                keep[r] = !(top.valid && bot.valid);
+                out[r] = vmix_rgba8(top, bot, ay.fr);
+            }
+        }
+        // finest texels; a centre pixel without data keeps (and reports) what the atlas holds, an apron pixel copies what
+        // its home tile holds (the rare path, taken per wave only when some lane needs it)
+        bool any_keep = false;
+#pragma unroll
+        for (uint32_t r = 0; r < kRows; r++) {
+            if ((active || apron_lane) && r < nrows && !keep[r]) tile[(b + cr0 + r) * T + store_px] = out[r];
+            any_keep = any_keep || keep[r];
+        }
+        if (__ballot((active || apron_lane) && any_keep)) {
+#pragma unroll
+            for (uint32_t r = 0; r < kRows; r++)
+                if ((active || apron_lane) && r < nrows && keep[r]) {
+                    out[r] = atlas[uint64_t(home) * tile_texels + (b + cr0 + r) * T + b + home_col];
+                    if (apron_lane) tile[(b + cr0 + r) * T + store_px] = out[r];
+                }
+        }
+        if (A.levels < 2 || self4 == kInvalid) continue;
+        // LOD-1: rows (2i, 2i+1) in registers, columns (cx, cx + 1) in the lane pair; downsample.wgsl OFFSETS order
+        uint32_t q[kRows / 2];
+#pragma unroll
+        for (uint32_t i = 0; i < kRows / 2; i++) {
+            const uint32_t p0 = uint32_t(__builtin_amdgcn_update_dpp(0, int(out[2 * i]), 0xB1, 0xf, 0xf, true));      // quad_perm [1, 0, 3, 2]
+            const uint32_t p1 = uint32_t(__builtin_amdgcn_update_dpp(0, int(out[2 * i + 1]), 0xB1, 0xf, 0xf, true));
+            q[i] = downsample4_rgba8(out[2 * i], out[2 * i + 1], p0, p1);
+            if (active && (tid & 1u) == 0 && 2 * i + 1 < nrows)  // centre texel; the parents' aprons come from the batched stitch kernel
+                atlas[uint64_t(self4) * tile_texels + (b + (it.y & 1u) * (c / 2u) + (cr0 >> 1) + i) * T + b + (it.x & 1u) * (c / 2u) + (cx >> 1)] = q[i];
+        }
+        if (A.levels < 3 || self3 == kInvalid) continue;
+        // LOD-2: the even lanes of a quad hold two adjacent LOD-1 pixels
+#pragma unroll
+        for (uint32_t j = 0; j < kRows / 4; j++) {
+            const uint32_t pa = uint32_t(__builtin_amdgcn_update_dpp(0, int(q[2 * j]), 0x4E, 0xf, 0xf, true));      // quad_perm [2, 3, 0, 1]
+            const uint32_t pb = uint32_t(__builtin_amdgcn_update_dpp(0, int(q[2 * j + 1]), 0x4E, 0xf, 0xf, true));
+            const uint32_t w = downsample4_rgba8(q[2 * j], q[2 * j + 1], pa, pb);
+            if (active && (tid & 3u) == 0 && 4 * j + 3 < nrows)
+                atlas[uint64_t(self3) * tile_texels + (b + (it.y & 3u) * (c / 4u) + (cr0 >> 2) + j) * T + b + (it.x & 3u) * (c / 4u) + (cx >> 2)] = w;
+        }
+    }
+
+    // the tile's own apron: stitch.wgsl:53-118 with the neighbour's centre pixel evaluated from the source (its own
+    // formula), or the own centre clamped where the neighbour does not exist (same-face neighbours only: cube seams
+    // are re-stitched by the batched kernel afterwards)
+    const uint32_t n_cols = aprons_in_sweep ? 0u : nrows * 2u * b, n_top = blk == 0 ? b * T : 0u, n_bottom = blk == blocks_per_tile - 1 ? b * T : 0u;
+    for (uint32_t i = tid; i < n_cols + n_top + n_bottom; i += 256u) {
+        uint32_t px, py;
+        if (i < n_cols) {  // the apron columns of this block's rows
+            const uint32_t r = i / (2u * b), k = i % (2u * b);
+            px = k < b ? k : c + k;
+            py = b + cr0 + r;
+        } else if (i < n_cols + n_top) {  // whole apron rows above the first block ...
+            px = (i - n_cols) % T;
+            py = (i - n_cols) / T;
+        } else {  // ... and below the last one
+            px = (i - n_cols - n_top) % T;
+            py = b + c + (i - n_cols - n_top) / T;
+        }
+        const int rx = px < b ? -1 : (px >= b + c ? 1 : 0), ry = py < b ? -1 : (py >= b + c ? 1 : 0);
+        const uint32_t n = grid_lookup(A, it.side, A.lod, int(it.x) + rx, int(it.y) + ry);
+        const bool have = n != kInvalid;
+        const uint32_t sx = have ? uint32_t(int(it.x) + rx) : it.x, sy = have ? uint32_t(int(it.y) + ry) : it.y;
+        const uint32_t qx = have ? uint32_t(int(px) - int(b) - rx * int(c)) : min(max(px, b), b + c - 1u) - b;
+        const uint32_t qy = have ? uint32_t(int(py) - int(b) - ry * int(c)) : min(max(py, b), b + c - 1u) - b;
+        tile[py * T + px] = rgba8_value_slow(A, raster, sx, qx, sy, qy, have ? n : it.atlas_index);
+    }
+}
+
 // exhaustive device check of the fast unorm conversion against correctly rounded division
 __global__ void selftest_kernel(uint32_t* failures) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1090,6 +1324,7 @@ __global__ void selftest_kernel(uint32_t* failures) {
         volatile float d = 255.0f;
         const float x = float(t), r = 1.0f / 255.0f, q0 = x * r;
         if (__builtin_fmaf(__builtin_fmaf(-q0, 255.0f, x), r, q0) != x / d) atomicAdd(failures, 1u);
+        if (__builtin_fmaf(x, r, x) != 256.0f * (x / d)) atomicAdd(failures, 1u);  // fused_direct's scaled conversion
     }
 }
 
@@ -1170,7 +1405,9 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                              m.center_size >= 2 * m.border_size && m.border_size != 0 && (m.format != BT_FORMAT_R16 || (m.border_size & 1u) == 0);
         const bool main_ok = tail_ok && m.format == BT_FORMAT_R16 && m.texture_size <= 512 && m.border_size <= 8;
         if (!tail_ok) return false;
-        const bool hybrid = !main_ok;
+        // Rgba8: fused_direct (no LDS staging) produces the finest LOD with its aprons and the two parent LODs
+        const bool direct = !main_ok && m.format == BT_FORMAT_RGBA8;
+        const bool hybrid = !main_ok && !direct;
         // the kernels keep texel offsets into the atlas in 32 bits
         if (uint64_t(a->config.atlas_size) * m.texture_size * m.texture_size >= (1ull << 32)) return false;
         const uint32_t lod_hi = splits[0]->coord.lod;
@@ -1237,7 +1474,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         const uint32_t world = p->shard_world, rank = p->shard_rank;
         const uint32_t nlods_all = lod_hi - lod_lo + 1, main_levels_all = std::min(3u, nlods_all);
         const uint32_t strips = 1u << (lod_hi - (main_levels_all - 1)), units = sides * strips;
-        bool shard = world > 1 && units % world == 0 && !hybrid;
+        bool shard = world > 1 && units % world == 0 && !hybrid && !direct;
         std::vector<bt_shard_range> ranges;
         std::vector<bt_shard_piece> pieces;
         if (shard) {
@@ -1374,6 +1611,20 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             lt.task_count = uint32_t(tasks.size()) - lt.first_task;
             lt.algorithmic_bytes = uint64_t(lt.task_count) * 2 * (2 * m.border_size * (Tt + cc)) * bpp;
             if (lt.task_count) plan.push_back(lt);
+        } else if (direct) {
+            FusedJobDev job{args, ai};
+            job.args.lod = lod_hi;
+            job.args.levels = main_levels;
+            job.args.item_count = uint32_t(items.size());
+            Launch ld{};
+            ld.kind = kLaunchFusedDirect;
+            ld.attachment = ai;
+            ld.task_count = uint32_t(items.size());
+            ld.aux0 = uint32_t(jobs.size());
+            ld.algorithmic_bytes = source_bytes;
+            for (uint32_t k = 0; k < main_levels; k++) ld.algorithmic_bytes += tiles_at(lod_hi - k) * Tt * Tt * bpp;
+            jobs.push_back(job);
+            plan.push_back(ld);
         } else {
         FusedJobDev main_job{args, ai};
 #ifdef BT_DEBUG_HOOKS
@@ -1456,7 +1707,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         }
 
         const bool tail_follows = lod_hi - (main_levels - 1) > lod_lo;
-        const bool rows_in_tail = !shard && tail_follows && main_levels > 1 && m.border_size % 2u == 0;
+        const bool rows_in_tail = !direct && !shard && tail_follows && main_levels > 1 && m.border_size % 2u == 0;
         if (main_levels > 1 && !rows_in_tail) {
             // fused_main writes the centres and the left / right apron columns of the parent / grand-parent tiles; their
             // top / bottom apron rows (whole 1 KB rows) come from the batched stitch kernel — sharded: everything, after
@@ -1485,8 +1736,8 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             ls.phase = shard ? 2u : 0u;
             // fused_main also writes the left / right apron columns of these tiles (from registers); sharded runs lose
             // the ones that crossed a strip boundary in the all-gather and re-stitch everything
-            ls.aux0 = shard ? 0u : 1u;
-            if (!shard) ls.algorithmic_bytes = uint64_t(ls.task_count) * 2 * (2 * m.border_size * Tt) * bpp;
+            ls.aux0 = (shard || direct) ? 0u : 1u;  // (fused_direct writes centres only: all four sides)
+            if (!shard && !direct) ls.algorithmic_bytes = uint64_t(ls.task_count) * 2 * (2 * m.border_size * Tt) * bpp;
             if (ls.task_count) plan.push_back(ls);
         }
 
@@ -1563,7 +1814,10 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
     FusedJobDev job = jobs[l.aux0];
     if (l.kind == kLaunchFusedMain && (jobs[l.aux0].main_runs++ & 1u)) std::swap(job.args.todo, job.args.todo_next);
     job.args.rasters = p->rasters_dev;
-    if (l.kind == kLaunchFusedMain) {
+    if (l.kind == kLaunchFusedDirect) {
+        const uint32_t blocks_per_tile = (job.args.m.center_size + 7u) / 8u;
+        fused_direct_rgba8_kernel<<<job.args.item_count * blocks_per_tile, 256, 0, p->ctx->stream>>>(job.args);
+    } else if (l.kind == kLaunchFusedMain) {
         const uint32_t blocks = job.args.item_count * job.args.groups;
         if (job.args.lds_rows) {
             size_t lds = sizeof(MainShared) + 2 * size_t(job.args.lds_rows) * job.args.lds_pitch * 2;

@@ -153,7 +153,7 @@ struct bt_atlas {
 namespace bt {
 
 // One launch of the compiled plan.
-enum LaunchKind : uint32_t { kLaunchSplit, kLaunchDownsample, kLaunchStitch, kLaunchFusedMain, kLaunchFusedTail };
+enum LaunchKind : uint32_t { kLaunchSplit, kLaunchDownsample, kLaunchStitch, kLaunchFusedMain, kLaunchFusedTail, kLaunchFusedDirect };
 struct Launch {
     LaunchKind kind;
     uint32_t attachment;

@@ -502,3 +502,28 @@ def test_preprocess_from_png_and_tiff_files(device, tmp_path):
     oracle.preprocess_tile(0, height, (0, 3)).preprocess_tile(1, rgba, (0, 3)).preprocess_tile(2, height, (0, 3)).run(8)
     for i in range(3):
         assert K.assert_atlas_equal(atlas, oracle, i) == 21
+
+
+@pytest.mark.parametrize("fmt", [O.FORMAT_R16, O.FORMAT_RGBA8])
+def test_two_contexts_interleaved_on_one_gpu_stay_exact(device, fmt):
+    """Independent jobs in flight: two contexts (a HIP stream each) with their own atlas and source take turns without
+    any synchronisation in between — the kernels of one job run beside the other's (what bench.py --pipeline 2 does).
+    Sources with holes, so the todo path and its alternating lists are exercised too."""
+    T, b, lods = 256, 2, 4
+    srcs = [K.random_raster(fmt, 1000, 1100, 900 + k, holes=0.03) for k in range(2)]
+    devices = [device, bt.Device(device.index)]
+    jobs = []
+    for d, src in zip(devices, srcs):
+        cfg = bt.TerrainConfig(lod_count=lods, atlas_size=128, path="terrains/test", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+        cfg.add_attachment(bt.AttachmentConfig(name="att", texture_size=T, border_size=b, format=K.FMT[fmt]))
+        atlas = bt.TileAtlas.new(cfg, d)
+        server = bt.AssetServer().insert("src", src)
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_tile(
+            bt.PreprocessDataset(attachment_index=0, path="src", lod_range=range(0, lods)), server, atlas)
+        jobs.append((atlas, pre, server))
+    for k in (0, 1, 0, 1, 1, 0, 0, 1):
+        atlas, pre, _ = jobs[k]
+        pre.run(atlas, keep_queue=True, sync=False)
+    assert jobs[0][1].stats()["fused_jobs"] == 1
+    for (atlas, _, _), src in zip(jobs, srcs):
+        assert K.assert_atlas_equal(atlas, K.oracle_planar(src, lods, T, b, fmt)) == 85
