@@ -462,7 +462,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         const global_bytes base = data + uint64_t(uint32_t(ymin)) * raster.pitch;  // uniform
         const uint32_t bound = slots * P * 2u;
 #pragma unroll
-        for (uint32_t i = 0; i < kBatch; i++) v[i] = *(global_u4)(base + (lds_off[i] < bound ? src_off[i] : safe_off));
+        for (uint32_t i = 0; i < kBatch; i++) {
+            const global_u4 ptr = (global_u4)(base + (lds_off[i] < bound ? src_off[i] : safe_off));
+            v[i] = BT_ABLATE(A, 32768u) ? __builtin_nontemporal_load(ptr) : *ptr;  // (32768: streaming loads, timing experiment)
+        }
     };
     // registers -> LDS; returns this thread's "saw a no-data texel" bit
     auto stage_commit = [&](uint16_t* s_src, uint32_t slots, const u32x4 (&v)[kBatch]) -> bool {
@@ -690,7 +693,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         }
                         if (!is_idle && !BT_ABLATE(A, 2u)) {
 #pragma unroll
-                            for (uint32_t i = 0; i < 4; i++) dst5[(4 * quad + i) * (T / 2)] = ua[i] | (ub[i] << 16);
+                            for (uint32_t i = 0; i < 4; i++) {
+                                if (BT_ABLATE(A, 8192u)) __builtin_nontemporal_store(ua[i] | (ub[i] << 16), &dst5[(4 * quad + i) * (T / 2)]);  // (8192: streaming stores)
+                                else dst5[(4 * quad + i) * (T / 2)] = ua[i] | (ub[i] << 16);
+                            }
                         }
                         if (do4) {
                             // two level-1 pixels (row pairs 0-1, 2-3 of the quad), one per packed lane: ((a0 + a1) + b0) + b1, / 4
@@ -712,7 +718,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             if (is_centre && (tid & 1u) == 0 && !BT_ABLATE(A, 4u)) {
                                 uint32_t* dst = reinterpret_cast<uint32_t*>(tile4 + (b + cy4_first) * T + b + cx4);
 #pragma unroll
-                                for (uint32_t j = 0; j < 4; j++) dst[j * (T / 2)] = both[j];
+                                for (uint32_t j = 0; j < 4; j++) {
+                                    if (BT_ABLATE(A, 16384u)) __builtin_nontemporal_store(both[j], &dst[j * (T / 2)]);  // (16384: streaming parent stores)
+                                    else dst[j * (T / 2)] = both[j];
+                                }
                             }
                         }
                         if (x4_count && !BT_ABLATE(A, 4u)) {  // a few lanes of a tile; one texel each unless the x neighbour is absent
@@ -992,6 +1001,10 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
     const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
     const uint32_t gx = blockIdx.x * 64u + 4u * tx, gy = blockIdx.y * 64u + 4u * ty;  // first input pixel
     const bool active = gx < size && gy < size;
+    // ONE division per axis: c is a multiple of 4, so the 4 x 4 block lies in one tile, and the tile / in-tile coordinates
+    // of its pixel at LOD-k follow by shifts: tile >> k, ((tile & (2^k - 1)) * c + rem) >> k
+    const uint32_t tile_x = gx / c, tile_y = gy / c, rem_x = gx - tile_x * c, rem_y = gy - tile_y * c;
+    const uint32_t rx1 = ((tile_x & 1u) * c + rem_x) >> 1, ry1 = ((tile_y & 1u) * c + rem_y) >> 1;
     TT* atlas = reinterpret_cast<TT*>(A.atlas);
     auto down = [](uint32_t t00, uint32_t t01, uint32_t t10, uint32_t t11) -> uint32_t {
         if constexpr (kR16) return downsample4(t00, t01, t10, t11);
@@ -1006,14 +1019,14 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
     // all tile lookups up front (independent of the data): one round of memory latency instead of four
     uint32_t idx = kInvalid, self1 = kInvalid, self2 = kInvalid, self3 = kInvalid;
     if (active) {
-        idx = grid_lookup(A, side, A.lod, int(gx / c), int(gy / c));
-        self1 = grid_lookup(A, side, A.lod - 1, int((gx >> 1) / c), int((gy >> 1) / c));
-        if (A.levels >= 2) self2 = grid_lookup(A, side, A.lod - 2, int((gx >> 2) / c), int((gy >> 2) / c));
-        if (A.levels >= 3) self3 = grid_lookup(A, side, A.lod - 3, int((gx >> 3) / c), int((gy >> 3) / c));
+        idx = grid_lookup(A, side, A.lod, int(tile_x), int(tile_y));
+        self1 = grid_lookup(A, side, A.lod - 1, int(tile_x >> 1), int(tile_y >> 1));
+        if (A.levels >= 2) self2 = grid_lookup(A, side, A.lod - 2, int(tile_x >> 2), int(tile_y >> 2));
+        if (A.levels >= 3) self3 = grid_lookup(A, side, A.lod - 3, int(tile_x >> 3), int(tile_y >> 3));
     }
     if (active) {
         if (idx != kInvalid) {  // an absent tile reads as no data
-            const TT* p = atlas + uint64_t(idx) * tile_texels + (b + gy % c) * T + b + gx % c;
+            const TT* p = atlas + uint64_t(idx) * tile_texels + (b + rem_y) * T + b + rem_x;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 if constexpr (kR16) {  // 4-byte aligned (b even)
@@ -1044,11 +1057,10 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
 #pragma unroll
         for (int k = 0; k < 2; k++) q[r][k] = down(t[2 * r][2 * k], t[2 * r + 1][2 * k], t[2 * r][2 * k + 1], t[2 * r + 1][2 * k + 1]);
     if (active) {
-        const uint32_t x1 = gx >> 1, y1 = gy >> 1;
         const uint32_t self = self1;
         if (self != kInvalid) {
             // R16: the two pixels of a row are one aligned dword of the tile (x1, b, c even); aprons per pixel, edge pixels only
-            TT* centre = atlas + uint64_t(self) * tile_texels + (b + y1 % c) * T + b + x1 % c;
+            TT* centre = atlas + uint64_t(self) * tile_texels + (b + ry1) * T + b + rx1;
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 if constexpr (kR16) {
@@ -1058,25 +1070,25 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
                     centre[r * T + 1] = q[r][1];
                 }
 #pragma unroll
-                for (int k = 0; k < 2; k++) push_pixel<false, TT>(A, side, A.lod - 1, x1 / c, y1 / c, self, x1 % c + k, y1 % c + r, TT(q[r][k]));
+                for (int k = 0; k < 2; k++) push_pixel<false, TT>(A, side, A.lod - 1, tile_x >> 1, tile_y >> 1, self, rx1 + k, ry1 + r, TT(q[r][k]));
             }
         }
     }
     if (A.levels < 2) return;
     const uint32_t v2 = down(q[0][0], q[1][0], q[0][1], q[1][1]);
     if (active) {
-        const uint32_t x2 = gx >> 2, y2 = gy >> 2;
         const uint32_t self = self2;
-        if (self != kInvalid) push_pixel<true, TT>(A, side, A.lod - 2, x2 / c, y2 / c, self, x2 % c, y2 % c, TT(v2));
+        if (self != kInvalid)
+            push_pixel<true, TT>(A, side, A.lod - 2, tile_x >> 2, tile_y >> 2, self, ((tile_x & 3u) * c + rem_x) >> 2, ((tile_y & 3u) * c + rem_y) >> 2, TT(v2));
     }
     if (A.levels < 3) return;
     // lod-3: threads (tx, ty) with both even own the pixel; partners are lanes +1 (dx), +16 (dy), +17
     const uint32_t right = __shfl_down(v2, 1), below = __shfl_down(v2, 16), diag = __shfl_down(v2, 17);
     if (active && ((tx | ty) & 1u) == 0) {
         const uint32_t v3 = down(v2, below, right, diag);
-        const uint32_t x3 = gx >> 3, y3 = gy >> 3;
         const uint32_t self = self3;
-        if (self != kInvalid) push_pixel<true, TT>(A, side, A.lod - 3, x3 / c, y3 / c, self, x3 % c, y3 % c, TT(v3));
+        if (self != kInvalid)
+            push_pixel<true, TT>(A, side, A.lod - 3, tile_x >> 3, tile_y >> 3, self, ((tile_x & 7u) * c + rem_x) >> 3, ((tile_y & 7u) * c + rem_y) >> 3, TT(v3));
     }
 }
 
