@@ -512,8 +512,9 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         off = 0;
         count = 0;
         if (!is_centre || self == kInvalid) return;
-        const uint32_t mask = (1u << shift) - 1u;
-        const bool left = (it.x & mask) == 0 && cx < b, right = (it.x & mask) == mask && cx >= c - b;
+        // cx is the column in the PARENT tile (it already carries this finest tile's share of it): with narrow tiles
+        // (c / 2^shift < b) the strip of width b spans more than one finest tile's share
+        const bool left = cx < b, right = cx >= c - b;
         if (!left && !right) return;
         const uint32_t n = grid_lookup(A, it.side, A.lod - shift, int(it.x >> shift) + (left ? -1 : 1), int(it.y >> shift));
         const uint32_t j = left ? cx : cx - (c - b);

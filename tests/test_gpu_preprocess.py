@@ -527,3 +527,32 @@ def test_two_contexts_interleaved_on_one_gpu_stay_exact(device, fmt):
     assert jobs[0][1].stats()["fused_jobs"] == 1
     for (atlas, _, _), src in zip(jobs, srcs):
         assert K.assert_atlas_equal(atlas, K.oracle_planar(src, lods, T, b, fmt)) == 85
+
+
+@pytest.mark.parametrize("cube", [False, True])
+@pytest.mark.parametrize("T,b", [(16, 4), (24, 4), (20, 2)])
+def test_fused_path_narrow_tiles_wide_borders(device, cube, T, b):
+    """c / 4 < b: the b-wide apron strip of a grand-parent tile spans the shares of more than one finest tile (found by
+    the random sweep: the x pushes of fused_main assumed the strip lies inside the first / last finest tile's share)."""
+    lods, fmt = 4, O.FORMAT_R16
+    if cube:
+        faces = [K.random_raster(fmt, 21, 21, 49 + s, holes=0.3) for s in range(6)]
+        cfg = bt.TerrainConfig(lod_count=lods, atlas_size=600, path="terrains/narrow")
+        cfg.add_attachment(bt.AttachmentConfig(name="att", texture_size=T, border_size=b, format=K.FMT[fmt]))
+        atlas = bt.TileAtlas.new(cfg, device)
+        server = bt.AssetServer()
+        for s in range(6):
+            server.insert(f"f{s}", faces[s])
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_spherical(
+            bt.SphericalDataset(attachment_index=0, paths=[f"f{s}" for s in range(6)], lod_range=range(0, lods)), server, atlas)
+        pre.run(atlas)
+        assert pre.stats()["fused_jobs"] == 1
+        oracle = O.OracleAtlas(lods, 600, True, [(T, b, 1, fmt)])
+        oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(8)
+        assert K.assert_atlas_equal(atlas, oracle) == 6 * 85
+    else:
+        for holes in (0.0, 0.3):
+            src = K.random_raster(fmt, 70, 61, 5, holes=holes)
+            atlas, pre = K.product_planar(device, src, lods, T, b, fmt)
+            assert pre.stats()["fused_jobs"] == 1
+            assert K.assert_atlas_equal(atlas, K.oracle_planar(src, lods, T, b, fmt)) == 85
