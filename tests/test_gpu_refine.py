@@ -103,3 +103,27 @@ def test_overflow_is_reported(device):
     with pytest.raises(bt._ffi.BtError) as e:
         prepass.read()
     assert e.value.status == -7
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_random_views_equal_the_oracle_list(device, seed):
+    """Random models, view configs and camera teleports (far out, skimming the surface, above cube edges and corners):
+    the final tile list equals the oracle's sequential run, element for element; small frames also the numpy model's."""
+    from test_gpu_tile_tree import draw_tree_case
+
+    model, _, _, tree_cfg, pts = draw_tree_case(1000 + seed)
+    rng = np.random.default_rng(31_000 + seed)
+    cfg = bt.TerrainViewConfig(geometry_tile_count=150000, refinement_count=int(rng.choice([4, 12, 30])),
+                               grid_size=int(rng.choice([4, 16, 32])), subdivision_tolerance=float(rng.choice([0.05, 0.1, 0.5])),
+                               morph_distance=float(rng.choice([2.0, 8.0, 16.0])), origin_lod=tree_cfg["origin_lod"])
+    prepass = bt.TilingPrepass(device, cfg.geometry_tile_count)
+    for frame, pos in enumerate(pts[:10]):
+        v = bt.make_view_state(model, cfg, pos, approximate_height=float(rng.uniform(0.0, 1.0)))
+        prepass.run(v)
+        ours, indirect = prepass.read()
+        exp, exp_indirect, _ = O.refine(oracle_view(v))
+        assert np.array_equal(ours, exp), (seed, frame, pos)
+        assert list(indirect) == exp_indirect
+        if len(ours) < 3000:
+            final, dropped, _ = R.refine(v)
+            assert np.array_equal(ours, final) or len(dropped) > 0, (seed, frame)

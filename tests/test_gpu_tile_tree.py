@@ -221,3 +221,60 @@ def test_tile_is_loaded_only_when_all_its_attachments_are(device, tmp_path):
     assert lod == 1
     assert np.array_equal(fresh.download_tile(0, idx), originals[(0, 1, 1, 0)][0])
     assert np.array_equal(fresh.download_tile(1, idx), originals[(0, 1, 1, 0)][1])
+
+
+def draw_tree_case(seed):
+    rng = np.random.default_rng(77_000 + seed)
+    kind = ["planar", "sphere", "ellipsoid"][seed % 3]
+    centre = tuple(float(v) for v in rng.uniform(-500.0, 500.0, 3))
+    if kind == "planar":
+        side = float(rng.choice([10.0, 1000.0, 250000.0]))
+        lo, hi = 0.0, float(rng.choice([1.0, 0.25 * side]))
+        model, omodel = bt.TerrainModel.planar(centre, side, lo, hi), O.make_model("planar", centre, side, 0.0, lo, hi)
+        scale = side
+    elif kind == "sphere":
+        radius = float(rng.choice([50.0, 6371000.0]))
+        lo, hi = -0.002 * radius, 0.0015 * radius
+        model, omodel = bt.TerrainModel.sphere(centre, radius, lo, hi), O.make_model("spherical", centre, radius, 0.0, lo, hi)
+        scale = radius
+    else:
+        major = float(rng.choice([100.0, 6378137.0]))
+        minor = major * float(rng.choice([0.5, 0.9966, 1.0]))
+        lo, hi = -0.002 * major, 0.0015 * major
+        model, omodel = bt.TerrainModel.ellipsoid(centre, major, minor, lo, hi), O.make_model("ellipsoidal", centre, major, minor, lo, hi)
+        scale = major
+    lods = int(rng.integers(1, 16))
+    cfg = dict(tree_size=int(rng.choice([2, 4, 8, 16])), load_distance=float(rng.choice([0.6, 2.5, 5.0])),
+               blend_distance=float(rng.choice([1.0, 2.0])), origin_lod=int(rng.integers(0, 14)))
+    pts = []
+    for _ in range(24):  # teleports, not a smooth path: far away, skimming the surface, inside the body, on face edges
+        u = rng.random()
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        if kind == "planar":
+            p = np.array(centre) + np.array([rng.uniform(-0.8, 0.8) * scale, rng.choice([1e-3, 0.01, 0.3, 3.0]) * scale, rng.uniform(-0.8, 0.8) * scale])
+        elif u < 0.2:  # exactly above a cube edge / corner / face centre
+            e = np.array(rng.choice([-1.0, 0.0, 1.0], 3))
+            e = e if np.any(e) else np.array([0.0, 1.0, 0.0])
+            p = np.array(centre) + e / np.linalg.norm(e) * scale * rng.choice([1.0001, 1.3, 8.0])
+        else:
+            p = np.array(centre) + d * scale * rng.choice([0.4, 0.999, 1.00001, 1.01, 2.0, 50.0])
+        pts.append(tuple(float(v) for v in p))
+    return model, omodel, lods, cfg, pts
+
+
+@pytest.mark.parametrize("seed", range(45))
+def test_update_random_models_configs_and_teleports(device, seed):
+    model, omodel, lods, cfg, pts = draw_tree_case(seed)
+    vc = bt.TerrainViewConfig(**cfg)
+    tree = bt.TileTree(dummy_atlas(device, model, lods), model, lods, vc)
+    otree = O.TileTree(omodel, lods, O.make_view_config(**cfg))
+    for frame, pos in enumerate(pts):
+        released, requested = tree.update(pos)
+        exp_released, exp_requested = otree.update(pos)
+        assert released == exp_released, (seed, frame, pos)
+        assert requested == exp_requested, (seed, frame, pos)
+        entries, origins, coords, flags = tree.read()
+        e2, o2, c2, f2 = otree.read()
+        assert np.array_equal(origins, o2) and np.array_equal(coords, c2) and np.array_equal(flags, f2), (seed, frame)
+    tree.close()
