@@ -596,7 +596,12 @@ bt_status save_tiles(bt_atlas* a, uint32_t ai, const char* directory, std::vecto
         if (e != hipSuccess) rc = hip_fail(e, "save events");
     }
     if (rc == BT_OK) {
-        const uint32_t threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        // 16 writers: measured on tmpfs and the overlay disk, 6 / 8 / 12 / 16 / 24 / 32 / 64 / 128 threads write at 29 / 34 / 42 /
+        // 46-49 / 46 / 35 / 4 / 5 GB/s — beyond ~24 the page-cache allocation lock dominates
+        uint32_t threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+#ifdef BT_DEBUG_HOOKS
+        if (const char* e = getenv("BT_SAVE_THREADS")) threads = std::max(1, atoi(e));  // tools build only: writer-count experiments
+#endif
         FileWriters writers(threads, kBuffers);
         const size_t n = tiles.size(), chunks = (n + chunk - 1) / chunk;
         auto hand_over = [&](size_t c) -> bt_status {  // chunk c has been enqueued: wait for its copies, queue its files
