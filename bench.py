@@ -132,6 +132,24 @@ def end_to_end(device, src_ptr):
                 best, fs = mnt, typ
     except OSError:
         pass
+    # the way back (the streaming side's seam, tile_atlas.rs:77-116 + gpu_tile_atlas.rs:309-336): config.tc + every
+    # .bin file -> a fresh atlas, verified against the atlas that wrote them
+    load = None
+    try:
+        atlas2 = bt.TileAtlas.new(cfg, device)
+        atlas2.load_tile_config(root)
+        device.synchronize()
+        t0 = time.perf_counter()
+        atlas2.load_tiles(0, root)
+        device.synchronize()
+        t1 = time.perf_counter()
+        order = {(c.side, c.lod, c.x, c.y): i for c, i in atlas.tiles()}
+        ok = 0
+        for c, i in atlas2.tiles()[:64]:
+            ok += int(np.array_equal(atlas2.download_tiles(0, i, 1)[0], atlas.download_tiles(0, order[(c.side, c.lod, c.x, c.y)], 1)[0]))
+        load = {"ms": (t1 - t0) * 1e3, "GBps": written / (t1 - t0) / 1e9, "tiles": len(atlas2.tiles()), "spot_checked_identical": ok}
+    except Exception as e:  # a side measurement of a side measurement
+        load = {"error": repr(e)}
     shutil.rmtree(root, ignore_errors=True)
     up, run, save = results[-1]
     total = up + run + save
@@ -139,6 +157,7 @@ def end_to_end(device, src_ptr):
             "upload_ms": up * 1e3, "upload_GBps": host.nbytes / up / 1e9,
             "kernels_ms": run * 1e3,
             "save_ms": save * 1e3, "save_GBps": written / save / 1e9, "files": len(files), "bytes_written": written,
+            "load_back": load,  # not part of "ms"
             "filesystem": fs, "directory": root, "warm_up_pass_ms": sum(results[0]) * 1e3,
             "span": "source raster in pageable host memory -> hipMalloc + H2D -> 3 kernels -> D2H through 3 pinned "
                     "buffers + writer threads -> 1365 .bin files + config.tc (preprocessor.rs:363,419)"}

@@ -496,6 +496,7 @@ class FileWriters {
         const uint8_t* data;
         size_t bytes;
         uint32_t buffer;
+        bool read = false;  // fill `data` from the file, which must hold exactly `bytes` (tile load path)
     };
     FileWriters(uint32_t threads, uint32_t buffers) : pending_(buffers, 0) {
         for (uint32_t i = 0; i < threads; i++) workers_.emplace_back([this] { run(); });
@@ -541,6 +542,34 @@ class FileWriters {
             }
             bool ok = false;
             std::string why;
+            if (j.read) {
+                const int fd = open(j.path.c_str(), O_RDONLY);
+                if (fd >= 0) {
+                    uint8_t* dst = const_cast<uint8_t*>(j.data);
+                    size_t done = 0;
+                    while (done < j.bytes) {
+                        const ssize_t r = ::read(fd, dst + done, j.bytes - done);
+                        if (r <= 0) break;
+                        done += size_t(r);
+                    }
+                    uint8_t extra;
+                    ok = done == j.bytes && ::read(fd, &extra, 1) == 0;
+                    close(fd);
+                    if (!ok) why = "tile file " + j.path + " does not hold " + std::to_string(j.bytes) + " bytes";
+                } else {
+                    why = "tile file not found: " + j.path;
+                }
+                {
+                    std::lock_guard<std::mutex> lock(m_);
+                    if (!ok && !failed_) {
+                        failed_ = true;
+                        error_ = why;
+                    }
+                    pending_[j.buffer]--;
+                }
+                done_.notify_all();
+                continue;
+            }
             const int fd = open(j.path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
             if (fd >= 0) {
                 size_t done = 0;
@@ -796,47 +825,71 @@ bt_status bt_atlas_load_tiles(bt_atlas* a, uint32_t ai, const char* directory, c
     }
     if (!count) return BT_OK;
     BT_HIP(hipSetDevice(a->ctx->device));
+    // files -> three pinned buffers (reader threads) -> H2D on the context's stream: chunk c + 1 is read while chunk c uploads
+    constexpr uint32_t kBuffers = bt_ctx::kStagingBuffers;
     const uint32_t chunk = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (32ull << 20) / at.tile_bytes)));
     if (bt_status s = ctx_staging(a->ctx, std::max<size_t>(32ull << 20, at.tile_bytes))) return s;
-    void* pinned = a->ctx->staging[0];
+    void** pinned = a->ctx->staging;
     std::vector<uint32_t> layers;
+    hipEvent_t uploaded[kBuffers] = {};
+    bool in_flight[kBuffers] = {};
     bt_status rc = BT_OK;
-    for (uint32_t i = 0; i < count && rc == BT_OK; i += chunk) {
-        const uint32_t n = std::min(chunk, count - i);
-        std::vector<uint32_t> idx(n);
-        for (uint32_t k = 0; k < n && rc == BT_OK; k++) {
-            bt_atlas_tile tile;
-            rc = bt_atlas_get_or_allocate_tile(a, coords[i + k], &tile);
-            if (rc) break;
-            idx[k] = tile.atlas_index;
-            char name[64];
-            bt_tile_name(coords[i + k], name, sizeof name);
-            const std::string path = std::string(directory) + "/" + name + ".bin";
-            FILE* f = fopen(path.c_str(), "rb");
-            if (!f) {
-                set_error("tile file not found: %s", path.c_str());
-                rc = BT_ERR_IO;
-                break;
-            }
-            const size_t got = fread((uint8_t*)pinned + at.tile_bytes * k, 1, at.tile_bytes, f);
-            const bool longer = got == at.tile_bytes && fgetc(f) != EOF;
-            fclose(f);
-            if (got != at.tile_bytes || longer) {
-                set_error("tile file %s does not hold %llu bytes", path.c_str(), (unsigned long long)at.tile_bytes);
-                rc = BT_ERR_IO;
-            }
-        }
-        for (uint32_t k = 0; k < n && rc == BT_OK; k++) {
-            hipError_t e = hipMemcpyAsync((uint8_t*)at.level0 + at.tile_bytes * idx[k], (const uint8_t*)pinned + at.tile_bytes * k,
-                                          at.tile_bytes, hipMemcpyHostToDevice, a->ctx->stream);
-            if (e != hipSuccess) rc = hip_fail(e, "tile upload");
-            layers.push_back(idx[k]);
-        }
-        if (rc == BT_OK) {
-            hipError_t e = hipStreamSynchronize(a->ctx->stream);  // the pinned buffer is refilled next
-            if (e != hipSuccess) rc = hip_fail(e, "tile upload");
-        }
+    for (uint32_t k = 0; k < kBuffers && rc == BT_OK; k++) {
+        hipError_t e = hipEventCreateWithFlags(&uploaded[k], hipEventDisableTiming);
+        if (e != hipSuccess) rc = hip_fail(e, "load events");
     }
+    if (rc == BT_OK) {
+        FileWriters readers(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), kBuffers);
+        const uint32_t chunks = (count + chunk - 1) / chunk;
+        std::vector<std::vector<uint32_t>> index(kBuffers);
+        auto upload = [&](uint32_t c) -> bt_status {  // chunk c has been queued for reading: wait for its files, enqueue its copies
+            const uint32_t k = c % kBuffers;
+            readers.wait_buffer(k);
+            if (bt_status s = readers.status()) return s;
+            for (size_t t = 0; t < index[k].size();) {  // runs of consecutive layers are one copy
+                size_t run = 1;
+                while (t + run < index[k].size() && index[k][t + run] == index[k][t] + run) run++;
+                hipError_t e = hipMemcpyAsync((uint8_t*)at.level0 + at.tile_bytes * index[k][t], (const uint8_t*)pinned[k] + at.tile_bytes * t,
+                                              at.tile_bytes * run, hipMemcpyHostToDevice, a->ctx->stream);
+                if (e != hipSuccess) return hip_fail(e, "tile upload");
+                t += run;
+            }
+            hipError_t e = hipEventRecord(uploaded[k], a->ctx->stream);
+            if (e != hipSuccess) return hip_fail(e, "tile upload");
+            in_flight[k] = true;
+            return BT_OK;
+        };
+        for (uint32_t c = 0; c < chunks && rc == BT_OK; c++) {
+            const uint32_t k = c % kBuffers, first = c * chunk, n = std::min(chunk, count - first);
+            if (in_flight[k]) {  // the buffer's previous upload must have left it
+                hipError_t e = hipEventSynchronize(uploaded[k]);
+                if (e != hipSuccess) rc = hip_fail(e, "tile upload");
+                in_flight[k] = false;
+            }
+            std::vector<FileWriters::Job> jobs;
+            index[k].clear();
+            for (uint32_t t = 0; t < n && rc == BT_OK; t++) {
+                bt_atlas_tile tile;
+                rc = bt_atlas_get_or_allocate_tile(a, coords[first + t], &tile);
+                if (rc) break;
+                index[k].push_back(tile.atlas_index);
+                layers.push_back(tile.atlas_index);
+                char name[64];
+                bt_tile_name(coords[first + t], name, sizeof name);
+                FileWriters::Job job{std::string(directory) + "/" + name + ".bin", (const uint8_t*)pinned[k] + at.tile_bytes * t, size_t(at.tile_bytes), k};
+                job.read = true;
+                jobs.push_back(std::move(job));
+            }
+            if (rc == BT_OK) readers.push(std::move(jobs));
+            if (rc == BT_OK && c > 0) rc = upload(c - 1);
+        }
+        if (rc == BT_OK) rc = upload(chunks - 1);
+        for (uint32_t k = 0; k < kBuffers; k++) readers.wait_buffer(k);  // (error paths: nobody may still write into the buffers)
+        hipError_t e = hipStreamSynchronize(a->ctx->stream);  // the staging buffers belong to the context: free for the next call
+        if (rc == BT_OK && e != hipSuccess) rc = hip_fail(e, "tile upload");
+    }
+    for (uint32_t k = 0; k < kBuffers; k++)
+        if (uploaded[k]) hipEventDestroy(uploaded[k]);
     if (rc || at.mips.size() <= 1) return rc;
     std::sort(layers.begin(), layers.end());
     for (size_t i = 0; i < layers.size();) {
