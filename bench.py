@@ -163,8 +163,9 @@ def end_to_end(device, src_ptr):
                     "buffers + writer threads -> 1365 .bin files + config.tc (preprocessor.rs:363,419)"}
 
 
-def verify_against(atlas, oracle, shape):
-    """Byte-compare the GPU atlas with the oracle's (same coordinates at the same atlas indices)."""
+def verify_against(atlas, oracle, shape, held=None):
+    """Byte-compare the GPU atlas with the oracle's (same coordinates at the same atlas indices).  held: the atlas layers
+    this rank is expected to hold (distributed result), default all."""
     import numpy as np
 
     sample, lods = shape
@@ -174,13 +175,15 @@ def verify_against(atlas, oracle, shape):
     theirs = oracle.tiles()
     if ours != theirs:
         return {"tiles": len(theirs), "identical": 0, "index_contract": False}
-    identical = 0
+    identical = checked = 0
     for first in range(0, len(theirs), 128):
         count = min(128, len(theirs) - first)
         data = atlas.download_tiles(0, first, count)
         for k in range(count):
-            identical += int(np.array_equal(data[k], oracle.tile(0, first + k)))
-    return {"tiles": len(theirs), "identical": identical, "index_contract": True}
+            if held is None or (first + k) in held:
+                checked += 1
+                identical += int(np.array_equal(data[k], oracle.tile(0, first + k)))
+    return {"tiles": checked, "identical": identical, "index_contract": True}
 
 
 def main():
@@ -197,6 +200,10 @@ def main():
     ap.add_argument("--collective", choices=["library", "torch"], default=None,
                     help="N > 1: who issues the exchange — the library's own RCCL communicator, one grouped collective per "
                          "step (default with the nccl backend), or torch.distributed (gloo test hook)")
+    ap.add_argument("--result", choices=["replicated", "distributed"], default=None,
+                    help="N > 1: replicated = every rank ends with the full atlas; distributed (default for the planar job) = the "
+                         "finest LOD stays on the rank that computed it, only the two parent LODs are exchanged (a quarter of "
+                         "the bytes), every rank still holds every lower LOD")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="N = 1: independent jobs in flight — P contexts (HIP streams) with an atlas each over the same resident "
                          "source, steps issued round-robin, so the short serial tail of one job runs beside the main kernel "
@@ -231,6 +238,7 @@ def main():
     device = bt.Device(local_rank)
     cube = args.config == "cube"
     collective = args.collective or ("library" if backend == "nccl" else "torch")
+    result = args.result or ("replicated" if cube else "distributed")
     if cube:
         size, lod_count, paths = 8192, 5, [f"synthetic/face{f}" for f in range(6)]
         faces = [device.synth_fbm_r16(size, size, 7 + f) for f in range(6)]
@@ -259,7 +267,7 @@ def main():
             # every rank must end up on the same path: agree on whether the library's communicator came up everywhere
             ok = 1
             try:
-                job = ShardedPreprocess(pre, atlas, server, paths, range(0, lod_count), rank, world, generic=args.generic, collective="library")
+                job = ShardedPreprocess(pre, atlas, server, paths, range(0, lod_count), rank, world, generic=args.generic, collective="library", result=result)
                 bt._ffi.check(bt._ffi.lib().bt_comm_check(job._comm))
             except Exception as e:
                 print(f"[rank {rank}] library-issued collective unavailable ({e!r}); falling back to torch.distributed", file=sys.stderr)
@@ -270,7 +278,7 @@ def main():
                 collective = "torch"
                 pre = bt.Preprocessor.new().clear_attachment(0, atlas)
         if collective == "torch":
-            job = ShardedPreprocess(pre, atlas, server, paths, range(0, lod_count), rank, world, generic=args.generic, collective="torch")
+            job = ShardedPreprocess(pre, atlas, server, paths, range(0, lod_count), rank, world, generic=args.generic, collective="torch", result=result)
     else:
         if cube:
             pre.preprocess_spherical(bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lod_count)), server, atlas)
@@ -407,6 +415,10 @@ def main():
                    "host_wall_ms_per_step": wall_ms / args.steps,
                    "kernels_only_ms_per_step": compute_only_ms,  # N > 1: without the all-gathers
                    "all_gather_bytes_per_rank": (job.gather_bytes if job is not None else 0),
+                   "result": (None if job is None else
+                              "replicated: every rank ends with the full atlas" if job.held is None else
+                              "distributed: the finest LOD stays on the rank that computed it (complete there), the two parent "
+                              "LODs are exchanged, every rank holds every lower LOD"),
                    "launches": launches},
     }
     if dominant:
@@ -446,7 +458,13 @@ def main():
         if world == 1:
             line["cpu_baseline"] = baseline  # reported at N = 1 only
         if args.verify:
-            line["verify_vs_oracle"] = verify_against(atlas, oracle, shape)
+            held = None
+            if job is not None and job.held is not None:  # distributed result: rank 0 holds its finest pieces + every lower LOD
+                finest = max(c[1] for c, _ in oracle.tiles())
+                held = {i for c, i in oracle.tiles() if c[1] < finest}
+                for piece in job.held:
+                    held.update(range(piece["first_layer"], piece["first_layer"] + piece["layers"]))
+            line["verify_vs_oracle"] = verify_against(atlas, oracle, shape, held)
             for k, (_, a, _) in enumerate(lanes[1:], 1):  # every lane's atlas holds a complete, identical job
                 line[f"verify_vs_oracle_lane{k}"] = verify_against(a, oracle, shape)
     if world > 1:

@@ -16,7 +16,7 @@ INVALID_ATLAS_INDEX = 0xFFFFFFFF
 MAX_ATTACHMENTS = 8
 
 BT_OK = 0
-RUN_AUTO, RUN_GENERIC, RUN_KEEP_QUEUE, RUN_PROFILE, RUN_SHARD_LOCAL, RUN_SHARD_FINISH = 0, 1, 2, 4, 8, 16
+RUN_AUTO, RUN_GENERIC, RUN_KEEP_QUEUE, RUN_PROFILE, RUN_SHARD_LOCAL, RUN_SHARD_FINISH, RUN_SHARD_DISTRIBUTED = 0, 1, 2, 4, 8, 16, 32
 
 
 class BtError(RuntimeError):

@@ -189,14 +189,18 @@ bt_status bt_preprocessor_run_sharded(bt_preprocessor* p, bt_atlas* a, bt_comm* 
         // a world of one: nothing to exchange; the sharded entry point still runs both halves
         if (bt_status s = bt_preprocessor_run(p, a, pass | BT_RUN_KEEP_QUEUE)) return s;
     } else {
-        if (bt_status s = bt_preprocessor_run(p, a, pass | BT_RUN_KEEP_QUEUE | BT_RUN_SHARD_LOCAL)) return s;
+        if (bt_status s = bt_preprocessor_run(p, a, pass | BT_RUN_KEEP_QUEUE | BT_RUN_SHARD_LOCAL | (flags & BT_RUN_SHARD_DISTRIBUTED))) return s;
         if (!local_only) {
             hipStream_t stream = p->ctx->stream;
             const Rccl& R = rccl();
+            // BT_RUN_SHARD_DISTRIBUTED: the finest LOD of every attachment stays where it was computed
+            const bool distributed = (flags & BT_RUN_SHARD_DISTRIBUTED) != 0;
+            auto stays = [&](uint32_t attachment, uint32_t lod) { return distributed && lod == shard_finest_lod(p, attachment); };
             BT_NCCL(R.GroupStart());
             int rc = 0;
             if (!p->shard_ranges.empty()) {  // regular layout: one in-place all-gather per LOD
                 for (const bt_shard_range& r : p->shard_ranges) {
+                    if (stays(r.attachment_index, r.lod)) continue;
                     const Attachment& at = a->attachments[r.attachment_index];
                     uint8_t* base = (uint8_t*)at.level0 + at.tile_bytes * r.first_layer;
                     const size_t count = size_t(at.tile_bytes) * r.layers_per_rank;
@@ -204,6 +208,7 @@ bt_status bt_preprocessor_run_sharded(bt_preprocessor* p, bt_atlas* a, bt_comm* 
                 }
             } else {
                 for (const bt_shard_piece& piece : p->shard_pieces) {
+                    if (stays(piece.attachment_index, piece.lod)) continue;
                     const Attachment& at = a->attachments[piece.attachment_index];
                     uint8_t* buf = (uint8_t*)at.level0 + at.tile_bytes * piece.first_layer;
                     if (!rc) rc = R.Broadcast(buf, buf, size_t(at.tile_bytes) * piece.layers, kNcclUint8, int(piece.owner_rank), comm->comm, stream);
@@ -212,7 +217,7 @@ bt_status bt_preprocessor_run_sharded(bt_preprocessor* p, bt_atlas* a, bt_comm* 
             const int end = R.GroupEnd();
             if (rc) return nccl_fail(rc, "grouped collective");
             if (end) return nccl_fail(end, "ncclGroupEnd");
-            if (bt_status s = bt_preprocessor_run(p, a, (flags & BT_RUN_GENERIC) | BT_RUN_KEEP_QUEUE | BT_RUN_SHARD_FINISH)) return s;
+            if (bt_status s = bt_preprocessor_run(p, a, (flags & (BT_RUN_GENERIC | BT_RUN_SHARD_DISTRIBUTED)) | BT_RUN_KEEP_QUEUE | BT_RUN_SHARD_FINISH)) return s;
         }
     }
     if (!(flags & BT_RUN_KEEP_QUEUE)) return release_queue(p);

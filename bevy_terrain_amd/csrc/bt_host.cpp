@@ -1279,8 +1279,13 @@ bt_status bt_preprocessor_save(bt_preprocessor* p, bt_atlas* a, const char* asse
     const std::string terrain = std::string(assets_root) + "/" + a->config.path;
     for (uint32_t ai = 0; ai < a->attachments.size(); ai++) {
         std::vector<std::pair<uint32_t, bt_tile_coordinate>> tiles;
-        for (const AtlasTileAttachment& t : a->to_save)
-            if (t.attachment_index == ai && t.atlas_index != BT_INVALID_ATLAS_INDEX) tiles.push_back({t.atlas_index, t.coordinate});
+        for (const AtlasTileAttachment& t : a->to_save) {
+            if (t.attachment_index != ai || t.atlas_index == BT_INVALID_ATLAS_INDEX) continue;
+            // after a distributed sharded run a rank writes its share only: the finest tiles it computed, and of the lower
+            // LODs (complete on every rank) every world-th tile — each file has exactly one writer
+            if (p->shard_world > 1 && p->shard_distributed && shard_holder(p, ai, t.coordinate.lod, t.atlas_index) != p->shard_rank) continue;
+            tiles.push_back({t.atlas_index, t.coordinate});
+        }
         if (tiles.empty()) continue;
         // AtlasAttachment::new: path = "assets/{path}/data/{name}" (tile_atlas.rs:175)
         const std::string dir = terrain + "/data/" + a->attachments[ai].cfg.name;
@@ -1288,6 +1293,7 @@ bt_status bt_preprocessor_save(bt_preprocessor* p, bt_atlas* a, const char* asse
     }
     a->to_save.clear();
     p->saves_recorded = false;
+    if (p->shard_world > 1 && p->shard_distributed && p->shard_rank != 0) return BT_OK;  // config.tc: rank 0
     if (bt_status s = make_dirs(terrain)) return s;
     return bt_atlas_save_tile_config(a, (terrain + "/config.tc").c_str());
 }

@@ -195,6 +195,7 @@ struct bt_preprocessor {
     std::vector<bt::Raster> rasters;
     uint32_t jobs = 0;
     uint32_t shard_rank = 0, shard_world = 1;
+    bool shard_distributed = false;  // the last sharded run kept the finest LOD on its owners (BT_RUN_SHARD_DISTRIBUTED)
     std::vector<bt_shard_range> shard_ranges;
     std::vector<bt_shard_piece> shard_pieces;
     // compiled plan (rebuilt when the queue changes)
@@ -212,3 +213,22 @@ struct bt_preprocessor {
     std::vector<hipEvent_t> events;
     uint32_t profiled_runs = 0;
 };
+
+namespace bt {
+// the finest LOD among the sharded pieces of an attachment (what BT_RUN_SHARD_DISTRIBUTED leaves on its owners)
+inline uint32_t shard_finest_lod(const ::bt_preprocessor* p, uint32_t attachment) {
+    uint32_t lod = 0;
+    for (const bt_shard_piece& piece : p->shard_pieces)
+        if (piece.attachment_index == attachment && piece.lod > lod) lod = piece.lod;
+    return lod;
+}
+// the rank that holds tile `atlas_index` of `attachment` after a distributed run: the owner of its finest-LOD piece, or,
+// for every other tile (all ranks hold those), atlas_index % world — one writer per file
+inline uint32_t shard_holder(const ::bt_preprocessor* p, uint32_t attachment, uint32_t lod, uint32_t atlas_index) {
+    if (lod == shard_finest_lod(p, attachment))
+        for (const bt_shard_piece& piece : p->shard_pieces)
+            if (piece.attachment_index == attachment && piece.lod == lod && atlas_index >= piece.first_layer && atlas_index < piece.first_layer + piece.layers)
+                return piece.owner_rank;
+    return atlas_index % p->shard_world;
+}
+}  // namespace bt

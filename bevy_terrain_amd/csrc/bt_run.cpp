@@ -170,6 +170,16 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
         if (bt_status s = record()) return s;
 
     const bool sharded = p->shard_world > 1;
+    if (sharded && (flags & BT_RUN_SHARD_DISTRIBUTED)) {
+        // the finest LOD stays on its owners: possible when nothing after the exchange reads finest tiles of other
+        // ranks, i.e. not for cube jobs (their face seams are stitched from the neighbour face's finest tiles)
+        for (const bt_shard_piece& piece : p->shard_pieces)
+            if (piece.side != p->shard_pieces[0].side) {
+                set_error("BT_RUN_SHARD_DISTRIBUTED needs a one-sided (planar) job: cube seams read finest tiles of other ranks");
+                return BT_ERR_UNSUPPORTED;
+            }
+    }
+    if (sharded) p->shard_distributed = (flags & BT_RUN_SHARD_DISTRIBUTED) != 0 && !p->shard_pieces.empty();
     if (sharded && !(flags & (BT_RUN_SHARD_LOCAL | BT_RUN_SHARD_FINISH))) {
         set_error("a sharded preprocessor runs with BT_RUN_SHARD_LOCAL and / or BT_RUN_SHARD_FINISH");
         return BT_ERR_INVALID_ARGUMENT;

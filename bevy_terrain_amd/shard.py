@@ -75,7 +75,11 @@ class ShardedPreprocess:
     `path`: a source path (planar, preprocess_tile) or a list of six (cube, preprocess_spherical)."""
 
     def __init__(self, pre: Preprocessor, tile_atlas: TileAtlas, asset_server: AssetServer, path, lod_range: range,
-                 rank: int, world: int, *, attachment_index: int = 0, generic: bool = False, collective: str = "torch"):
+                 rank: int, world: int, *, attachment_index: int = 0, generic: bool = False, collective: str = "torch",
+                 result: str = "replicated"):
+        """result="replicated": every rank ends with the full atlas.  result="distributed" (planar jobs): the finest LOD is
+        not exchanged — its tiles stay on the rank that computed them, only the two parent LODs travel (a quarter of the
+        bytes); every rank still holds every lower LOD, and Preprocessor.save writes each rank's share."""
         import torch
         import torch.distributed as dist
 
@@ -84,7 +88,9 @@ class ShardedPreprocess:
         self.pre, self.atlas, self.rank, self.world = pre, tile_atlas, rank, world
         self.dist = dist
         self.collective = collective
-        self.flags = (_ffi.RUN_GENERIC if generic else 0) | _ffi.RUN_KEEP_QUEUE
+        assert result in ("replicated", "distributed")
+        self.result = result
+        self.flags = (_ffi.RUN_GENERIC if generic else 0) | _ffi.RUN_KEEP_QUEUE | (_ffi.RUN_SHARD_DISTRIBUTED if result == "distributed" else 0)
         if isinstance(path, (list, tuple)):
             pre.preprocess_spherical(SphericalDataset(attachment_index=attachment_index, paths=list(path), lod_range=lod_range),
                                      asset_server, tile_atlas)
@@ -98,6 +104,7 @@ class ShardedPreprocess:
         self.stream = tile_atlas.device.torch_stream
         self._ranges: Optional[List[dict]] = None
         self._pieces: Optional[List[dict]] = None
+        self.held: Optional[List[dict]] = None  # distributed result: the finest-LOD pieces this rank keeps
         self.gather_bytes = 0
         self._comm = None
         if collective == "library":
@@ -120,6 +127,11 @@ class ShardedPreprocess:
         if self._pieces is None:
             self._ranges = shard_ranges(self.pre)
             self._pieces = shard_pieces(self.pre)
+            if self.result == "distributed" and self._pieces:  # the finest LOD stays on its owners
+                finest = max(p["lod"] for p in self._pieces)
+                self.held = [p for p in self._pieces if p["lod"] == finest and p["owner_rank"] == self.rank]
+                self._ranges = [r for r in self._ranges if r["lod"] != finest]
+                self._pieces = [p for p in self._pieces if p["lod"] != finest]
             self.gather_bytes = sum(p["layers"] * self.tile_bytes for p in self._pieces)
 
     def step(self, profile: bool = False, gather: bool = True):

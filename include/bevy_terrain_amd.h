@@ -259,6 +259,11 @@ enum {
     BT_RUN_PROFILE = 4,    /* record a hipEvent after every launch; read with bt_preprocessor_profile() */
     BT_RUN_SHARD_LOCAL = 8,   /* sharded run, part 1: this rank's column strip of the finest LODs (no collective) */
     BT_RUN_SHARD_FINISH = 16, /* sharded run, part 2 (after the all-gathers): cross-strip aprons + the top LODs */
+    BT_RUN_SHARD_DISTRIBUTED = 32, /* sharded planar job: the finest LOD is NOT exchanged — its tiles stay on the rank that
+                                    * computed them (they are complete there: finest aprons come from the source), only the
+                                    * two parent LODs travel (a quarter of the bytes), every rank still ends with every
+                                    * lower LOD.  bt_preprocessor_save then writes this rank's share only.  Jobs with more
+                                    * than one side (cube seams read neighbour tiles of the finest LOD): BT_ERR_UNSUPPORTED. */
 };
 /* Replaces select_ready_tasks + GpuPreprocessor::prepare + TerrainPreprocessNode::run for the whole
  * queue: enqueues every kernel on the context's stream and returns (asynchronous).  Save tasks are
@@ -281,7 +286,8 @@ bt_status bt_preprocessor_last_run_stats(const bt_preprocessor* p, bt_run_stats*
  * runs BT_RUN_SHARD_LOCAL, all-gathers each returned range IN PLACE over its atlas storage
  * (ncclAllGather with sendbuff = recvbuff + rank * count: layers [first_layer + r * layers_per_rank, ...) hold
  * rank r's tiles because atlas indices are x-major), then runs BT_RUN_SHARD_FINISH.  Every rank ends with the
- * full atlas, bit-identical to a single-GPU run.  world == 1 restores the normal behaviour. */
+ * full atlas, bit-identical to a single-GPU run (with BT_RUN_SHARD_DISTRIBUTED: with its own finest tiles and every
+ * lower LOD — the ranges / pieces of the finest LOD are then skipped).  world == 1 restores the normal behaviour. */
 typedef struct bt_shard_range {
     uint32_t attachment_index, side, lod;
     uint32_t first_layer;     /* atlas index of tile (x = 0, y = 0) of this (side, lod) */

@@ -171,7 +171,8 @@ def test_nccl_single_rank_group_runs_the_sharded_step():
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_end_to_end_on_one_gpu():
+@pytest.mark.parametrize("result,held_tiles", [("replicated", 1365), ("distributed", 512 + 341)])
+def test_bench_two_ranks_end_to_end_on_one_gpu(result, held_tiles):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), except that both
     ranks share GPU 0 and the collective is gloo (RCCL refuses two ranks on one device): every rank preprocesses its
     column strip of the 16k job, the in-place all-gathers assemble the atlas, and rank 0's atlas must equal the
@@ -183,12 +184,14 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     env = dict(os.environ, BT_BENCH_BACKEND="gloo", BT_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--spinup-ms", "20", "--verify"]
+           "--spinup-ms", "20", "--verify", "--result", result]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["collective_backend"] == "gloo"
-    assert line["verify_vs_oracle"] == {"tiles": 1365, "identical": 1365, "index_contract": True}
+    # replicated: rank 0 ends with all 1365 tiles; distributed: with its half of the 1024 finest tiles + the 341 below
+    assert line["verify_vs_oracle"] == {"tiles": held_tiles, "identical": held_tiles, "index_contract": True}
+    assert line["config"]["result"].startswith(result)
     assert "cpu_baseline" not in line
 
 
@@ -442,3 +445,98 @@ def test_random_jobs_sharded_over_emulated_ranks(seed):
         _ffi.check(L.bt_preprocessor_run(probe._h, probe_atlas._h, _ffi.RUN_KEEP_QUEUE | _ffi.RUN_SHARD_FINISH))
         device.synchronize()
         assert K.assert_atlas_equal(probe_atlas, oracle) == n_tiles
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_planar_job_distributed_result_over_emulated_ranks(world, tmp_path):
+    """BT_RUN_SHARD_DISTRIBUTED: the finest LOD is not exchanged.  One atlas per emulated rank; only the two parent LODs
+    travel (to every rank); afterwards rank r holds its own finest tiles and EVERY lower LOD, all equal to the oracle's,
+    and the ranks' saves together write every tile file exactly once (+ config.tc from rank 0)."""
+    import bevy_terrain_amd as bt
+    from bevy_terrain_amd import _ffi
+    from bevy_terrain_amd.shard import shard_pieces
+
+    device = bt.Device(0)
+    L = _ffi.lib()
+    T, b, lods = 64, 2, 6
+    src = K.random_raster(O.FORMAT_R16, 1100, 1100, seed=36, holes=0.01)
+    oracle = K.oracle_planar(src, lods, T, b, O.FORMAT_R16, atlas_size=2048)
+    jobs = []
+    D = _ffi.RUN_SHARD_DISTRIBUTED | _ffi.RUN_KEEP_QUEUE
+    for rank in range(world):
+        cfg = bt.TerrainConfig(lod_count=lods, atlas_size=2048, path="terrains/dist", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+        cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=T, border_size=b))
+        atlas = bt.TileAtlas.new(cfg, device)
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas, str(tmp_path)).preprocess_tile(
+            bt.PreprocessDataset(path="s", lod_range=range(0, lods)), bt.AssetServer().insert("s", src), atlas)
+        _ffi.check(L.bt_preprocessor_set_shard(pre._h, rank, world))
+        _ffi.check(L.bt_preprocessor_run(pre._h, atlas._h, D | _ffi.RUN_SHARD_LOCAL))
+        jobs.append((atlas, pre))
+    device.synchronize()
+    pieces = shard_pieces(jobs[0][1])
+    finest = max(p["lod"] for p in pieces)
+    assert finest == lods - 1 and len(pieces) == 3 * world
+    moved = 0
+    for p in pieces:
+        if p["lod"] == finest:
+            continue  # stays on its owner
+        data = jobs[p["owner_rank"]][0].download_tiles(0, p["first_layer"], p["layers"])
+        moved += data.nbytes
+        for r, (atlas, _) in enumerate(jobs):
+            if r != p["owner_rank"]:
+                for k in range(p["layers"]):
+                    atlas.upload_tile(0, p["first_layer"] + k, data[k])
+    total = sum(p["layers"] for p in pieces) * T * T * 2
+    assert moved * 4 < total * 1.3  # about a quarter of the replicated exchange
+    for atlas, pre in jobs:
+        _ffi.check(L.bt_preprocessor_run(pre._h, atlas._h, D | _ffi.RUN_SHARD_FINISH))
+    device.synchronize()
+    coords = {i: c for c, i in oracle.tiles()}
+    for rank, (atlas, pre) in enumerate(jobs):
+        held = [p for p in pieces if p["lod"] == finest and p["owner_rank"] == rank]
+        assert held
+        layers = set()
+        for p in held:
+            layers.update(range(p["first_layer"], p["first_layer"] + p["layers"]))
+        layers.update(i for i, c in coords.items() if c[1] < finest)
+        data = atlas.download_tiles(0, 0, 1365)
+        bad = [coords[i] for i in sorted(layers) if not np.array_equal(data[i], oracle.tile(0, i))]
+        assert not bad, (rank, len(bad), bad[:4])
+        pre.save(atlas, str(tmp_path))
+    directory = jobs[0][0].attachment_directory(str(tmp_path), 0)
+    files = sorted(f for f in os.listdir(directory) if f.endswith(".bin"))
+    assert len(files) == 1365
+    import ctypes
+
+    def name_of(c):
+        buf = ctypes.create_string_buffer(64)
+        L.bt_tile_name(bt.TileCoordinate(*c)._c(), buf, 64)
+        return buf.value.decode()
+
+    by_name = {name_of(c): i for i, c in coords.items()}
+    for f in files[::23]:
+        tile = np.fromfile(os.path.join(directory, f), dtype=np.uint16).reshape(T, T)
+        assert np.array_equal(tile, oracle.tile(0, by_name[f[:-4]])), f
+    assert os.path.exists(os.path.join(str(tmp_path), "terrains/dist", "config.tc"))
+
+
+@pytest.mark.gpu
+def test_distributed_result_is_refused_for_cube_jobs():
+    import bevy_terrain_amd as bt
+    from bevy_terrain_amd import _ffi
+
+    device = bt.Device(0)
+    T, b, lods = 32, 2, 4
+    faces = [K.random_raster(O.FORMAT_R16, 200, 200, seed=90 + s) for s in range(6)]
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=600, path="terrains/spherical")
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=T, border_size=b, format=bt.AttachmentFormat.R16))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer()
+    for s in range(6):
+        server.insert(f"f{s}", faces[s])
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_spherical(
+        bt.SphericalDataset(attachment_index=0, paths=[f"f{s}" for s in range(6)], lod_range=range(0, lods)), server, atlas)
+    _ffi.check(_ffi.lib().bt_preprocessor_set_shard(pre._h, 1, 4))
+    rc = _ffi.lib().bt_preprocessor_run(pre._h, atlas._h, _ffi.RUN_KEEP_QUEUE | _ffi.RUN_SHARD_LOCAL | _ffi.RUN_SHARD_DISTRIBUTED)
+    assert rc == -5  # BT_ERR_UNSUPPORTED
