@@ -24,6 +24,7 @@
 // liberty: t / 65535.0f is evaluated as q0 = t*r, e = fma(-q0, 65535, t), q = fma(e, r, q0) with
 // r = RN(1/65535) (Markstein's correctly rounded division); equality with `/` for all 65536 inputs is
 // checked on the device by bt_selftest() and on the CPU by tests/test_oracle_preprocess.py.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -67,7 +68,7 @@ struct FusedArgs {
     uint32_t* todo;       // fused_main: [0] count, [2..] chunks (item * chunks_per_tile + k) left to the generic variant
     uint32_t* todo_next;  // the list of the NEXT run (the two alternate): fused_todo zeroes its count, so no reset protocol
     uint32_t apron_lods;  // fused_tail: LODs lod, lod+1, ... (this many) get their top / bottom apron rows from extra workgroups
-    uint32_t ablate;      // debug only (env BT_FUSED_ABLATE): 1 no pyramid, 2 no finest stores, 4 no parent stores, 64 no grand-parent stores (static path), 8 no staging loads, 16 prologue only, 256 / 512 finest / parent stores without arithmetic (use with 16)
+    uint32_t ablate;      // debug only (env BT_FUSED_ABLATE): 1 no pyramid, 2 no finest stores, 4 no parent stores, 64 no grand-parent stores (static path), 8 no staging loads, 16 prologue only, 256 / 512 finest / parent stores without arithmetic (use with 16); skeleton shapes: 65536 parent rows in bursts of four chunks, 262144 parent rows as 16-byte stores, 1048576 finest rows as 16-byte stores
 };
 
 // t / 65535.0f, correctly rounded, in 3 VALU ops (see header)
@@ -619,13 +620,41 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             // (4096: the same bytes with thread t on dword t of the row — what a texture-aligned thread mapping would store)
             uint32_t* dst5 = BT_ABLATE(A, 4096u) ? tile5_u32 + (((b + cr0) * T) >> 1) + tid : tile5_u32 + (((b + cr0) * T + px0) >> 1);
             if (BT_ABLATE(A, 256u)) {
+                if (BT_ABLATE(A, 1048576u)) {  // (1048576: a wave's 4 rows x 256 bytes as ONE 16-byte-per-lane store — what a per-wave transposition would emit)
+                    const uint32_t wave = tid >> 6, lane = tid & 63u;
 #pragma unroll
-                for (uint32_t i = 0; i < kMainRows; i++) dst5[i * (T / 2)] = tid + i;
+                    for (uint32_t quad = 0; quad < kMainRows / 4; quad++) {
+                        uint8_t* row = reinterpret_cast<uint8_t*>(tile5 + (b + cr0 + 4 * quad + (lane >> 4)) * T) + (BT_ABLATE(A, 4096u) ? 0u : 2u * b);
+                        if (wave * 256u + (lane & 15u) * 16u + 16u <= 2u * T - 2u * b)
+                            *reinterpret_cast<u32x4*>(row + wave * 256u + (lane & 15u) * 16u) = u32x4{tid, tid + quad, tid, tid};
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t i = 0; i < kMainRows; i++) dst5[i * (T / 2)] = tid + i;
+                }
             }
-            if (is_centre && do4 && BT_ABLATE(A, 512u)) {
-                uint16_t* dst = tile4 + (b + cy4_base + (cr0 >> 1)) * T + b + cx4;
+            if (do4 && BT_ABLATE(A, 262144u)) {  // (262144: the chunk's four parent rows as 16-byte stores of 32 lanes each — two wave instructions instead of sixteen)
+                const uint32_t wave = tid >> 6, lane = tid & 63u;
+                if (wave < 2) {
+                    uint16_t* row = tile4 + (b + cy4_base + (cr0 >> 1) + 2 * wave + (lane >> 5)) * T + (it.x & 1u) * (T / 2);
+                    reinterpret_cast<u32x4*>(row)[lane & 31u] = u32x4{tid, tid, tid, tid};
+                }
+                if (do3 && !BT_ABLATE(A, 64u) && wave == 2 && lane < 32) {  // and the two grand-parent rows as one
+                    uint16_t* row = tile3 + (b + cy3_base + (cr0 >> 2) + (lane >> 4)) * T + (it.x & 3u) * (T / 4);
+                    reinterpret_cast<u32x4*>(row)[lane & 15u] = u32x4{tid, tid, tid, tid};
+                }
+            } else if (is_centre && do4 && BT_ABLATE(A, 512u)) {
+                if (BT_ABLATE(A, 65536u)) {  // (65536: the parent rows of four chunks in one burst every fourth chunk — same bytes, same addresses)
+                    if ((k & 3u) == 3u) {
+                        uint16_t* dst = tile4 + (b + cy4_base + ((cr0 - 3u * kMainRows) >> 1)) * T + b + cx4;
 #pragma unroll
-                for (uint32_t j = 0; j < 4; j++) dst[j * T] = uint16_t(tid);
+                        for (uint32_t j = 0; j < 16; j++) dst[j * T] = uint16_t(tid);
+                    }
+                } else {
+                    uint16_t* dst = tile4 + (b + cy4_base + (cr0 >> 1)) * T + b + cx4;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) dst[j * T] = uint16_t(tid);
+                }
             }
         }
         if (!BT_ABLATE(A, 16u) && !skip_chunk) {
@@ -1534,6 +1563,26 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             std::stable_sort(items.begin(), items.end(), [](const MainItem& a, const MainItem& b2) {
                 return a.side != b2.side ? a.side < b2.side : (a.y != b2.y ? a.y < b2.y : a.x < b2.x);
             });
+#ifdef BT_DEBUG_HOOKS
+        // workgroup -> tile experiments (tools/order_search.py): a file of item_count u32, position i of the (XCD-contiguous)
+        // work order runs the tile at that position of the tile-row order
+        if (const char* e = getenv("BT_FUSED_ORDER")) {
+            std::vector<uint32_t> perm(items.size());
+            FILE* f = fopen(e, "rb");
+            const bool ok = f && fread(perm.data(), 4, perm.size(), f) == perm.size();
+            if (f) fclose(f);
+            if (ok) {
+                std::vector<MainItem> sorted = items;
+                std::vector<uint8_t> seen(items.size(), 0);
+                bool valid = true;
+                for (uint32_t v : perm) valid = valid && v < items.size() && !seen[v] && (seen[v] = 1);
+                if (valid)
+                    for (size_t i = 0; i < items.size(); i++) items[i] = sorted[perm[i]];
+                else
+                    fprintf(stderr, "BT_FUSED_ORDER: %s is not a permutation of %zu items, ignored\n", e, items.size());
+            }
+        }
+#endif
         if (shard) {
             p->shard_ranges.insert(p->shard_ranges.end(), ranges.begin(), ranges.end());
             p->shard_pieces.insert(p->shard_pieces.end(), pieces.begin(), pieces.end());

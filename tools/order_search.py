@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Which workgroup runs which finest tile?  fused_main is ONE resident generation of 1024 workgroups on the 16k job, so
+the order of its item list only decides which XCD (and which CU of it) streams which tile — the addresses touched per
+unit of time stay the same.  The profiling build (tools/libbevy_terrain_amd_dbg.so) takes an arbitrary order from a
+file (BT_FUSED_ORDER); this tool times fused_main under families of orders and re-measures the best ones.
+
+  python tools/order_search.py [--quick] [--out gpurun_out/order_search.json]
+
+Order = permutation `perm` of the tile-row order (t = ty * 32 + tx): work position w runs tile perm[w]; XCD k runs the
+positions [128 k, 128 k + 128) in dispatch order (xcd_remap in bt_fused.hip)."""
+import argparse
+import itertools
+import json
+import os
+import random
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bevy_terrain_amd import _ffi
+
+_ffi.LIB_PATH = os.path.join(ROOT, "tools", "libbevy_terrain_amd_dbg.so")
+import numpy as np
+
+import bevy_terrain_amd as bt
+
+SIZE, T, B, LODS, ATLAS = 16384, 512, 2, 6, 2048
+N = 32  # finest tiles per axis
+
+
+def bit_perm_order(bits):
+    """bits[j] = the bit of t = ty << 5 | tx that bit j of the work position w feeds."""
+    w = np.arange(N * N, dtype=np.uint32)
+    t = np.zeros_like(w)
+    for j, tb in enumerate(bits):
+        t |= ((w >> j) & 1) << tb
+    return t
+
+
+def xcd_function_order(fn, inner="row"):
+    """XCD of a tile from fn(tx, ty) (must give 128 tiles each); inside an XCD tile-row order (or column order)."""
+    tx, ty = np.meshgrid(np.arange(N), np.arange(N))
+    tx, ty = tx.ravel(), ty.ravel()
+    xcd = fn(tx, ty) % 8
+    key = (ty * N + tx) if inner == "row" else (tx * N + ty)
+    order = np.lexsort((key, xcd))
+    counts = np.bincount(xcd, minlength=8)
+    if not np.all(counts == 128):
+        return None
+    return (ty[order] * N + tx[order]).astype(np.uint32)
+
+
+def inner_order(fn):
+    """The default XCD assignment (4 tile rows each); fn permutes the 128 positions of every XCD."""
+    perm = np.arange(N * N, dtype=np.uint32)
+    out = perm.copy()
+    idx = np.array([fn(i) for i in range(128)])
+    assert sorted(idx) == list(range(128))
+    for k in range(8):
+        out[128 * k:128 * (k + 1)] = perm[128 * k + idx]
+    return out
+
+
+def candidates(quick):
+    c = [("identity (tile rows, XCD = 4 rows)", np.arange(N * N, dtype=np.uint32))]
+    # XCD bits = any 3 bits of t; the other 7 in ascending (tx fastest) or ty-first order
+    for xb in itertools.combinations(range(10), 3):
+        rest = [b for b in range(10) if b not in xb]
+        for name, r in (("tx fastest", rest), ("ty fastest", [b for b in rest if b >= 5] + [b for b in rest if b < 5])):
+            c.append((f"bits xcd={xb} inner {name}", bit_perm_order(list(r) + list(xb))))
+    rng = random.Random(7)
+    for i in range(20 if quick else 120):
+        bits = list(range(10))
+        rng.shuffle(bits)
+        c.append((f"bits random {bits}", bit_perm_order(bits)))
+    for name, fn in (("(tx + ty) % 8", lambda x, y: x + y), ("(tx ^ ty) % 8", lambda x, y: x ^ y), ("(tx + 2 ty) % 8", lambda x, y: x + 2 * y),
+                     ("(tx / 4 + ty) % 8", lambda x, y: x // 4 + y), ("(tx + ty / 4) % 8", lambda x, y: x + y // 4),
+                     ("(tx / 2 + ty / 2) % 8", lambda x, y: x // 2 + y // 2), ("(tx / 4 + ty / 4) % 8", lambda x, y: x // 4 + y // 4),
+                     ("(tx / 2 ^ ty / 2) % 8", lambda x, y: (x // 2) ^ (y // 2)), ("(tx / 4 ^ ty / 4) % 8", lambda x, y: (x // 4) ^ (y // 4)),
+                     ("(3 tx + ty) % 8", lambda x, y: 3 * x + y), ("(tx / 4 + 2 (ty / 4)) % 8", lambda x, y: x // 4 + 2 * (y // 4))):
+        for inner in ("row", "col"):
+            o = xcd_function_order(fn, inner)
+            if o is not None:
+                c.append((f"xcd = {name}, inner {inner}", o))
+    rev7 = lambda i: int(f"{i:07b}"[::-1], 2)
+    for name, fn in (("reversed", lambda i: 127 - i), ("bit-reversed", rev7), ("rows interleaved (ty fastest)", lambda i: (i % 4) * 32 + i // 4),
+                     ("2 x 2 sibling quads", lambda i: (2 * ((i >> 2) // 16) + ((i >> 1) & 1)) * 32 + 2 * ((i >> 2) % 16) + (i & 1)),
+                     ("4 x 4 blocks, Morton inside", lambda i: (((i >> 3) & 1) * 2 + ((i >> 1) & 1)) * 32 + 4 * (i >> 4) + ((i >> 2) & 1) * 2 + (i & 1)),
+                     ("4 x 4 blocks, rows inside", lambda i: ((i >> 2) & 3) * 32 + 4 * (i >> 4) + (i & 3)),
+                     ("snake", lambda i: i if (i // 32) % 2 == 0 else (i // 32) * 32 + 31 - i % 32),
+                     ("odd rows shifted by 16", lambda i: i if (i // 32) % 2 == 0 else (i // 32) * 32 + (i % 32 + 16) % 32),
+                     ("stride 5", lambda i: (i * 5) % 128), ("stride 37", lambda i: (i * 37) % 128)):
+        c.append((f"default XCDs, inner {name}", inner_order(fn)))
+    # de-duplicate
+    seen, out = set(), []
+    for name, o in c:
+        key = o.tobytes()
+        if key not in seen and sorted(o.tolist()) == list(range(N * N)):
+            seen.add(key)
+            out.append((name, o))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--launches", type=int, default=24)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "order_search.json"))
+    args = ap.parse_args()
+    import torch
+
+    torch.cuda.set_device(0)
+    device = bt.Device(0)
+    src = device.synth_fbm_r16(SIZE, SIZE, 42)
+    cfg = bt.TerrainConfig(lod_count=LODS, atlas_size=ATLAS, path="terrains/order", model=bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=T, border_size=B, format=bt.AttachmentFormat.R16))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer()
+    server.insert("src", (src, SIZE, SIZE))
+    fd, path = tempfile.mkstemp(prefix="bt_order_")
+    os.close(fd)
+
+    def measure(order, launches, digest=False):
+        if order is None:
+            os.environ.pop("BT_FUSED_ORDER", None)
+        else:
+            order.astype(np.uint32).tofile(path)
+            os.environ["BT_FUSED_ORDER"] = path
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas)
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="src", lod_range=range(0, LODS)), server, atlas)
+        for _ in range(4):
+            pre.run(atlas, keep_queue=True, sync=False)
+        for _ in range(launches):
+            pre.run(atlas, keep_queue=True, sync=False, profile=True)
+        device.synchronize()
+        prof = {l["kind"]: l["avg_ms"] * 1e3 for l in pre.profile()}
+        h = None
+        if digest:  # all 1365 tiles of the atlas
+            import hashlib
+
+            m = hashlib.sha256()
+            for first in range(0, 1365, 105):
+                m.update(atlas.download_tiles(0, first, min(105, 1365 - first)).tobytes())
+            h = m.hexdigest()
+        pre.close()
+        return prof.get("fused_main"), h
+
+    # spin-up
+    for _ in range(6):
+        measure(None, 32)
+    base, base_digest = measure(None, 100, digest=True)
+    print(f"baseline (no order file): fused_main {base:.1f} us", flush=True)
+    cands = candidates(args.quick)
+    results = []
+    for i, (name, order) in enumerate(cands):
+        us, _ = measure(order, args.launches)
+        results.append({"name": name, "us": us, "i": i})
+        if i % 25 == 0:
+            ident, _ = measure(cands[0][1], args.launches)
+            print(f"[{i}/{len(cands)}] identity now {ident:.1f} us; best so far {min(r['us'] for r in results):.1f}", flush=True)
+    results.sort(key=lambda r: r["us"])
+    top = []
+    for r in results[:12] + [x for x in results if x["i"] == 0]:
+        us, h = measure(cands[r["i"]][1], 200, digest=True)
+        top.append({"name": r["name"], "us_first": r["us"], "us": us, "identical_to_baseline": h == base_digest,
+                    "order": cands[r["i"]][1].tolist() if len(top) < 3 else None})
+        print(f"{us:7.1f} us (first pass {r['us']:.1f})  {'ok ' if h == base_digest else 'DIFFERENT '} {r['name']}", flush=True)
+    again, _ = measure(None, 100)
+    summary = {"baseline_us": base, "baseline_again_us": again, "candidates": len(cands), "top": top,
+               "all": [{"name": r["name"], "us": round(r["us"], 1)} for r in results],
+               "worst": results[-5:]}
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(summary, open(args.out, "w"), indent=1)
+    os.unlink(path)
+    print(f"baseline {base:.1f} / {again:.1f} us; best {top[0]['us']:.1f} us: {top[0]['name']}")
+
+
+if __name__ == "__main__":
+    main()
