@@ -68,6 +68,7 @@ struct FusedArgs {
     uint32_t* todo;       // fused_main: [0] count, [2..] chunks (item * chunks_per_tile + k) left to the generic variant
     uint32_t* todo_next;  // the list of the NEXT run (the two alternate): fused_todo zeroes its count, so no reset protocol
     uint32_t apron_lods;  // fused_tail: LODs lod, lod+1, ... (this many) get their top / bottom apron rows from extra workgroups
+    uint32_t apron_cols;  // fused_tail (Rgba8 after fused_direct, which writes centres only): ... and their left / right apron columns
     uint32_t ablate;      // debug only (env BT_FUSED_ABLATE): 1 no pyramid, 2 no finest stores, 4 no parent stores, 64 no grand-parent stores (static path), 8 no staging loads, 16 prologue only, 256 / 512 finest / parent stores without arithmetic (use with 16); skeleton shapes: 65536 parent rows in bursts of four chunks, 262144 parent rows as 16-byte stores, 1048576 finest rows as 16-byte stores
 };
 
@@ -1013,14 +1014,55 @@ __device__ __forceinline__ void tail_apron_rows(const FusedArgs& A, uint32_t sid
     }
 }
 
+// Rgba8 twin (one 4-byte texel per thread) that also does the left / right apron columns: after fused_direct, which writes
+// the centres of the two parent LODs only, these workgroups are the whole stitch of those tiles (stitch.wgsl:53-118 for
+// same-face neighbours; cube seams are re-stitched by the batched kernel afterwards, like everywhere in the fused plans).
+__device__ __forceinline__ uint32_t tail_apron_texels_per_tile(const FusedArgs& A) {
+    return 2u * A.m.border_size * A.m.texture_size + (A.apron_cols ? 2u * A.m.border_size * A.m.center_size : 0u);
+}
+__device__ __forceinline__ void tail_aprons_rgba8(const FusedArgs& A, uint32_t side, uint32_t e) {
+    const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
+    const uint32_t per_tile = tail_apron_texels_per_tile(A), blocks_per_tile = (per_tile + 255u) / 256u;
+    uint32_t* atlas = reinterpret_cast<uint32_t*>(A.atlas);
+    for (uint32_t k = 0; k < A.apron_lods; k++) {
+        const uint32_t lod = A.lod + k, n = 1u << lod, blocks = n * n * blocks_per_tile;
+        if (e >= blocks) {
+            e -= blocks;
+            continue;
+        }
+        const uint32_t tile = e / blocks_per_tile, i = (e % blocks_per_tile) * 256u + threadIdx.x;
+        if (i >= per_tile) return;
+        const uint32_t tx = tile / n, ty = tile % n;
+        const uint32_t self = grid_lookup(A, side, lod, int(tx), int(ty));
+        if (self == kInvalid) return;
+        uint32_t px, py;
+        if (i < 2u * b * T) {  // whole apron rows (with the corners)
+            const uint32_t r = i / T;
+            px = i % T;
+            py = r < b ? r : c + r;
+        } else {  // apron columns of the centre rows
+            const uint32_t j = i - 2u * b * T, kk = j % (2u * b);
+            px = kk < b ? kk : c + kk;
+            py = b + j / (2u * b);
+        }
+        const int rx = px < b ? -1 : (px >= o ? 1 : 0), ry = py < b ? -1 : (py >= o ? 1 : 0);
+        const uint32_t nb = grid_lookup(A, side, lod, int(tx) + rx, int(ty) + ry);
+        const uint32_t sx = nb != kInvalid ? uint32_t(int(px) - rx * int(c)) : min(max(px, b), o - 1u);
+        const uint32_t sy = nb != kInvalid ? uint32_t(int(py) - ry * int(c)) : min(max(py, b), o - 1u);
+        atlas[uint64_t(self) * T * T + py * T + px] = atlas[uint64_t(nb != kInvalid ? nb : self) * T * T + sy * T + sx];
+        return;
+    }
+}
+
 template <uint32_t kFormat>
 __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
     constexpr bool kR16 = kFormat == BT_FORMAT_R16;
     using TT = typename std::conditional<kR16, uint16_t, uint32_t>::type;  // texel
-    if constexpr (kR16) {
+    {
         const uint32_t extent = (1u << A.lod) * A.m.center_size, ny = (extent + 63u) / 64u;
-        if (blockIdx.y >= ny) {  // workgroups past the mosaic: apron rows
-            tail_apron_rows(A, blockIdx.z, (blockIdx.y - ny) * gridDim.x + blockIdx.x);
+        if (blockIdx.y >= ny) {  // workgroups past the mosaic: apron rows (Rgba8: and columns)
+            if constexpr (kR16) tail_apron_rows(A, blockIdx.z, (blockIdx.y - ny) * gridDim.x + blockIdx.x);
+            else tail_aprons_rgba8(A, blockIdx.z, (blockIdx.y - ny) * gridDim.x + blockIdx.x);
             return;
         }
     }
@@ -1195,15 +1237,80 @@ __device__ __forceinline__ uint32_t rgba8_value_slow(const FusedArgs& A, const R
     return vmix_rgba8(top, bot, ay.fr);
 }
 
+// split_axis with the two divisions that are exact by construction taken out (same bits): x / 2^lod == x * 2^-lod (no
+// underflow: x is 0 or >= 1 / c), and (s - lo) / 1 == s - lo for datasets that span the whole side.
+__device__ __forceinline__ Axis split_axis_pow2(uint32_t r, uint32_t c, uint32_t tile, float inv_scale, float lo, float hi, uint32_t dim) {
+    const float tc = float(r) / float(c);
+    const float s = (float(tile) + tc) * inv_scale;
+    const float w = hi - lo;
+    const float u = w == 1.0f ? s - lo : (s - lo) / w;
+    const float q = u * float(dim) - 0.5f;
+    const float fl = floorf(q);
+    Axis a;
+    a.fr = q - fl;
+    const int i = int(fl);
+    const int last = int(dim) - 1;
+    const int j = i + 1;
+    a.i0 = i < 0 ? 0 : (i > last ? last : i);
+    a.i1 = j < 0 ? 0 : (j > last ? last : j);
+    return a;
+}
+
+typedef float direct_f2 __attribute__((ext_vector_type(2)));
+struct H4p {  // horizontally blended texel in the 2^8-scaled domain: channels (0, 1) and (2, 3)
+    direct_f2 lo, hi;
+};
+// F(t) for the four channels of a texel (see hrow_rgba8_scaled), two channels per packed operation
+__device__ __forceinline__ H4p conv_rgba8_scaled(uint32_t t) {
+    const direct_f2 kr = {1.0f / 255.0f, 1.0f / 255.0f};
+    const direct_f2 x01 = {float(t & 0xFFu), float((t >> 8) & 0xFFu)}, x23 = {float((t >> 16) & 0xFFu), float(t >> 24)};
+    return H4p{__builtin_elementwise_fma(x01, kr, x01), __builtin_elementwise_fma(x23, kr, x23)};
+}
+__device__ __forceinline__ H4p hrow_rgba8_packed(uint32_t t0, uint32_t t1, float fx) {
+    const direct_f2 f2x = {fx, fx}, g2x = {1.0f - fx, 1.0f - fx};
+    const H4p a = conv_rgba8_scaled(t0), bq = conv_rgba8_scaled(t1);
+    return H4p{a.lo * g2x + bq.lo * f2x, a.hi * g2x + bq.hi * f2x};
+}
+__device__ __forceinline__ uint32_t vmix_rgba8_packed(const H4p& top, const H4p& bot, float fy) {
+    const direct_f2 f2y = {fy, fy}, g2y = {1.0f - fy, 1.0f - fy}, kn = {255.0f / 256.0f, 255.0f / 256.0f}, khalf = {0.5f, 0.5f};
+    const direct_f2 lo = khalf + kn * (top.lo * g2y + bot.lo * f2y), hi = khalf + kn * (top.hi * g2y + bot.hi * f2y);
+    return uint32_t(lo.x) | (uint32_t(lo.y) << 8) | (uint32_t(hi.x) << 16) | (uint32_t(hi.y) << 24);
+}
+// 2 x 2 average of four texels that all count (rgb != 0), two of the four channels: the ones at bit `sh` (0 or 16) of the
+// texels.  Sum order and arithmetic of downsample4_rgba8's common case: ((t00 + t01) + t10) + t11, x 0.25 (exact), quantise
+// — 0.5 + (255 / 256) * (sum * 0.25) == 0.5 + (255 / 1024) * sum, both products being the same real number with an exactly
+// representable factor.  Returns the two quantised channels in bits 0..15.
+__device__ __forceinline__ uint32_t downsample4_rgba8_half(uint32_t t00, uint32_t t01, uint32_t t10, uint32_t t11, uint32_t sh) {
+    const direct_f2 kr = {1.0f / 255.0f, 1.0f / 255.0f}, knq = {0.25f * (255.0f / 256.0f), 0.25f * (255.0f / 256.0f)}, khalf = {0.5f, 0.5f};
+    auto conv = [&](uint32_t t) -> direct_f2 {
+        const uint32_t u = t >> sh;
+        const direct_f2 x = {float(u & 0xFFu), float((u >> 8) & 0xFFu)};
+        return __builtin_elementwise_fma(x, kr, x);
+    };
+    const direct_f2 sum = ((conv(t00) + conv(t01)) + conv(t10)) + conv(t11);
+    const direct_f2 w = khalf + knq * sum;
+    return uint32_t(w.x) | (uint32_t(w.y) << 8);
+}
+template <int kCtrl>
+__device__ __forceinline__ uint32_t quad_dpp(uint32_t v) {
+    return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), kCtrl, 0xf, 0xf, true));
+}
+
+constexpr uint32_t kDirectRows = 8, kDirectMaxBlocks = 8;
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_direct_rgba8_kernel(FusedArgs A) {
-    constexpr uint32_t kRows = 8;
+    constexpr uint32_t kRows = kDirectRows;
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
     const uint32_t blocks_per_tile = (c + kRows - 1) / kRows;
+    // a workgroup runs A.groups consecutive 8-row blocks of one tile: the column axes (one IEEE division per column),
+    // neighbour lookups and apron-lane set-up are paid once per sweep instead of once per block
+    const uint32_t nb = A.groups, wgs_per_tile = (blocks_per_tile + nb - 1) / nb;
     const uint32_t work = xcd_remap(blockIdx.x, gridDim.x);
-    const MainItem it = A.items[work / blocks_per_tile];
-    const uint32_t blk = work % blocks_per_tile, cr0 = blk * kRows, nrows = min(kRows, c - cr0);
+    const MainItem it = A.items[work / wgs_per_tile];
+    const uint32_t blk_begin = (work % wgs_per_tile) * nb, blk_end = min(blk_begin + nb, blocks_per_tile);
+    const uint32_t row_begin = blk_begin * kRows, row_end = min(blk_end * kRows, c);
     const RasterDev raster = A.rasters[it.raster];
-    const float scale = float(1u << A.lod);
+    const float scale = float(1u << A.lod), inv_scale = 1.0f / scale;
     const uint32_t tid = threadIdx.x;
     uint32_t* atlas = reinterpret_cast<uint32_t*>(A.atlas);
     const uint32_t tile_texels = T * T;
@@ -1211,17 +1318,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint32_t self4 = A.levels >= 2 ? grid_lookup(A, it.side, A.lod - 1, int(it.x >> 1), int(it.y >> 1)) : kInvalid;
     const uint32_t self3 = A.levels >= 3 ? grid_lookup(A, it.side, A.lod - 2, int(it.x >> 2), int(it.y >> 2)) : kInvalid;
 
-    __shared__ Axis s_ay[kRows];
-    __shared__ int s_consecutive;
-    if (tid < nrows) s_ay[tid] = split_axis(cr0 + tid, c, it.y, scale, A.tly, A.bry, raster.height);
+    __shared__ Axis s_ay[kDirectMaxBlocks * kRows];
+    __shared__ int s_consecutive[kDirectMaxBlocks];
+    for (uint32_t i = tid; i < row_end - row_begin; i += 256u) s_ay[i] = split_axis_pow2(row_begin + i, c, it.y, inv_scale, A.tly, A.bry, raster.height);
     __syncthreads();
-    if (tid == 0) {
-        bool ok = nrows == kRows;
-        for (uint32_t r = 0; ok && r < kRows; r++) ok = s_ay[r].i0 == s_ay[0].i0 + int(r) && s_ay[r].i1 == s_ay[r].i0 + 1;
-        s_consecutive = ok ? 1 : 0;
+    if (tid < blk_end - blk_begin) {
+        const Axis* ay = s_ay + tid * kRows;
+        bool ok = (blk_begin + tid) * kRows + kRows <= c;
+        for (uint32_t r = 0; ok && r < kRows; r++) ok = ay[r].i0 == ay[0].i0 + int(r) && ay[r].i1 == ay[r].i0 + 1;
+        s_consecutive[tid] = ok ? 1 : 0;
     }
     __syncthreads();
-    const bool consecutive = __builtin_amdgcn_readfirstlane(s_consecutive) != 0;
     const global_bytes_t data = (global_bytes_t)raster.data;
 
     const uint32_t c_lanes = (c + 3u) & ~3u;  // whole lane quads take part in the reductions
@@ -1233,10 +1340,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const uint32_t cx = cx0 + tid;
         const bool active = cx < c;
         const bool apron_lane = aprons_in_sweep && cx0 == last_cx0 && !active && cx - c < 2u * b;
+        const bool used = active || apron_lane;
         uint32_t home = it.atlas_index, home_col = cx, store_px = b + cx;
         Axis ax = Axis{0, 0, 0.0f};
         if (active) {
-            ax = split_axis(cx, c, it.x, scale, A.tlx, A.brx, raster.width);
+            ax = split_axis_pow2(cx, c, it.x, inv_scale, A.tlx, A.brx, raster.width);
         } else if (apron_lane) {
             const uint32_t k = cx - c;
             const int rx = k < b ? -1 : 1;
@@ -1245,102 +1353,154 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (n != kInvalid) {
                 home = n;
                 home_col = uint32_t(int(store_px) - int(b) - rx * int(c));
-                ax = split_axis(home_col, c, uint32_t(int(it.x) + rx), scale, A.tlx, A.brx, raster.width);
+                ax = split_axis_pow2(home_col, c, uint32_t(int(it.x) + rx), inv_scale, A.tlx, A.brx, raster.width);
             } else {
                 home_col = k < b ? 0u : c - 1u;
-                ax = split_axis(home_col, c, it.x, scale, A.tlx, A.brx, raster.width);
+                ax = split_axis_pow2(home_col, c, it.x, inv_scale, A.tlx, A.brx, raster.width);
             }
         }
-        uint32_t out[kRows];
-        bool keep[kRows];
+        const uint32_t half_sh = (tid & 1u) * 16u;  // the channel pair this lane finishes in the lane-split reductions
+
+        for (uint32_t blk = blk_begin; blk < blk_end; blk++) {
+            const uint32_t cr0 = blk * kRows, nrows = min(kRows, c - cr0);
+            const Axis* ay_blk = s_ay + (blk - blk_begin) * kRows;
+            uint32_t out[kRows];
 #pragma unroll
-        for (uint32_t r = 0; r < kRows; r++) {
-            out[r] = 0;
-            keep[r] = false;
-        }
-        if (consecutive) {
-            const int y_first = __builtin_amdgcn_readfirstlane(s_ay[0].i0);
-            uint32_t raw0[kRows + 1], raw1[kRows + 1];
+            for (uint32_t r = 0; r < kRows; r++) out[r] = 0;
+            // ---- the fast path: the block's 8 rows use 9 consecutive source rows, and no texel any lane of the wave reads is
+            // "no data" (channel 0 == 0, split.wgsl:34): no per-pixel validity, plain stores
+            bool fast = __builtin_amdgcn_readfirstlane(s_consecutive[blk - blk_begin]) != 0;
+            if (fast) {
+                const int y_first = __builtin_amdgcn_readfirstlane(ay_blk[0].i0);
+                uint32_t raw0[kRows + 1], raw1[kRows + 1];
 #pragma unroll
-            for (uint32_t j = 0; j <= kRows; j++) {
-                const global_u32_t row = (global_u32_t)(data + uint64_t(y_first + int(j)) * raster.pitch);
-                raw0[j] = row[ax.i0];
-                raw1[j] = row[ax.i1];
-            }
-            H4 top = hrow_rgba8_scaled(raw0[0], raw1[0], ax.fr);
-#pragma unroll
-            for (uint32_t r = 0; r < kRows; r++) {
-                const H4 bot = hrow_rgba8_scaled(raw0[r + 1], raw1[r + 1], ax.fr);
-                keep[r] = !(top.valid && bot.valid);
-                out[r] = vmix_rgba8_scaled(top, bot, s_ay[r].fr);
-                top = bot;
-            }
-        } else {
-#pragma unroll
-            for (uint32_t r = 0; r < kRows; r++) {
-                if (r >= nrows) continue;
-                const Axis ay = s_ay[r];
-                const global_u32_t row0 = (global_u32_t)(data + uint64_t(ay.i0) * raster.pitch), row1 = (global_u32_t)(data + uint64_t(ay.i1) * raster.pitch);
-                const H4 top = hrow_rgba8(row0[ax.i0], row0[ax.i1], ax.fr), bot = hrow_rgba8(row1[ax.i0], row1[ax.i1], ax.fr);
-                keep[r] = !(top.valid && bot.valid);
-                out[r] = vmix_rgba8(top, bot, ay.fr);
-            }
-        }
-        // finest texels; a centre pixel without data keeps (and reports) what the atlas holds, an apron pixel copies what
-        // its home tile holds (the rare path, taken per wave only when some lane needs it)
-        bool any_keep = false;
-#pragma unroll
-        for (uint32_t r = 0; r < kRows; r++) {
-            if ((active || apron_lane) && r < nrows && !keep[r]) tile[(b + cr0 + r) * T + store_px] = out[r];
-            any_keep = any_keep || keep[r];
-        }
-        if (__ballot((active || apron_lane) && any_keep)) {
-#pragma unroll
-            for (uint32_t r = 0; r < kRows; r++)
-                if ((active || apron_lane) && r < nrows && keep[r]) {
-                    out[r] = atlas[uint64_t(home) * tile_texels + (b + cr0 + r) * T + b + home_col];
-                    if (apron_lane) tile[(b + cr0 + r) * T + store_px] = out[r];
+                for (uint32_t j = 0; j <= kRows; j++) {
+                    const global_u32_t row = (global_u32_t)(data + uint64_t(y_first + int(j)) * raster.pitch);
+                    raw0[j] = row[ax.i0];
+                    raw1[j] = row[ax.i1];
                 }
-        }
-        if (A.levels < 2 || self4 == kInvalid) continue;
-        // LOD-1: rows (2i, 2i+1) in registers, columns (cx, cx + 1) in the lane pair; downsample.wgsl OFFSETS order
-        uint32_t q[kRows / 2];
+                // rolling over the source rows as they arrive (the loads were all requested above); the no-data test rides along
+                // and is evaluated before anything is stored
+                uint32_t z = min(raw0[0] & 0xFFu, raw1[0] & 0xFFu);
+                H4p top = hrow_rgba8_packed(raw0[0], raw1[0], ax.fr);
 #pragma unroll
-        for (uint32_t i = 0; i < kRows / 2; i++) {
-            const uint32_t p0 = uint32_t(__builtin_amdgcn_update_dpp(0, int(out[2 * i]), 0xB1, 0xf, 0xf, true));      // quad_perm [1, 0, 3, 2]
-            const uint32_t p1 = uint32_t(__builtin_amdgcn_update_dpp(0, int(out[2 * i + 1]), 0xB1, 0xf, 0xf, true));
-            q[i] = downsample4_rgba8(out[2 * i], out[2 * i + 1], p0, p1);
-            if (active && (tid & 1u) == 0 && 2 * i + 1 < nrows)  // centre texel; the parents' aprons come from the batched stitch kernel
-                atlas[uint64_t(self4) * tile_texels + (b + (it.y & 1u) * (c / 2u) + (cr0 >> 1) + i) * T + b + (it.x & 1u) * (c / 2u) + (cx >> 1)] = q[i];
-        }
-        if (A.levels < 3 || self3 == kInvalid) continue;
-        // LOD-2: the even lanes of a quad hold two adjacent LOD-1 pixels
+                for (uint32_t r = 0; r < kRows; r++) {
+                    z = min(z, min(raw0[r + 1] & 0xFFu, raw1[r + 1] & 0xFFu));
+                    const H4p bot = hrow_rgba8_packed(raw0[r + 1], raw1[r + 1], ax.fr);
+                    const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ay_blk[r].fr)));
+                    out[r] = vmix_rgba8_packed(top, bot, fy);
+                    top = bot;
+                }
+                if (__ballot(used && z == 0u)) {
+                    fast = false;  // (wave-uniform) the general path below redoes the block
+                } else if (used) {
 #pragma unroll
-        for (uint32_t j = 0; j < kRows / 4; j++) {
-            const uint32_t pa = uint32_t(__builtin_amdgcn_update_dpp(0, int(q[2 * j]), 0x4E, 0xf, 0xf, true));      // quad_perm [2, 3, 0, 1]
-            const uint32_t pb = uint32_t(__builtin_amdgcn_update_dpp(0, int(q[2 * j + 1]), 0x4E, 0xf, 0xf, true));
-            const uint32_t w = downsample4_rgba8(q[2 * j], q[2 * j + 1], pa, pb);
-            if (active && (tid & 3u) == 0 && 4 * j + 3 < nrows)
-                atlas[uint64_t(self3) * tile_texels + (b + (it.y & 3u) * (c / 4u) + (cr0 >> 2) + j) * T + b + (it.x & 3u) * (c / 4u) + (cx >> 2)] = w;
+                    for (uint32_t r = 0; r < kRows; r++) tile[(b + cr0 + r) * T + store_px] = out[r];
+                }
+            }
+            if (!fast) {
+                // ---- the general path, row by row: a pixel without data is not stored (it keeps the atlas value,
+                // split.wgsl:37-42) and its previous value is fetched for the reductions; an apron pixel copies what its
+                // home tile holds
+                bool keep[kRows];
+#pragma unroll
+                for (uint32_t r = 0; r < kRows; r++) keep[r] = false;
+#pragma unroll
+                for (uint32_t r = 0; r < kRows; r++) {
+                    if (r >= nrows) continue;
+                    const Axis ay = ay_blk[r];
+                    const global_u32_t row0 = (global_u32_t)(data + uint64_t(ay.i0) * raster.pitch), row1 = (global_u32_t)(data + uint64_t(ay.i1) * raster.pitch);
+                    const H4 top = hrow_rgba8(row0[ax.i0], row0[ax.i1], ax.fr), bot = hrow_rgba8(row1[ax.i0], row1[ax.i1], ax.fr);
+                    keep[r] = !(top.valid && bot.valid);
+                    out[r] = vmix_rgba8(top, bot, ay.fr);
+                }
+                bool any_keep = false;
+#pragma unroll
+                for (uint32_t r = 0; r < kRows; r++) {
+                    if (used && r < nrows && !keep[r]) tile[(b + cr0 + r) * T + store_px] = out[r];
+                    any_keep = any_keep || keep[r];
+                }
+                if (__ballot(used && any_keep)) {
+#pragma unroll
+                    for (uint32_t r = 0; r < kRows; r++)
+                        if (used && r < nrows && keep[r]) {
+                            out[r] = atlas[uint64_t(home) * tile_texels + (b + cr0 + r) * T + b + home_col];
+                            if (apron_lane) tile[(b + cr0 + r) * T + store_px] = out[r];
+                        }
+                }
+            }
+            if (A.levels < 2 || self4 == kInvalid) continue;
+            // ---- LOD-1: rows (2i, 2i+1) in registers, columns (cx, cx + 1) in the lane pair.  Common case (every texel of the
+            // wave counts, rgb != 0): the two lanes of a pair split the four channels — each gathers the pair's four texels
+            // (left column = even lane, downsample.wgsl OFFSETS order) and finishes two channels; the halves meet by one DPP swap.
+            uint32_t q[kRows / 2];
+            uint32_t zr = 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t r = 0; r < kRows; r++) zr = min(zr, out[r] << 8);
+            if (nrows == kRows && !__ballot(active && zr == 0u)) {
+#pragma unroll
+                for (uint32_t i = 0; i < kRows / 2; i++) {
+                    const uint32_t l0 = quad_dpp<0xA0>(out[2 * i]), l1 = quad_dpp<0xA0>(out[2 * i + 1]);  // quad_perm [0, 0, 2, 2]: the even lane's column
+                    const uint32_t r0 = quad_dpp<0xF5>(out[2 * i]), r1 = quad_dpp<0xF5>(out[2 * i + 1]);  // quad_perm [1, 1, 3, 3]: the odd lane's
+                    const uint32_t mine = downsample4_rgba8_half(l0, l1, r0, r1, half_sh) << half_sh;
+                    q[i] = mine | quad_dpp<0xB1>(mine);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t i = 0; i < kRows / 2; i++) {
+                    // (the odd lane's own result sums in another order; it is replaced by the even lane's, the one the reference order gives)
+                    const uint32_t v = downsample4_rgba8(out[2 * i], out[2 * i + 1], quad_dpp<0xB1>(out[2 * i]), quad_dpp<0xB1>(out[2 * i + 1]));
+                    q[i] = quad_dpp<0xA0>(v);
+                }
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < kRows / 2; i++)
+                if (active && (tid & 1u) == 0 && 2 * i + 1 < nrows)  // centre texel; the parents' aprons come from the batched stitch kernel
+                    atlas[uint64_t(self4) * tile_texels + (b + (it.y & 1u) * (c / 2u) + (cr0 >> 1) + i) * T + b + (it.x & 1u) * (c / 2u) + (cx >> 1)] = q[i];
+            if (A.levels < 3 || self3 == kInvalid) continue;
+            // ---- LOD-2: every lane of a quad holds the quad's two LOD-1 texels of a row (lanes 0, 1 the left, 2, 3 the right)
+            uint32_t w[kRows / 4];
+            uint32_t zq = 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t i = 0; i < kRows / 2; i++) zq = min(zq, q[i] << 8);
+            if (nrows == kRows && !__ballot(active && zq == 0u)) {
+#pragma unroll
+                for (uint32_t j = 0; j < kRows / 4; j++) {
+                    const uint32_t l0 = quad_dpp<0x00>(q[2 * j]), l1 = quad_dpp<0x00>(q[2 * j + 1]);  // quad_perm [0, 0, 0, 0]
+                    const uint32_t r0 = quad_dpp<0xAA>(q[2 * j]), r1 = quad_dpp<0xAA>(q[2 * j + 1]);  // quad_perm [2, 2, 2, 2]
+                    const uint32_t mine = downsample4_rgba8_half(l0, l1, r0, r1, half_sh) << half_sh;
+                    w[j] = mine | quad_dpp<0xB1>(mine);
+                }
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < kRows / 4; j++)
+                    w[j] = downsample4_rgba8(quad_dpp<0x00>(q[2 * j]), quad_dpp<0x00>(q[2 * j + 1]), quad_dpp<0xAA>(q[2 * j]), quad_dpp<0xAA>(q[2 * j + 1]));
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kRows / 4; j++)
+                if (active && (tid & 3u) == 0 && 4 * j + 3 < nrows)
+                    atlas[uint64_t(self3) * tile_texels + (b + (it.y & 3u) * (c / 4u) + (cr0 >> 2) + j) * T + b + (it.x & 3u) * (c / 4u) + (cx >> 2)] = w[j];
         }
     }
 
     // the tile's own apron: stitch.wgsl:53-118 with the neighbour's centre pixel evaluated from the source (its own
     // formula), or the own centre clamped where the neighbour does not exist (same-face neighbours only: cube seams
     // are re-stitched by the batched kernel afterwards)
-    const uint32_t n_cols = aprons_in_sweep ? 0u : nrows * 2u * b, n_top = blk == 0 ? b * T : 0u, n_bottom = blk == blocks_per_tile - 1 ? b * T : 0u;
-    for (uint32_t i = tid; i < n_cols + n_top + n_bottom; i += 256u) {
+    // The 2b whole apron rows (above the first block, below the last) are shared out over ALL workgroups of the tile, an equal
+    // run of pixels each: left to the first / last workgroup they were a 10 us tail on one resident generation of workgroups.
+    const uint32_t n_cols = aprons_in_sweep ? 0u : (row_end - row_begin) * 2u * b;
+    const uint32_t row_px = 2u * b * T, share = (row_px + wgs_per_tile - 1u) / wgs_per_tile;
+    const uint32_t px_begin = min((work % wgs_per_tile) * share, row_px), px_end = min(px_begin + share, row_px);
+    for (uint32_t i = tid; i < n_cols + (px_end - px_begin); i += 256u) {
         uint32_t px, py;
-        if (i < n_cols) {  // the apron columns of this block's rows
+        if (i < n_cols) {  // the apron columns of this workgroup's rows
             const uint32_t r = i / (2u * b), k = i % (2u * b);
             px = k < b ? k : c + k;
-            py = b + cr0 + r;
-        } else if (i < n_cols + n_top) {  // whole apron rows above the first block ...
-            px = (i - n_cols) % T;
-            py = (i - n_cols) / T;
-        } else {  // ... and below the last one
-            px = (i - n_cols - n_top) % T;
-            py = b + c + (i - n_cols - n_top) / T;
+            py = b + row_begin + r;
+        } else {  // apron rows: b above the centre, then b below
+            const uint32_t e = px_begin + (i - n_cols), r = e / T;
+            px = e % T;
+            py = r < b ? r : c + r;
         }
         const int rx = px < b ? -1 : (px >= b + c ? 1 : 0), ry = py < b ? -1 : (py >= b + c ? 1 : 0);
         const uint32_t n = grid_lookup(A, it.side, A.lod, int(it.x) + rx, int(it.y) + ry);
@@ -1678,6 +1838,13 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             job.args.lod = lod_hi;
             job.args.levels = main_levels;
             job.args.item_count = uint32_t(items.size());
+            {   // row blocks per workgroup: as many as keep at least one resident generation (1024 workgroups) busy
+                const uint64_t blocks = uint64_t(items.size()) * ((m.center_size + kDirectRows - 1) / kDirectRows);
+                job.args.groups = uint32_t(std::min<uint64_t>(kDirectMaxBlocks, std::max<uint64_t>(1, blocks / 1024)));
+#ifdef BT_DEBUG_HOOKS
+                if (const char* e = getenv("BT_FUSED_PARTS")) job.args.groups = std::max(1u, std::min(kDirectMaxBlocks, uint32_t(atoi(e))));
+#endif
+            }
             Launch ld{};
             ld.kind = kLaunchFusedDirect;
             ld.attachment = ai;
@@ -1769,7 +1936,8 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         }
 
         const bool tail_follows = lod_hi - (main_levels - 1) > lod_lo;
-        const bool rows_in_tail = !direct && !shard && tail_follows && main_levels > 1 && m.border_size % 2u == 0;
+        // (after fused_direct, which writes centres only, the tail's extra workgroups do all four sides: no stitch launch)
+        const bool rows_in_tail = !shard && tail_follows && main_levels > 1 && (direct || m.border_size % 2u == 0);
         if (main_levels > 1 && !rows_in_tail) {
             // fused_main writes the centres and the left / right apron columns of the parent / grand-parent tiles; their
             // top / bottom apron rows (whole 1 KB rows) come from the batched stitch kernel — sharded: everything, after
@@ -1813,8 +1981,9 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             tail.args.levels = levels;
             // the first tail launch also fills the top / bottom apron rows of the LODs fused_main produced (see above)
             tail.args.apron_lods = (rows_in_tail && in_lod == lod_hi - (main_levels - 1)) ? main_levels - 1 : 0u;
+            tail.args.apron_cols = direct ? 1u : 0u;
             if (tail.args.apron_lods)
-                for (uint32_t k = 0; k < tail.args.apron_lods; k++) lt_extra += tiles_at(in_lod + k) * 2 * (2 * m.border_size * Tt) * bpp;
+                for (uint32_t k = 0; k < tail.args.apron_lods; k++) lt_extra += tiles_at(in_lod + k) * 2 * (2 * m.border_size * (Tt + (direct ? cc : 0))) * bpp;
             Launch lt{};
             lt.kind = kLaunchFusedTail;
             lt.attachment = ai;
@@ -1877,8 +2046,9 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
     if (l.kind == kLaunchFusedMain && (jobs[l.aux0].main_runs++ & 1u)) std::swap(job.args.todo, job.args.todo_next);
     job.args.rasters = p->rasters_dev;
     if (l.kind == kLaunchFusedDirect) {
-        const uint32_t blocks_per_tile = (job.args.m.center_size + 7u) / 8u;
-        fused_direct_rgba8_kernel<<<job.args.item_count * blocks_per_tile, 256, 0, p->ctx->stream>>>(job.args);
+        const uint32_t blocks_per_tile = (job.args.m.center_size + kDirectRows - 1) / kDirectRows;
+        const uint32_t wgs_per_tile = (blocks_per_tile + job.args.groups - 1) / job.args.groups;
+        fused_direct_rgba8_kernel<<<job.args.item_count * wgs_per_tile, 256, 0, p->ctx->stream>>>(job.args);
     } else if (l.kind == kLaunchFusedMain) {
         const uint32_t blocks = job.args.item_count * job.args.groups;
         if (job.args.lds_rows) {
@@ -1897,7 +2067,9 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
         const uint32_t size = (1u << job.args.lod) * job.args.m.center_size;
         dim3 grid((size + 63) / 64, (size + 63) / 64, job.args.sides);
         if (job.args.apron_lods) {
-            const uint32_t blocks_per_tile = (job.args.m.border_size * job.args.m.texture_size + 255u) / 256u;
+            const uint32_t blocks_per_tile = job.args.m.format == BT_FORMAT_R16
+                ? (job.args.m.border_size * job.args.m.texture_size + 255u) / 256u  // texel pairs of the 2b apron rows
+                : (2u * job.args.m.border_size * (job.args.m.texture_size + (job.args.apron_cols ? job.args.m.center_size : 0u)) + 255u) / 256u;
             uint64_t extra = 0;
             for (uint32_t k = 0; k < job.args.apron_lods; k++) extra += (1ull << (2 * (job.args.lod + k))) * blocks_per_tile;
             grid.y += uint32_t((extra + grid.x - 1) / grid.x);
