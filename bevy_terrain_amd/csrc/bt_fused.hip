@@ -1376,8 +1376,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                 for (uint32_t j = 0; j <= kRows; j++) {
                     const global_u32_t row = (global_u32_t)(data + uint64_t(y_first + int(j)) * raster.pitch);
-                    raw0[j] = row[ax.i0];
-                    raw1[j] = row[ax.i1];
+                    raw0[j] = BT_ABLATE(A, 8u) ? 0x01010101u * (tid + j + 1u) | 1u : row[ax.i0];  // (8: no source loads)
+                    raw1[j] = BT_ABLATE(A, 8u) ? 0x01010101u * (tid + j + 2u) | 1u : row[ax.i1];
                 }
                 // rolling over the source rows as they arrive (the loads were all requested above); the no-data test rides along
                 // and is evaluated before anything is stored
@@ -1393,7 +1393,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
                 if (__ballot(used && z == 0u)) {
                     fast = false;  // (wave-uniform) the general path below redoes the block
-                } else if (used) {
+                } else if (used && !BT_ABLATE(A, 2u)) {  // (2: no finest stores)
 #pragma unroll
                     for (uint32_t r = 0; r < kRows; r++) tile[(b + cr0 + r) * T + store_px] = out[r];
                 }
@@ -1429,7 +1429,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         }
                 }
             }
-            if (A.levels < 2 || self4 == kInvalid) continue;
+            if (A.levels < 2 || self4 == kInvalid || BT_ABLATE(A, 1u)) continue;  // (1: no pyramid)
             // ---- LOD-1: rows (2i, 2i+1) in registers, columns (cx, cx + 1) in the lane pair.  Common case (every texel of the
             // wave counts, rgb != 0): the two lanes of a pair split the four channels — each gathers the pair's four texels
             // (left column = even lane, downsample.wgsl OFFSETS order) and finishes two channels; the halves meet by one DPP swap.
@@ -1491,7 +1491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint32_t n_cols = aprons_in_sweep ? 0u : (row_end - row_begin) * 2u * b;
     const uint32_t row_px = 2u * b * T, share = (row_px + wgs_per_tile - 1u) / wgs_per_tile;
     const uint32_t px_begin = min((work % wgs_per_tile) * share, row_px), px_end = min(px_begin + share, row_px);
-    for (uint32_t i = tid; i < n_cols + (px_end - px_begin); i += 256u) {
+    for (uint32_t i = tid; i < n_cols + (px_end - px_begin) && !BT_ABLATE(A, 4u); i += 256u) {  // (4: no apron rows)
         uint32_t px, py;
         if (i < n_cols) {  // the apron columns of this workgroup's rows
             const uint32_t r = i / (2u * b), k = i % (2u * b);
