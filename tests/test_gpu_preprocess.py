@@ -556,3 +556,15 @@ def test_fused_path_narrow_tiles_wide_borders(device, cube, T, b):
             atlas, pre = K.product_planar(device, src, lods, T, b, fmt)
             assert pre.stats()["fused_jobs"] == 1
             assert K.assert_atlas_equal(atlas, K.oracle_planar(src, lods, T, b, fmt)) == 85
+
+
+@pytest.mark.parametrize("T,b,lod_count,W,holes", [(64, 2, 6, 1930, 0.0), (64, 2, 6, 1900, 0.01), (100, 2, 5, 1560, 0.002), (36, 2, 6, 1000, 0.0)])
+def test_direct_rgba8_several_row_blocks_per_workgroup(device, T, b, lod_count, W, holes):
+    # fused_direct with many small tiles: the planner gives a workgroup several 8-row blocks (8 blocks of a 64^2 tile =
+    # the whole tile, 3 of the 12 blocks of a 100^2 tile, a ragged last block for c = 32 ...), with and without no-data
+    # texels (the wave-uniform fast path and the per-pixel path side by side), the parents' aprons from the tail launch
+    src = K.random_raster(O.FORMAT_RGBA8, W + 30, W, seed=T * lod_count, holes=holes)
+    tiles = sum(4 ** l for l in range(lod_count))
+    atlas, pre = K.product_planar(device, src, lod_count, T, b, O.FORMAT_RGBA8, atlas_size=2048)
+    assert pre.stats()["fused_jobs"] == 1
+    assert K.assert_atlas_equal(atlas, K.oracle_planar(src, lod_count, T, b, O.FORMAT_RGBA8, atlas_size=2048)) == tiles
