@@ -557,6 +557,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     // block-wide OR of the threads' bits around ONE barrier: a wave writes its ballot into the slot of the chunk's
     // parity, everybody reads the four slots after the barrier (the slot is rewritten two barriers later)
     auto any_nodata = [&](bool mine, uint32_t parity) -> bool {
+        if (BT_ABLATE(A, 16777216u)) {  // (16777216: the barrier without the no-data flag exchange — timing of the control path, clean inputs only)
+            __syncthreads();
+            return false;
+        }
         const unsigned long long wave_bits = __ballot(mine);
         if ((tid & 63u) == 0) S.nodata[parity][tid >> 6] = wave_bits != 0ull;
         __syncthreads();
@@ -715,7 +719,8 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                 n3 = pb1[(r + 2) * P];
                             }
                             const f2 hnew = conv2(t0, t1) * gx + conv2(t2, t3) * fx;
-                            const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fyt[r])));
+                            const float fy = BT_ABLATE(A, 33554432u) ? 0.25f + 0.0625f * float(r)  // (33554432: y weights without the LDS reads — timing only)
+                                                                    : __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fyt[r])));
                             const f2 fy2 = {fy, fy}, gy2 = {1.0f - fy, 1.0f - fy};
                             const f2 w = quantise(hprev * gy2 + hnew * fy2);
                             hprev = hnew;
