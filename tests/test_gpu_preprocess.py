@@ -558,10 +558,10 @@ def test_fused_path_narrow_tiles_wide_borders(device, cube, T, b):
             assert K.assert_atlas_equal(atlas, K.oracle_planar(src, lods, T, b, fmt)) == 85
 
 
-@pytest.mark.parametrize("T,b,lod_count,W,holes", [(64, 2, 6, 1930, 0.0), (64, 2, 6, 1900, 0.01), (100, 2, 5, 1560, 0.002), (36, 2, 6, 1000, 0.0)])
+@pytest.mark.parametrize("T,b,lod_count,W,holes", [(64, 2, 6, 1930, 0.0), (64, 2, 6, 1900, 0.01), (100, 2, 5, 1560, 0.002), (36, 2, 6, 1000, 0.0), (260, 4, 4, 2100, 0.003)])
 def test_direct_rgba8_several_row_blocks_per_workgroup(device, T, b, lod_count, W, holes):
     # fused_direct with many small tiles: the planner gives a workgroup several 8-row blocks (8 blocks of a 64^2 tile =
-    # the whole tile, 3 of the 12 blocks of a 100^2 tile, a ragged last block for c = 32 ...), with and without no-data
+    # the whole tile, 3 of the 12 blocks of a 100^2 tile, a ragged last block for c = 32, apron columns outside the sweeps for c + 2b > 256 ...), with and without no-data
     # texels (the wave-uniform fast path and the per-pixel path side by side), the parents' aprons from the tail launch
     src = K.random_raster(O.FORMAT_RGBA8, W + 30, W, seed=T * lod_count, holes=holes)
     tiles = sum(4 ** l for l in range(lod_count))
