@@ -51,11 +51,11 @@ __device__ __forceinline__ void coordinate_change_lod(Coordinate& c, uint32_t ne
         c.u = su - truncf(su);
         c.v = sv - truncf(sv);
     } else {
-        const uint32_t x = c.x, y = c.y;
-        c.x = x / delta_count;
-        c.y = y / delta_count;
-        c.u = (float(x % delta_count) + c.u) * delta_size;
-        c.v = (float(y % delta_count) + c.v) * delta_size;
+        const uint32_t x = c.x, y = c.y, sh = uint32_t(-d);  // delta_count = 2^sh: quotient and remainder by shift and mask
+        c.x = x >> sh;
+        c.y = y >> sh;
+        c.u = (float(x & (delta_count - 1u)) + c.u) * delta_size;
+        c.v = (float(y & (delta_count - 1u)) + c.v) * delta_size;
     }
 }
 
@@ -71,14 +71,16 @@ __device__ bool should_be_divided(const bt_view_state& v, const bt_tile_coordina
     const float uv_x = off_x < 0 ? 0.0f : (off_x > 0 ? 1.0f : vc.u);
     const float uv_y = off_y < 0 ? 0.0f : (off_y > 0 ? 1.0f : vc.v);
 
-    const float tc = float(1u << tile.lod);
-    float u = (float(tile.x) + uv_x) / tc;
-    float w = (float(tile.y) + uv_y) / tc;
+    // tile_count(lod) = 2^lod: x / 2^lod == x * 2^-lod bit for bit (no underflow at these magnitudes), and so is / 0.5 == * 2 —
+    // five of the function's eleven IEEE divisions (each ~10 instructions, and this kernel is one CU's VALU)
+    const float inv_tc = __builtin_bit_cast(float, (127u - tile.lod) << 23);
+    float u = (float(tile.x) + uv_x) * inv_tc;
+    float w = (float(tile.y) + uv_y) * inv_tc;
     float lx, ly, lz;
     if (v.spherical) {
         const float C_SQR = 0.87f * 0.87f;
-        u = (u - 0.5f) / 0.5f;
-        w = (w - 0.5f) / 0.5f;
+        u = (u - 0.5f) * 2.0f;
+        w = (w - 0.5f) * 2.0f;
         u = u / sqrtf(1.0f + C_SQR - C_SQR * u * u);
         w = w / sqrtf(1.0f + C_SQR - C_SQR * w * w);
         switch (tile.side) {
@@ -116,7 +118,7 @@ __device__ bool should_be_divided(const bt_view_state& v, const bt_tile_coordina
     const float dy = (wy + v.approximate_height * ny) - v.world_position[1];
     const float dz = (wz + v.approximate_height * nz) - v.world_position[2];
     const float view_distance = length3(dx, dy, dz);
-    return view_distance < v.subdivision_distance / tc;
+    return view_distance < v.subdivision_distance * inv_tc;
 }
 
 __global__ __launch_bounds__(kThreads) void tiling_prepass_kernel(bt_view_state view, uint32_t capacity,
