@@ -1365,6 +1365,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         }
         const uint32_t half_sh = (tid & 1u) * 16u;  // the channel pair this lane finishes in the lane-split reductions
+        const uint32_t off0 = uint32_t(ax.i0) * 4u, off1 = uint32_t(ax.i1) * 4u;  // (host: raster rows shorter than 2^32 bytes)
 
         for (uint32_t blk = blk_begin; blk < blk_end; blk++) {
             const uint32_t cr0 = blk * kRows, nrows = min(kRows, c - cr0);
@@ -1378,11 +1379,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (fast) {
                 const int y_first = __builtin_amdgcn_readfirstlane(ay_blk[0].i0);
                 uint32_t raw0[kRows + 1], raw1[kRows + 1];
+                // uniform row pointer (stepped by the pitch) + this lane's 32-bit byte offsets: scalar-base loads, no per-load address arithmetic
+                global_bytes_t rowp = data + uint64_t(uint32_t(y_first)) * raster.pitch;
+                uint32_t o0 = off0, o1 = off1;
+                asm volatile("" : "+v"(o0), "+v"(o1));  // keeps the zero-extension next to the loads (scalar base + 32-bit VGPR offset form)
 #pragma unroll
                 for (uint32_t j = 0; j <= kRows; j++) {
-                    const global_u32_t row = (global_u32_t)(data + uint64_t(y_first + int(j)) * raster.pitch);
-                    raw0[j] = BT_ABLATE(A, 8u) ? 0x01010101u * (tid + j + 1u) | 1u : row[ax.i0];  // (8: no source loads)
-                    raw1[j] = BT_ABLATE(A, 8u) ? 0x01010101u * (tid + j + 2u) | 1u : row[ax.i1];
+                    raw0[j] = BT_ABLATE(A, 8u) ? 0x01010101u * (tid + j + 1u) | 1u : *(global_u32_t)(rowp + o0);  // (8: no source loads)
+                    raw1[j] = BT_ABLATE(A, 8u) ? 0x01010101u * (tid + j + 2u) | 1u : *(global_u32_t)(rowp + o1);
+                    rowp += raster.pitch;
                 }
                 // rolling over the source rows as they arrive (the loads were all requested above); the no-data test rides along
                 // and is evaluated before anything is stored
@@ -1399,8 +1404,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 if (__ballot(used && z == 0u)) {
                     fast = false;  // (wave-uniform) the general path below redoes the block
                 } else if (used && !BT_ABLATE(A, 2u)) {  // (2: no finest stores)
+                    typedef uint8_t __attribute__((address_space(1))) * global_wbytes_t;
+                    typedef uint32_t __attribute__((address_space(1))) * global_wu32_t;
+                    global_wbytes_t rowq = (global_wbytes_t)(tile + (b + cr0) * T);  // uniform row pointer + 32-bit lane offset, like the loads
+                    uint32_t so = store_px * 4u;
+                    asm volatile("" : "+v"(so));
 #pragma unroll
-                    for (uint32_t r = 0; r < kRows; r++) tile[(b + cr0 + r) * T + store_px] = out[r];
+                    for (uint32_t r = 0; r < kRows; r++) {
+                        *(global_wu32_t)(rowq + so) = out[r];
+                        rowq += T * 4u;
+                    }
                 }
             }
             if (!fast) {
