@@ -1376,7 +1376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             // ---- the fast path: the block's 8 rows use 9 consecutive source rows, and no texel any lane of the wave reads is
             // "no data" (channel 0 == 0, split.wgsl:34): no per-pixel validity, plain stores
             bool fast = __builtin_amdgcn_readfirstlane(s_consecutive[blk - blk_begin]) != 0;
-            if (fast) {
+            if (__builtin_expect(fast, 1)) {
                 const int y_first = __builtin_amdgcn_readfirstlane(ay_blk[0].i0);
                 uint32_t raw0[kRows + 1], raw1[kRows + 1];
                 // uniform row pointer (stepped by the pitch) + this lane's 32-bit byte offsets: scalar-base loads, no per-load address arithmetic
@@ -1401,7 +1401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     out[r] = vmix_rgba8_packed(top, bot, fy);
                     top = bot;
                 }
-                if (__ballot(used && z == 0u)) {
+                if (__builtin_expect(__ballot(used && z == 0u) != 0ull, 0)) {
                     fast = false;  // (wave-uniform) the general path below redoes the block
                 } else if (used && !BT_ABLATE(A, 2u)) {  // (2: no finest stores)
                     typedef uint8_t __attribute__((address_space(1))) * global_wbytes_t;
@@ -1416,7 +1416,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     }
                 }
             }
-            if (!fast) {
+            if (__builtin_expect(!fast, 0)) {
                 // ---- the general path, row by row: a pixel without data is not stored (it keeps the atlas value,
                 // split.wgsl:37-42) and its previous value is fetched for the reductions; an apron pixel copies what its
                 // home tile holds
@@ -1455,7 +1455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             uint32_t zr = 0xFFFFFFFFu;
 #pragma unroll
             for (uint32_t r = 0; r < kRows; r++) zr = min(zr, out[r] << 8);
-            if (nrows == kRows && !__ballot(active && zr == 0u)) {
+            if (__builtin_expect(nrows == kRows && !__ballot(active && zr == 0u), 1)) {
 #pragma unroll
                 for (uint32_t i = 0; i < kRows / 2; i++) {
                     const uint32_t l0 = quad_dpp<0xA0>(out[2 * i]), l1 = quad_dpp<0xA0>(out[2 * i + 1]);  // quad_perm [0, 0, 2, 2]: the even lane's column
@@ -1481,7 +1481,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             uint32_t zq = 0xFFFFFFFFu;
 #pragma unroll
             for (uint32_t i = 0; i < kRows / 2; i++) zq = min(zq, q[i] << 8);
-            if (nrows == kRows && !__ballot(active && zq == 0u)) {
+            if (__builtin_expect(nrows == kRows && !__ballot(active && zq == 0u), 1)) {
 #pragma unroll
                 for (uint32_t j = 0; j < kRows / 4; j++) {
                     const uint32_t l0 = quad_dpp<0x00>(q[2 * j]), l1 = quad_dpp<0x00>(q[2 * j + 1]);  // quad_perm [0, 0, 0, 0]
