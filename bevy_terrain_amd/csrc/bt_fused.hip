@@ -594,6 +594,27 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             }
         };
 
+#ifdef BT_DEBUG_HOOKS
+        // (134217728: real-time (100 MHz) stamps of chunks 0, 16, 32, 48 and of the end, per tile, into the atlas's last layer — how far do
+        // the workgroups of a tile row drift apart?  tools/drift_probe.py)
+        if (BT_ABLATE(A, 134217728u) && tid == 0 && (k & 15u) == 0 && k < 64u)
+            reinterpret_cast<unsigned long long*>(A.atlas + uint64_t(A.m.atlas_size - 1u) * tile_texels)[item_index * 8u + (k >> 4)] = __builtin_amdgcn_s_memrealtime();
+#endif
+        // (1073741824, timing experiment: the wave priority rotates with the chunk index, offset by the dispatch rank inside the
+        // XCD.  The CU's arbiters serve the highest-priority wave first and, among equals, the OLDEST — strictly: of the four
+        // resident workgroups of a CU the first-dispatched finishes its tile after 190 us, the last after 275
+        // (tools/drift_probe.py; reversed priorities reverse the staircase).  Rotation makes them finish within 10 us of each
+        // other, one job alone gains 1.3 - 2 %, but jobs in flight behind each other LOSE 3 %: the staircase is what lets the
+        // next job's workgroups move in early.  Aggregate throughput is the memory system's either way.  Not in the product.)
+        if (BT_ABLATE(A, 1073741824u)) {
+            const uint32_t rot_rank = (blockIdx.x / 8u) / 32u + k;
+            switch (rot_rank & 3u) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
         // a chunk with no-data goes to the generic variant as a whole
         const bool skip_chunk = !kGeneric && has_nodata;
         if (skip_chunk && tid == 0) A.todo[2 + atomicAdd(&A.todo[0], 1u)] = item_index * chunks_per_tile + k;
@@ -929,6 +950,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         slots = next_slots;
         has_nodata = any_nodata(nodata, (k + 1) & 1u);
     }
+#ifdef BT_DEBUG_HOOKS
+    if (BT_ABLATE(A, 134217728u) && tid == 0)
+        reinterpret_cast<unsigned long long*>(A.atlas + uint64_t(A.m.atlas_size - 1u) * tile_texels)[item_index * 8u + 4u] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // fast / non-staged variants: workgroup = (tile, part of its chunks), XCD-contiguous order
@@ -940,6 +965,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint32_t part = work % A.groups;
     const uint32_t k_begin = part * chunks_per_tile / A.groups, k_end = (part + 1) * chunks_per_tile / A.groups;
     if (k_begin >= k_end) return;  // more parts than chunks (tiny tiles)
+#ifdef BT_DEBUG_HOOKS
+    {   // wave priority by dispatch rank inside the XCD (rank = which of the 4 resident workgroups of a CU this one is):
+        // 268435456: rank, 536870912: rank / 2, both: 3 - rank
+        const uint32_t rank = min(3u, (blockIdx.x / 8u) / 32u), mode = (A.ablate >> 28) & 3u;
+        const uint32_t prio = mode == 1u ? rank : (mode == 2u ? rank / 2u : (mode == 3u ? 3u - rank : 0u));
+        if (prio == 1u) __builtin_amdgcn_s_setprio(1);
+        else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
+        else if (prio == 3u) __builtin_amdgcn_s_setprio(3);
+    }
+#endif
     fused_main_chunks<kStaged, kGeneric, kT, kP>(A, work / A.groups, k_begin, k_end, smem);
 }
 
