@@ -6,9 +6,13 @@ over the resident 16k x 16k R16 heightmap into 1365 tiles of 512^2 (T=512, b=2, 
 Inputs are already in HBM when the timed region starts; value = tiles / s over all ranks.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1: launched by torch.distributed.run, one rank per GPU: the finest tile grid is split into
-column strips, every rank preprocesses its strip and one in-place RCCL all-gather per LOD
-assembles the full atlas on every rank (strong scaling: the 16k job is fixed).
+N = 1: two independent jobs in flight by default (two contexts = two HIP streams, an atlas each, the source shared; steps
+issued round-robin, `--pipeline 1` for a single stream); the roofline's launch durations come from a one-stream pass of the
+same K steps (a launch that shares the GPU with another job's has no duration of its own).
+N > 1: launched by torch.distributed.run, one rank per GPU: the finest tile grid is split into column strips, every rank
+preprocesses its strip, ONE grouped RCCL collective per step issued by the library exchanges the two parent LODs (the finest
+LOD stays on the rank that computed it: `--result distributed`, the default; `replicated` gathers everything), then the short
+finishing kernels run on every rank (strong scaling: the 16k job is fixed).
 """
 import argparse
 import json
