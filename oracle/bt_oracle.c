@@ -167,6 +167,8 @@ struct orc_atlas {
     uint32_t next_unused; /* unused_tiles is 0..atlas_size FIFO: tile_atlas.rs:307-309 */
     task* tasks;
     size_t n_tasks, cap_tasks;
+    orc_task_backend backend; /* NULL: the kernels below */
+    void* backend_user;
 };
 
 static uint64_t coord_hash(orc_coord c) {
@@ -688,6 +690,28 @@ static void run_task(orc_atlas* a, const task* k, uint8_t* scratch) {
     uint32_t T = at->cfg.texture_size, b = at->cfg.border_size, fmt = at->cfg.format;
     size_t tile_bytes = (size_t)T * T * at->pixel_size;
     uint8_t* dst = at->data + (size_t)k->atlas_index * tile_bytes;
+    if (a->backend) {
+        orc_task_desc d;
+        memset(&d, 0, sizeof d);
+        d.type = k->type == TASK_SPLIT ? ORC_TASK_SPLIT : (k->type == TASK_STITCH ? ORC_TASK_STITCH : ORC_TASK_DOWNSAMPLE);
+        d.format = fmt;
+        d.lod_count = a->lod_count;
+        d.texture_size = T;
+        d.border_size = b;
+        d.atlas_size = a->atlas_size;
+        d.tile.coordinate = k->coord;
+        d.tile.atlas_index = k->atlas_index;
+        memcpy(d.rel, k->rel, sizeof d.rel);
+        memcpy(d.top_left, k->top_left, sizeof d.top_left);
+        memcpy(d.bottom_right, k->bottom_right, sizeof d.bottom_right);
+        d.src = k->src;
+        d.src_w = k->src_w;
+        d.src_h = k->src_h;
+        d.atlas = at->data;
+        a->backend(a->backend_user, &d, scratch);
+        memcpy(dst, scratch, tile_bytes);
+        return;
+    }
     /* the reference copies the atlas layer into a write section, lets the kernel overwrite every
      * entry and copies it back (preprocess/mod.rs:169-210): compute into scratch, then store. */
     for (uint32_t py = 0; py < T; py++)
@@ -705,6 +729,11 @@ static void run_task(orc_atlas* a, const task* k, uint8_t* scratch) {
             store_pixel(fmt, scratch, T, px, py, v);
         }
     memcpy(dst, scratch, tile_bytes);
+}
+
+void orc_set_task_backend(orc_atlas* a, orc_task_backend backend, void* user) {
+    a->backend = backend;
+    a->backend_user = user;
 }
 
 int orc_run(orc_atlas* a, int threads) {

@@ -99,6 +99,26 @@ int orc_save_tile_config(const orc_atlas* a, const char* path);
 size_t orc_tc_encode(const orc_coord* tiles, uint32_t n, uint8_t* out, size_t cap);
 long orc_tc_decode(const uint8_t* in, size_t n, orc_coord* tiles, uint32_t cap);
 
+/* ---- task backend: run the queue with someone else's kernels ------------ */
+/* The queue driver (orc_run) normally executes each Split / Downsample / Stitch task with this file's restated
+ * kernels.  A backend replaces ONLY that step: it receives the task exactly as the reference's GPU path would (tile,
+ * related tiles, dataset rectangle, source raster, the attachment's atlas as it stands) and must return the tile's new
+ * contents (tight T x T texels) in out_tile; the driver stores it after the task, as the write-section copy-back does.
+ * Used by tests to run the queue through oracle/_ref (the reference's WGSL executed on the CPU). */
+enum { ORC_TASK_SPLIT = 0, ORC_TASK_STITCH = 1, ORC_TASK_DOWNSAMPLE = 2 };
+typedef struct {
+    int32_t type;          /* ORC_TASK_* */
+    uint32_t format, lod_count, texture_size, border_size, atlas_size;
+    orc_atlas_tile tile;
+    orc_atlas_tile rel[8]; /* children (4) or neighbours (8) */
+    float top_left[2], bottom_right[2];
+    const void* src;       /* split: source raster, tightly packed */
+    uint32_t src_w, src_h;
+    const void* atlas;     /* this attachment's layers: atlas_size x T x T texels, tightly packed */
+} orc_task_desc;
+typedef void (*orc_task_backend)(void* user, const orc_task_desc* task, void* out_tile);
+void orc_set_task_backend(orc_atlas* a, orc_task_backend backend, void* user); /* NULL restores the built-in kernels */
+
 /* Sampler model for split (process-wide; test infrastructure): fractional_bits = 0 -> exact f32 bilinear (the
  * definition the product implements); N > 0 -> filter weights snapped to N fractional bits, mode 0 to nearest,
  * mode 1 truncated — what the hardware sampler behind split.wgsl:32 may do. */

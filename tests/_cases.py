@@ -53,6 +53,16 @@ def oracle_planar(src, lod_count, T, b, fmt, atlas_size=128, threads=8, **ds):
     return a
 
 
+def reference_kernels(oracle_atlas):
+    """Checker for the BASELINE configs and smoke(): the oracle's queue driver with every Split / Downsample / Stitch task
+    executed by the REFERENCE'S OWN WGSL (oracle/_ref, see tests/_wgslref.py) instead of the hand-written kernels.  The
+    built library travels to the GPU box; its absence is an error, not a silent fallback."""
+    import _wgslref as W
+
+    assert W.available(), "oracle/_ref/libbt_wgslref.so missing: run `make -C oracle/wgsl_ref` where /root/reference exists"
+    return W.attach(oracle_atlas)
+
+
 def assert_atlas_equal(atlas, oracle, attachment=0):
     ours = atlas.tiles()
     theirs = oracle.tiles()

@@ -1,7 +1,9 @@
-"""Committed golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py from this repository's
-oracle — NOT from the reference, which cannot run here): the oracle must still reproduce them (CPU), and the
-HIP product must reproduce them through the C ABI without the oracle in the loop (GPU)."""
+"""Committed golden vectors (tests/golden/*.npz).  Since round 3 they are OUTPUTS OF THE REFERENCE'S OWN WGSL, executed
+on the CPU by oracle/wgsl_ref (tests/golden/make_golden.py; formats.npz alone is oracle-made: Rust-side byte formats).
+The hand-written oracle must reproduce them (CPU, also on the GPU box where /root/reference does not exist), and the HIP
+product must reproduce them through the C ABI without any oracle in the loop (GPU)."""
 import glob
+from ctypes import sizeof as C_sizeof
 import hashlib
 import os
 
@@ -11,7 +13,7 @@ import pytest
 import _oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not p.endswith("formats.npz"))
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not p.endswith(("formats.npz", "refine.npz")))
 
 
 def check_tiles(g, tiles_of):
@@ -24,7 +26,12 @@ def check_tiles(g, tiles_of):
 
 
 def test_fixture_set_is_complete():
-    assert CASES == ["cube_r16_t16", "planar_r16_t128_one_hole", "planar_r16_t16", "planar_r16_t64", "planar_rgba8_t16"]
+    assert CASES == ["cube_r16_t16", "cube_rgba8_t16", "planar_r16_t128_one_hole", "planar_r16_t16", "planar_r16_t24_overlay",
+                     "planar_r16_t32_subrect", "planar_r16_t64", "planar_rgba8_t16", "planar_rgba8_t32_b3"]
+    for name in CASES + ["refine"]:
+        g = np.load(os.path.join(GOLDEN, name + ".npz"))
+        assert str(g["generator"]) == "oracle/_ref: executed WGSL"
+        assert any("preprocess/split.wgsl" in s for s in g["wgsl_sha256"].tolist())
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -37,10 +44,35 @@ def test_oracle_reproduces_golden(name):
     if cube:
         a.preprocess_spherical(0, list(g["source"]), (0, lods))
     else:
-        a.preprocess_tile(0, g["source"], (0, lods))
+        for src, r in zip(g["source"], g["rects"]):
+            a.preprocess_tile(0, src, (0, lods), top_left=(float(r[0]), float(r[1])), bottom_right=(float(r[2]), float(r[3])))
     a.run(4)
     assert [list(c) + [i] for c, i in a.tiles()] == g["coords"].tolist()
     check_tiles(g, lambda i: a.tile(0, i))
+
+
+REFINE_PATHS = ("planar", "sphere", "ellipsoid")
+
+
+def refine_frames(g, name):
+    views, off = g[name + "_views"], g[name + "_offsets"]
+    for k in range(len(views)):
+        yield k, O.View.from_buffer_copy(views[k].tobytes()), g[name + "_tiles"][off[k]:off[k + 1]], g[name + "_indirect"][k].tolist(), g[name + "_passes"][k].tolist()
+
+
+@pytest.mark.parametrize("name", REFINE_PATHS)
+def test_oracle_reproduces_golden_refine(name):
+    """prepare_prepass.wgsl + refine_tiles.wgsl + functions.wgsl executed (fixture) vs the oracle's restatement: the same
+    final list in the same order, the same indirect args and per-pass tile counts; and the oracle's own derivation of
+    the view uniforms still gives the byte-identical struct the fixture was made from"""
+    g = np.load(os.path.join(GOLDEN, "refine.npz"))
+    total = 0
+    for k, view, tiles, indirect, passes in refine_frames(g, name):
+        ours, ours_indirect, ours_passes = O.refine(view)
+        assert np.array_equal(ours, tiles), (name, k)
+        assert ours_indirect == indirect and ours_passes == passes
+        total += len(tiles)
+    assert total > 1000
 
 
 def test_oracle_reproduces_golden_formats():
@@ -74,12 +106,31 @@ def test_product_reproduces_golden(name, generic):
             server.insert(p, np.ascontiguousarray(f))
         pre.preprocess_spherical(bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lods)), server, atlas)
     else:
-        server.insert("src", np.ascontiguousarray(g["source"]))
-        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="src", lod_range=range(0, lods)), server, atlas)
+        for k, (src, r) in enumerate(zip(g["source"], g["rects"])):
+            server.insert(f"src{k}", np.ascontiguousarray(src))
+            pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path=f"src{k}", lod_range=range(0, lods), top_left=(float(r[0]), float(r[1])),
+                                                     bottom_right=(float(r[2]), float(r[3]))), server, atlas)
     pre.run(atlas, generic=generic)
     assert [[c.side, c.lod, c.x, c.y, i] for c, i in atlas.tiles()] == g["coords"].tolist()
     data = atlas.download_tiles(0, 0, int(g["coords"][:, 4].max()) + 1)
     check_tiles(g, lambda i: data[i])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", REFINE_PATHS)
+def test_product_reproduces_golden_refine(name):
+    import bevy_terrain_amd as bt
+    from bevy_terrain_amd import _ffi
+
+    g = np.load(os.path.join(GOLDEN, "refine.npz"))
+    prepass = bt.TilingPrepass(bt.Device(0), 100000)
+    for k, view, tiles, indirect, passes in refine_frames(g, name):
+        assert C_sizeof(_ffi.ViewStateC) == C_sizeof(O.View)  # bt_view_state and orc_view: the same fields in the same order
+        v = _ffi.ViewStateC.from_buffer_copy(bytes(view))
+        prepass.run(v)
+        ours, ours_indirect = prepass.read()
+        assert np.array_equal(ours, tiles), (name, k)
+        assert list(ours_indirect) == indirect
 
 
 @pytest.mark.gpu

@@ -41,7 +41,8 @@ def test_planar_reference_tile_shape_512(device, generic):
 
 
 def test_config2_planar_4k_height_and_albedo(device):
-    """BASELINE config 2: 4096^2 height (R16) + albedo (Rgba8), lod_count 4, 85 tiles each, bit-compare."""
+    """BASELINE config 2: 4096^2 height (R16) + albedo (Rgba8), lod_count 4, 85 tiles each, bit-compared with the
+    reference's own WGSL executed on the CPU (oracle/_ref)."""
     height = K.smooth_raster(4096, 4096, seed=1234, device=device)
     rng = np.random.default_rng(1235)
     albedo = rng.integers(1, 256, size=(4096, 4096, 4), dtype=np.uint8)
@@ -56,7 +57,7 @@ def test_config2_planar_4k_height_and_albedo(device):
            .preprocess_tile(bt.PreprocessDataset(attachment_index=1, path="terrains/planar/source/albedo.png", lod_range=range(0, 4)), server, atlas))
     assert pre.task_counts() == {"split": 128, "stitch": 170, "downsample": 42, "save": 170, "barrier": 16}
     pre.run(atlas)
-    oracle = O.OracleAtlas(4, 1024, False, [(512, 2, 1, O.FORMAT_R16), (512, 2, 1, O.FORMAT_RGBA8)])
+    oracle = K.reference_kernels(O.OracleAtlas(4, 1024, False, [(512, 2, 1, O.FORMAT_R16), (512, 2, 1, O.FORMAT_RGBA8)]))  # executed WGSL
     oracle.clear_attachment(0).clear_attachment(1)
     oracle.preprocess_tile(0, height, (0, 4)).preprocess_tile(1, albedo, (0, 4)).run(8)
     assert K.assert_atlas_equal(atlas, oracle, 0) == 85
@@ -203,7 +204,8 @@ def test_single_nodata_texel_is_seen_at_every_position_of_a_staging_load(device,
 
 def test_config5_cube_8k_faces_full_size(device):
     """BASELINE config 5 at full size: 6 cube faces of 8192^2 (R16), lod_count 5, T = 512 -> 2046 tiles through the
-    fused path (cube seams re-stitched by the batched kernel), every tile compared with the oracle."""
+    fused path (cube seams re-stitched by the batched kernel), every tile compared with the reference's own WGSL executed on
+    the CPU (oracle/_ref)."""
     W, lods = 8192, 5
     faces = [K.smooth_raster(W, W, seed=7 + s, device=device) for s in range(6)]
     for s in range(6):
@@ -219,7 +221,7 @@ def test_config5_cube_8k_faces_full_size(device):
         bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lods)), server, atlas)
     pre.run(atlas)
     assert pre.stats()["fused_jobs"] >= 1 and pre.stats()["tiles"] == 2046
-    oracle = O.OracleAtlas(lods, 2048, True, [(512, 2, 1, O.FORMAT_R16)])
+    oracle = K.reference_kernels(O.OracleAtlas(lods, 2048, True, [(512, 2, 1, O.FORMAT_R16)]))  # the reference's WGSL, executed
     oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(os.cpu_count() or 8)
     assert [((c.side, c.lod, c.x, c.y), i) for c, i in atlas.tiles()] == oracle.tiles()
     for first in range(0, 2046, 128):
@@ -379,7 +381,7 @@ def _nodata_mask_16k(seed=43):
 def test_config3_16k_single_gpu_all_tiles(device, masked):
     """BASELINE config 3 at N = 1, the workload bench.py times: 16384^2 fBm (seed 42), T = 512, b = 2, lod_count 6 ->
     1365 tiles through the fused plan (1024 workgroups, fused_main / fused_todo / fused_tail), every tile byte-compared
-    with the oracle; the masked variant (seed 43, 5 % no-data) drives fused_todo at full size."""
+    with the reference's own WGSL executed on the CPU (oracle/_ref); the masked variant (seed 43, 5 % no-data) drives fused_todo at full size."""
     size, lods = 16384, 6
     ptr = device.synth_fbm_r16(size, size, 42)
     src = device.download(ptr, (size, size), np.uint16)
@@ -401,7 +403,7 @@ def test_config3_16k_single_gpu_all_tiles(device, masked):
     device.free(ptr)
     st = pre.stats()
     assert st["fused_jobs"] == 1 and st["tiles"] == 1365 and st["algorithmic_bytes"] == 1252524032
-    oracle = O.OracleAtlas(lods, 2048, False, [(512, 2, 1, O.FORMAT_R16)])
+    oracle = K.reference_kernels(O.OracleAtlas(lods, 2048, False, [(512, 2, 1, O.FORMAT_R16)]))  # the reference's WGSL, executed
     oracle.clear_attachment(0).preprocess_tile(0, src, (0, lods)).run(os.cpu_count() or 8)
     assert [((c.side, c.lod, c.x, c.y), i) for c, i in atlas.tiles()] == oracle.tiles()
     for first in range(0, 1365, 128):
