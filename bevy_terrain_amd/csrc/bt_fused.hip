@@ -304,7 +304,7 @@ struct MainShared {  // fixed part of the dynamic LDS block (size is a multiple 
     float row_fy[kMaxChunks * kMainRows];  // y weight (8 consecutive ones = two 16-byte uniform reads)
     int win_ymin[kMaxChunks];              // source window of a chunk: first row ...
     uint32_t win_slots[kMaxChunks];        // ... and row count; bit 31: the chunk's rows use source rows y, y+1, ..., y+kMainRows
-    uint32_t nodata[2][4];                 // [chunk parity][wave]: the staged window holds a no-data texel
+    uint32_t nodata[2][4];                 // [chunk parity][wave]: the staged window holds a no-data texel; kDma: [parity][0] = some thread of the chunk read one
     RowParam apron[2 * kMaxBorder];  // [0, b): top apron rows, [b, 2b): bottom apron rows (pad = mosaic row ry)
     int xmin, xmax;
     uint32_t pad[2];
@@ -332,7 +332,12 @@ __device__ __forceinline__ Texel4 convert4(uint32_t ta0, uint32_t ta1, uint32_t 
 // chunks with per-pixel validity, the keep-previous rule and the valid-average.  (Keeping both loops in one kernel
 // costs ~90 spilled VGPRs at the 4-waves-per-SIMD budget.)  kStaged == false reads the source directly (window too
 // large for LDS) and always takes the generic loop.
-template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP>
+// kDma (fast staged variant only, rasters 16-byte aligned): the source rows of the next chunk travel global -> LDS by
+// LDS-DMA (global_load_lds_dwordx4: no staging registers, no commit pass); the no-data test moves from the staging pass to
+// the texels each thread actually reads, per thread: a thread (pair) that saw a no-data texel stores nothing for that
+// quad of rows and flags the chunk for fused_todo, whose generic pass rewrites the whole chunk (identical values where the
+// fast pass did store, keep-previous / valid-average where it did not).
+template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP, bool kDma = false>
 __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t item_index, uint32_t k_begin, uint32_t k_end, uint8_t* smem) {
     MainShared& S = *reinterpret_cast<MainShared*>(smem);
     uint16_t* s_buf = reinterpret_cast<uint16_t*>(smem + sizeof(MainShared));
@@ -499,6 +504,33 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         return z;
     };
 
+    // LDS-DMA staging of a window: wave w moves window rows w, w + 4, ...; a row is one 1 KB instruction (64 lanes x 16
+    // bytes, LDS destination = uniform base + lane * 16) plus a 2-lane instruction for the last 32 bytes of the 1056-byte
+    // row; pieces past the raster row's end re-read its last piece like the register path (never used: the column
+    // indices are clamped into the raster)
+    typedef __attribute__((address_space(3))) uint8_t* lds_bytes;
+    const uint32_t dma_lane = tid & 63u;
+    const uint32_t dma_off_main = min(uint32_t(xa) * 2u + dma_lane * 16u, uint32_t(raster.pitch) - 16u);
+    const uint32_t dma_off_tail = min(uint32_t(xa) * 2u + 1024u + (dma_lane & 1u) * 16u, uint32_t(raster.pitch) - 16u);
+    auto dma_issue = [&](uint16_t* s_dst, int ymin, uint32_t slots) {
+        static_assert(!kDma || kP == 528, "the DMA variant assumes 1056-byte LDS rows");
+        const lds_bytes dst = (lds_bytes)reinterpret_cast<uint8_t*>(s_dst);
+        for (uint32_t slot = tid >> 6; slot < slots; slot += 4u) {  // wave-uniform
+            const global_bytes row = data + uint64_t(uint32_t(ymin) + slot) * raster.pitch;
+            if (BT_ABLATE(A, 32768u))  // (32768: the non-temporal policy on the source stream — timing experiment)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + dma_off_main),
+                                                 (__attribute__((address_space(3))) void*)(dst + slot * (kP * 2u)), 16, 0, 2);
+            else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + dma_off_main),
+                                             (__attribute__((address_space(3))) void*)(dst + slot * (kP * 2u)), 16, 0, 0);
+            if (dma_lane < 2u)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + dma_off_tail),
+                                                 (__attribute__((address_space(3))) void*)(dst + slot * (kP * 2u) + 1024u), 16, 0, 0);
+        }
+    };
+    // exchange inside the lane pair (2m, 2m+1): quad_perm [1, 0, 3, 2]
+    auto pair_min = [](uint32_t v) -> uint32_t { return min(v, uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0xB1, 0xf, 0xf, true))); };
+
     uint16_t* tile5 = A.atlas + uint64_t(t5.self) * tile_texels;
     uint32_t* tile5_u32 = reinterpret_cast<uint32_t*>(tile5);
     uint16_t* tile4 = A.atlas + uint64_t(self4 == kInvalid ? 0u : self4) * tile_texels;
@@ -546,7 +578,11 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     bool nodata = !kStaged;
     u32x4 pre[kBatch];
     window(k_begin, ymin, slots);
-    if (kStaged && !BT_ABLATE(A, 8u)) {
+    if constexpr (kDma) {
+        if (tid == 0) S.nodata[0][0] = S.nodata[1][0] = 0;
+        dma_issue(s_buf + (k_begin & 1u) * buf_texels, ymin, slots);
+        nodata = false;
+    } else if (kStaged && !BT_ABLATE(A, 8u)) {
         if (wide) {
             stage_issue(ymin, slots, pre);
             nodata = stage_commit(s_buf + (k_begin & 1u) * buf_texels, slots, pre);
@@ -557,6 +593,11 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     // block-wide OR of the threads' bits around ONE barrier: a wave writes its ballot into the slot of the chunk's
     // parity, everybody reads the four slots after the barrier (the slot is rewritten two barriers later)
     auto any_nodata = [&](bool mine, uint32_t parity) -> bool {
+        if constexpr (kDma) {  // a plain barrier behind the landing of this wave's DMA rows (and, one counter, its stores)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            return false;
+        }
         if (BT_ABLATE(A, 16777216u)) {  // (16777216: the barrier without the no-data flag exchange — timing of the control path, clean inputs only)
             __syncthreads();
             return false;
@@ -581,8 +622,17 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         const bool more = k + 1 < k_end;
         if (more) {
             window(k + 1, next_ymin, next_slots);
-            if (kStaged && wide && !BT_ABLATE(A, 8u)) stage_issue(next_ymin, next_slots, pre);
+            if constexpr (kDma) dma_issue(s_buf + ((k + 1) & 1u) * buf_texels, next_ymin, next_slots);
+            else if (kStaged && wide && !BT_ABLATE(A, 8u)) stage_issue(next_ymin, next_slots, pre);
         }
+        // kDma: the chunk before this one was flagged by some thread: append it to the todo list (once), clear the flag
+        if constexpr (kDma) {
+            if (tid == 0 && k > k_begin && S.nodata[(k - 1u) & 1u][0]) {
+                S.nodata[(k - 1u) & 1u][0] = 0;
+                A.todo[2 + atomicAdd(&A.todo[0], 1u)] = item_index * chunks_per_tile + (k - 1u);
+            }
+        }
+        uint32_t dirty = 0;  // kDma: this thread skipped stores in this chunk
 
         auto fetch_row = [&](int y) -> Texel4 {
             if constexpr (kStaged) {
@@ -637,6 +687,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                     const uint16_t* h = A.atlas + uint64_t(nrow == kInvalid ? t5.self : nrow) * tile_texels + (b + S.apron[r].pad) * T + b;
                     if (min(t0.za, t1.za) == 0) va = h[rxa];
                     if (min(t0.zb, t1.zb) == 0) vb = h[rxb];
+                }
+                if (kDma && min(min(t0.za, t1.za), min(t0.zb, t1.zb)) == 0) {
+                    dirty = 1;
+                    continue;
                 }
                 tile5_u32[(py * T + px0) >> 1] = va | (vb << 16);
             }
@@ -722,6 +776,8 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                     uint32_t n0 = pa0[P], n1 = pb0[P], n2 = pa1[P], n3 = pb1[P];
                     f2 hprev = conv2(t0, t1) * gx + conv2(t2, t3) * fx;
                     uint32_t q[4];
+                    // kDma: smallest raw texel this thread read for the rows of a quad (source rows 4 * quad .. 4 * quad + 4)
+                    uint32_t zq[2] = {min(min(t0, t1), min(t2, t3)), 0xFFFFu}, zp[2] = {1u, 1u};
                     uint32_t* dst5 = tile5_u32 + (((b + cr0) * T + px0) >> 1);
 #pragma unroll
                     for (uint32_t quad = 0; quad < 2; quad++) {
@@ -739,6 +795,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                 n2 = pa1[(r + 2) * P];
                                 n3 = pb1[(r + 2) * P];
                             }
+                            if constexpr (kDma) {
+                                zq[quad] = min(zq[quad], min(min(t0, t1), min(t2, t3)));
+                                if (quad == 0 && i == 3) zq[1] = min(min(t0, t1), min(t2, t3));  // source row 4 feeds both quads
+                            }
                             const f2 hnew = conv2(t0, t1) * gx + conv2(t2, t3) * fx;
                             const float fy = BT_ABLATE(A, 33554432u) ? 0.25f + 0.0625f * float(r)  // (33554432: y weights without the LDS reads — timing only)
                                                                     : __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fyt[r])));
@@ -748,7 +808,11 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             ua[i] = uint32_t(w.x);
                             ub[i] = uint32_t(w.y);
                         }
-                        if (!is_idle && !BT_ABLATE(A, 2u)) {
+                        if constexpr (kDma) {
+                            zp[quad] = pair_min(zq[quad]);
+                            dirty |= zp[quad] == 0 ? 1u : 0u;
+                        }
+                        if (!is_idle && !BT_ABLATE(A, 2u) && (!kDma || zq[quad] != 0)) {
 #pragma unroll
                             for (uint32_t i = 0; i < 4; i++) {
                                 if (BT_ABLATE(A, 8192u)) __builtin_nontemporal_store(ua[i] | (ub[i] << 16), &dst5[(4 * quad + i) * (T / 2)]);  // (8192: streaming stores)
@@ -776,6 +840,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                 uint32_t* dst = reinterpret_cast<uint32_t*>(tile4 + (b + cy4_first) * T + b + cx4);
 #pragma unroll
                                 for (uint32_t j = 0; j < 4; j++) {
+                                    if (kDma && zp[j >> 1] == 0) continue;  // the pair read a no-data texel in this quad's rows
                                     if (BT_ABLATE(A, 16384u)) __builtin_nontemporal_store(both[j], &dst[j * (T / 2)]);  // (16384: streaming parent stores)
                                     else dst[j * (T / 2)] = both[j];
                                 }
@@ -784,11 +849,13 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         if (x4_count && !BT_ABLATE(A, 4u)) {  // a few lanes of a tile; one texel each unless the x neighbour is absent
                             uint16_t* t = A.atlas + x4_off + cy4_first * T;
 #pragma unroll
-                            for (uint32_t j = 0; j < 4; j++) t[j * T] = uint16_t(q[j]);
+                            for (uint32_t j = 0; j < 4; j++)
+                                if (!kDma || zq[j >> 1] != 0) t[j * T] = uint16_t(q[j]);
                             if (x4_count > 1)
                                 for (uint32_t e = 1; e < x4_count; e++)
 #pragma unroll
-                                    for (uint32_t j = 0; j < 4; j++) t[j * T + e] = uint16_t(q[j]);
+                                    for (uint32_t j = 0; j < 4; j++)
+                                        if (!kDma || zq[j >> 1] != 0) t[j * T + e] = uint16_t(q[j]);
                         }
                         if (do3) {
                             // the lane pair (2m, 2m+1) owns two level-2 pixels (quads 0 and 1): the even lane finishes
@@ -806,8 +873,9 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             const float s3 = (sa + sb) + sc;
                             const uint32_t w3 = uint32_t(0.5f + (0.25f * (65535.0f / 65536.0f)) * s3);  // scaled domain, see quantise_quarter; the clamp is a no-op here
                             const uint32_t row3 = (b + cy3_first + (even ? 0u : 1u)) * T;
-                            if (is_centre && !BT_ABLATE(A, 64u)) tile3[row3 + b + cx3] = uint16_t(w3);
-                            if (x3_count && !BT_ABLATE(A, 64u)) {
+                            const bool clean3 = !kDma || (even ? zp[0] : zp[1]) != 0;
+                            if (is_centre && clean3 && !BT_ABLATE(A, 64u)) tile3[row3 + b + cx3] = uint16_t(w3);
+                            if (x3_count && clean3 && !BT_ABLATE(A, 64u)) {
                                 uint16_t* t = A.atlas + x3_off + (cy3_first + (even ? 0u : 1u)) * T;
                                 t[0] = uint16_t(w3);
                                 if (x3_count > 1)
@@ -816,31 +884,52 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         }
                     }
                 } else {
+                uint32_t zrow = 1;  // kDma: smallest raw texel of the row hblend converted last
                 auto hblend = [&](int y) -> f2 {  // (mix(t00, t10, fx) for column a, same for column b) of source row y
                     const uint16_t* row = s_src + uint32_t(y - cur_ymin) * P;
-                    const f2 left = conv2(row[la0], row[lb0]), right = conv2(row[la1], row[lb1]);
+                    const uint32_t r0 = row[la0], r1 = row[lb0], r2 = row[la1], r3 = row[lb1];
+                    if constexpr (kDma) zrow = min(min(r0, r1), min(r2, r3));
+                    const f2 left = conv2(r0, r1), right = conv2(r2, r3);
                     return left * gx + right * fx;
                 };
                 f2 hcur = kzero;
                 int hy = -1;
+                uint32_t zcur = 1;  // ... and of the row hcur came from
                 for (uint32_t q = 0; q < nrows; q += 4) {
                     uint32_t ua[4], ub[4];
+                    uint32_t zq = 1, zp = 1;
 #pragma unroll
                     for (uint32_t i = 0; i < 4; i++) {
                         const int yy = __builtin_amdgcn_readfirstlane(row_y0[q + i]);
                         const int y0 = yy & 0x7fffffff, y1 = y0 + (yy < 0 ? 0 : 1);
                         const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row_fy[q + i])));
-                        const f2 top = (y0 == hy) ? hcur : hblend(y0);
-                        const f2 bot = (y1 == y0) ? top : hblend(y1);
+                        f2 top = hcur;
+                        uint32_t ztop = zcur;
+                        if (y0 != hy) {
+                            top = hblend(y0);
+                            ztop = zrow;
+                        }
+                        f2 bot = top;
+                        uint32_t zbot = ztop;
+                        if (y1 != y0) {
+                            bot = hblend(y1);
+                            zbot = zrow;
+                        }
                         hcur = bot;
+                        zcur = zbot;
                         hy = y1;
+                        zq = min(zq, min(ztop, zbot));
                         const f2 fy2 = {fy, fy}, gy2 = {1.0f - fy, 1.0f - fy};
                         const f2 w = quantise(top * gy2 + bot * fy2);
                         ua[i] = uint32_t(w.x);
                         ub[i] = uint32_t(w.y);
                     }
+                    if constexpr (kDma) {
+                        zp = pair_min(zq);
+                        dirty |= zp == 0 ? 1u : 0u;
+                    }
                     const uint32_t py = b + cr0 + q;
-                    if (!is_idle && !BT_ABLATE(A, 2u)) {
+                    if (!is_idle && !BT_ABLATE(A, 2u) && (!kDma || zq != 0)) {
 #pragma unroll
                         for (uint32_t i = 0; i < 4; i++) tile5_u32[((py + i) * T + px0) >> 1] = ua[i] | (ub[i] << 16);
                     }
@@ -850,18 +939,18 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         const f2 wq = quantise_quarter(s);
                         const uint32_t q0 = uint32_t(wq.x), q1 = uint32_t(wq.y);
                         const uint32_t cy = cr0 + q, cy4 = cy4_base + (cy >> 1);
-                        if (is_centre) {
+                        if (is_centre && (!kDma || zq != 0)) {
                             uint16_t* dst = tile4 + (b + cy4) * T + b + cx4;
                             dst[0] = uint16_t(q0);
                             dst[T] = uint16_t(q1);
                         }
-                        if (x4_count) {
+                        if (x4_count && (!kDma || zq != 0)) {
                             xpush4(cy4, uint16_t(q0));
                             xpush4(cy4 + 1, uint16_t(q1));
                         }
                         if (do3) {
                             const uint32_t other0 = __shfl_xor(q0, 1), other1 = __shfl_xor(q1, 1);
-                            if (is_centre && (tid & 1u) == 0) {
+                            if (is_centre && (tid & 1u) == 0 && (!kDma || zp != 0)) {
                                 const f2 mine = conv2(q0, q1), theirs = conv2(other0, other1);
                                 const float s3 = ((mine.x + mine.y) + theirs.x) + theirs.y;
                                 const uint32_t w3 = uint32_t(0.5f + (0.25f * (65535.0f / 65536.0f)) * s3);  // scaled domain (conv2)
@@ -938,17 +1027,24 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             }
         }
 
+        if constexpr (kDma) {
+            if (dirty) S.nodata[k & 1u][0] = 1;  // read and cleared by thread 0 after the barrier
+        }
         if (!more) break;
         // chunk k + 1 goes into the other staging buffer (nobody reads it any more: its last readers passed the
         // previous barrier), the row table of chunk k + 3 replaces the one of chunk k after the barrier
         nodata = !kStaged;
-        if (kStaged && !BT_ABLATE(A, 8u)) {
+        if (kStaged && !kDma && !BT_ABLATE(A, 8u)) {
             uint16_t* s_next = s_buf + ((k + 1) & 1u) * buf_texels;
             nodata = wide ? stage_commit(s_next, next_slots, pre) : stage_narrow(s_next, next_ymin, next_slots);
         }
         ymin = next_ymin;
         slots = next_slots;
         has_nodata = any_nodata(nodata, (k + 1) & 1u);
+    }
+    if constexpr (kDma) {  // the last chunk's flag
+        __syncthreads();
+        if (tid == 0 && k_end > k_begin && S.nodata[(k_end - 1u) & 1u][0]) A.todo[2 + atomicAdd(&A.todo[0], 1u)] = item_index * chunks_per_tile + (k_end - 1u);
     }
 #ifdef BT_DEBUG_HOOKS
     if (BT_ABLATE(A, 134217728u) && tid == 0)
@@ -957,7 +1053,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
 }
 
 // fast / non-staged variants: workgroup = (tile, part of its chunks), XCD-contiguous order
-template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP>
+template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP, bool kDma = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_main_kernel(FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t work = BT_ABLATE(A, 1024u) ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);  // (1024: dispatch order, no XCD remap)
@@ -975,7 +1071,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         else if (prio == 3u) __builtin_amdgcn_s_setprio(3);
     }
 #endif
-    fused_main_chunks<kStaged, kGeneric, kT, kP>(A, work / A.groups, k_begin, k_end, smem);
+    fused_main_chunks<kStaged, kGeneric, kT, kP, kDma>(A, work / A.groups, k_begin, k_end, smem);
 }
 
 // the b x b apron corners of the finest tiles: governed by the diagonal neighbour alone (stitch.wgsl:57-66,
@@ -1592,6 +1688,7 @@ struct FusedJobDev {  // one fused launch of a compiled queue
     uint32_t attachment;
     uint32_t main_runs = 0;  // parity selects the todo list
     uint32_t lds_pad = 0;    // profiling build only (BT_FUSED_LDS_PAD at plan time): extra dynamic LDS per workgroup
+    bool dma = false;        // fused_main stages through LDS-DMA (every raster of the job 16-byte aligned in base and pitch)
 };
 
 // the fused path's per-queue state, owned by the bt_preprocessor that compiled it (bt_preprocessor::fused)
@@ -1975,6 +2072,14 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             // and its byte offsets from the first row are kept in 32 bits
             main_job.args.lds_rows = (2 * rows_needed * pitch * 2 <= budget && rows_needed * (pitch / 8) <= 256 * 4 &&
                                       (rows_needed + 1) * max_pitch < (1ull << 31)) ? uint32_t(rows_needed) : 0u;
+            main_job.dma = main_job.args.lds_rows != 0;
+            for (const Task* t : splits) {
+                const RasterDev& r = p->rasters[t->raster].dev;
+                if (((reinterpret_cast<uintptr_t>(r.data) | r.pitch) & 15u) != 0) main_job.dma = false;
+            }
+#ifdef BT_DEBUG_HOOKS
+            if (const char* e = getenv("BT_FUSED_DMA")) main_job.dma = main_job.dma && atoi(e) != 0;
+#endif
         }
         Launch lm{};
         lm.kind = kLaunchFusedMain;
@@ -2107,7 +2212,9 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
         if (job.args.lds_rows) {
             size_t lds = sizeof(MainShared) + 2 * size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
             lds = std::min<size_t>(65536, lds + job.lds_pad);  // (occupancy experiments)
-            if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528)
+            if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528 && job.dma)
+                fused_main_kernel<true, false, 512, 528, true><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
+            else if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528)
                 fused_main_kernel<true, false, 512, 528><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
             else
                 fused_main_kernel<true, false, 0, 0><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
