@@ -6,13 +6,15 @@ over the resident 16k x 16k R16 heightmap into 1365 tiles of 512^2 (T=512, b=2, 
 Inputs are already in HBM when the timed region starts; value = tiles / s over all ranks.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-N = 1: two independent jobs in flight by default (two contexts = two HIP streams, an atlas each, the source shared; steps
-issued round-robin, `--pipeline 1` for a single stream); the roofline's launch durations come from a one-stream pass of the
-same K steps (a launch that shares the GPU with another job's has no duration of its own).
-N > 1: launched by torch.distributed.run, one rank per GPU: the finest tile grid is split into column strips, every rank
-preprocesses its strip, ONE grouped RCCL collective per step issued by the library exchanges the two parent LODs (the finest
-LOD stays on the rank that computed it: `--result distributed`, the default; `replicated` gathers everything), then the short
-finishing kernels run on every rank (strong scaling: the 16k job is fixed).
+The headline (`value`, `ms_per_step`) is defined the same way at every N: ONE job at a time on ONE stream per rank.
+N = 1: job after job on the context's stream.  A second pass with two independent jobs in flight (two contexts = two HIP
+streams, an atlas each, the source shared, steps issued round-robin) is reported as `config.ms_per_step_two_in_flight`.
+N > 1: one rank per GPU (launched by torch.distributed.run, or — when WORLD_SIZE is not set — by this script re-executing
+itself under it): the finest tile grid is split into column strips, every rank preprocesses its strip, ONE grouped RCCL
+collective per step issued by the library assembles the atlas on EVERY rank (in-place all-gathers, `result: replicated`,
+BASELINE config 4), then the short finishing kernels run on every rank (strong scaling: the 16k job is fixed).  The same run
+also reports, as extras in `config`: the kernels alone, the collective alone, and the `distributed` result (the finest LOD
+stays on the rank that computed it; a quarter of the bytes travel).
 """
 import argparse
 import json
@@ -30,53 +32,65 @@ SEED = 42
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
 
 
+def ram_directory():
+    """a RAM-backed directory when it has room (the container's overlay disk throttles at its dirty-page limit), else None"""
+    try:
+        st = os.statvfs("/dev/shm")
+        if st.f_bavail * st.f_frsize > (2 << 30):
+            return "/dev/shm"
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(device, src_ptr):
-    """The CPU oracle (a port: the reference has no CPU path and cannot be built here) timed on the host cores, the
-    span the reference times (preprocessor.rs:363,419: sources in memory -> all tiles produced, and -> all files
-    written).  All cores: with >= 32 cores the whole 16k workload (about 5-10 s); on smaller hosts a bounded sample,
-    the top-left 8192^2 window of the same heightmap with lod_count 5 (341 tiles).  One thread: the top-left 4096^2
-    window with lod_count 4 (85 tiles, a few seconds)."""
-    import shutil
+    """The CPU oracle (a port: the reference has no CPU path and cannot be built here) timed on the host cores over the
+    span the reference times (preprocessor.rs:363,419): tools/cpu_baseline.py in a process of its own — built on this machine
+    with BASELINE.md §3's flags, threads bound, atlas pages pre-touched, per-phase seconds, files on the same file system as the
+    product's end_to_end leg.  A bounded sample: the whole 16k workload with >= 32 cores (a few seconds), else a window."""
+    import subprocess
     import tempfile
 
     import numpy as np
 
+    host = device.download(src_ptr, (SIZE, SIZE), np.uint16)
+    parent = ram_directory() or tempfile.gettempdir()
+    path = os.path.join(parent, f"bt_bench_source_{os.getpid()}.npy")
+    np.save(path, host)
+    del host
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), path, parent], capture_output=True, text=True, timeout=900)
+        if out.returncode != 0:
+            return {"error": out.stderr[-1500:]}
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+
+
+def oracle_atlas(device, src_ptr):
+    """--verify: the 16k job through the checker — the oracle's queue driver with the reference's own WGSL executed for
+    every task (oracle/_ref) when that library is present, else the oracle's own kernels"""
+    import numpy as np
+
     import _oracle as O
 
-    cores = os.cpu_count() or 1
-    sample, lods = (SIZE, LOD_COUNT) if cores >= 32 else (8192, 5)
-    rows = device.download(src_ptr, (sample, SIZE), np.uint16)  # first `sample` rows, all columns
-    window = np.ascontiguousarray(rows[:, :sample])
-    del rows
+    host = device.download(src_ptr, (SIZE, SIZE), np.uint16)
+    a = O.OracleAtlas(LOD_COUNT, ATLAS_SIZE, False, [(TEXTURE_SIZE, BORDER, 1, O.FORMAT_R16)])
+    checker = "oracle/bt_oracle.c"
+    try:
+        import _wgslref as W
 
-    def run(win, nlods, threads):
-        a = O.OracleAtlas(nlods, ATLAS_SIZE, False, [(TEXTURE_SIZE, BORDER, 1, O.FORMAT_R16)])
-        a.preprocess_tile(0, win, (0, nlods))
-        t0 = time.perf_counter()
-        a.run(threads)
-        return a, time.perf_counter() - t0
-
-    a, dt = run(window, lods, cores)
-    tiles = len(a.tiles())
-    out_dir = tempfile.mkdtemp(prefix="bt_cpu_baseline_")
-    t0 = time.perf_counter()
-    a.save_attachment(0, out_dir)
-    a.save_tile_config(os.path.join(out_dir, "config.tc"))
-    dt_files = time.perf_counter() - t0
-    shutil.rmtree(out_dir, ignore_errors=True)
-    small = np.ascontiguousarray(window[:4096, :4096])
-    a1, dt1 = run(small, 4, 1)
-    tiles1 = len(a1.tiles())
-    del a1
-    what = "the whole workload" if sample == SIZE else f"the top-left {sample}x{sample} window of the same heightmap"
-    return {"value": tiles / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/bt_oracle.c (OpenMP over the tasks of a phase) on {what}, lod_count {lods}: "
-                      f"{tiles} tiles of 512^2 in {dt:.2f} s",
-            "files_written": {"value": tiles / (dt + dt_files), "unit": "tiles/s", "cores": cores,
-                              "sample": f"the same run + its {tiles} .bin files and config.tc written to a temporary "
-                                        f"directory ({dt_files:.2f} s, one thread)"},
-            "one_thread": {"value": tiles1 / dt1, "unit": "tiles/s", "cores": 1,
-                           "sample": f"the top-left 4096x4096 window, lod_count 4: {tiles1} tiles in {dt1:.2f} s"}}, a, (sample, lods)
+        if W.available():
+            W.attach(a)
+            checker = "oracle/_ref: the reference's WGSL executed on the CPU (queue driven by oracle/bt_oracle.c)"
+    except Exception:
+        pass
+    a.preprocess_tile(0, host, (0, LOD_COUNT))
+    a.run(O.usable_cores())
+    return a, (SIZE, LOD_COUNT), checker
 
 
 def end_to_end(device, src_ptr):
@@ -101,13 +115,7 @@ def end_to_end(device, src_ptr):
     # where the files go: a RAM-backed file system when it has room (isolates the library's D2H + write pipeline from
     # the box's disk: the container's overlay disk sustains ~3 GB/s once the kernel's dirty-page limit is reached, and
     # how soon that happens depends on what ran before), else the default temporary directory
-    parent = None
-    try:
-        st = os.statvfs("/dev/shm")
-        if st.f_bavail * st.f_frsize > (1 << 30):
-            parent = "/dev/shm"
-    except OSError:
-        pass
+    parent = ram_directory()
     root = tempfile.mkdtemp(prefix="bt_e2e_", dir=parent)
 
     def one_pass(window, lods):
@@ -123,8 +131,54 @@ def end_to_end(device, src_ptr):
         pre.close()
         return (t1 - t0, t2 - t1, t3 - t2)
 
+    def streamed_pass(window, lods, directory):
+        """the overlapped pipeline (bt_preprocessor_run_streamed): deferred upload in bands || kernels || D2H + file writes"""
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas, directory)
+        t0 = time.perf_counter()
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="host", lod_range=range(0, lods)),
+                            bt.AssetServer().insert("host", window), atlas, defer_upload=True)
+        st = pre.run_streamed(atlas, directory)
+        t1 = time.perf_counter()
+        pre.close()
+        return t1 - t0, st
+
+    def digest(directory):
+        import hashlib
+
+        d = atlas.attachment_directory(directory, 0)
+        h = hashlib.sha256()
+        for f in sorted(os.listdir(d)):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+        return h.hexdigest(), len(os.listdir(d))
+
     warm = one_pass(np.ascontiguousarray(host[:2048, :2048]), 3)  # 21 tiles: allocates the pinned staging buffers, warms the paths
     results = [warm, one_pass(host, LOD_COUNT)]
+    serial_digest = digest(root)
+    streamed = None
+    try:
+        streamed_pass(np.ascontiguousarray(host[:4096, :4096]), 4, root)  # warm the side streams / the saver thread's paths
+        times = []
+        for _ in range(3):
+            dt, st = streamed_pass(host, LOD_COUNT, root)
+            times.append(dt)
+        streamed = {"ms": min(times) * 1e3, "ms_all": [t * 1e3 for t in times], "bands": st["bands"], "overlapped": st["streamed"],
+                    "files_identical_to_serial_pass": digest(root) == serial_digest}
+        # the same pipeline into the default temporary directory (the box's disk / overlay file system)
+        other = tempfile.mkdtemp(prefix="bt_e2e_disk_")
+        try:
+            dt, _ = streamed_pass(host, LOD_COUNT, other)
+            fs_other = "?"
+            best = ""
+            for ln in open("/proc/mounts"):
+                dev, mnt, typ = ln.split()[:3]
+                if other.startswith(mnt) and len(mnt) > len(best):
+                    best, fs_other = mnt, typ
+            streamed["default_tmp_dir"] = {"ms": dt * 1e3, "filesystem": fs_other, "directory": other}
+        finally:
+            shutil.rmtree(other, ignore_errors=True)
+    except Exception as e:
+        streamed = {"error": repr(e)}
     files = [f for f in os.listdir(atlas.attachment_directory(root, 0)) if f.endswith(".bin")]
     written = sum(os.path.getsize(os.path.join(atlas.attachment_directory(root, 0), f)) for f in files)
     fs = "?"
@@ -157,7 +211,11 @@ def end_to_end(device, src_ptr):
     shutil.rmtree(root, ignore_errors=True)
     up, run, save = results[-1]
     total = up + run + save
-    return {"ms": total * 1e3, "tiles_per_s": len(files) / total,
+    best = streamed["ms"] / 1e3 if streamed and "ms" in streamed else total
+    return {"ms": best * 1e3, "tiles_per_s": len(files) / best,
+            "pipeline": streamed,  # bt_preprocessor_run_streamed: H2D in bands || kernels || D2H + writes; "ms" above is its best of 3
+            "serial": {"ms": total * 1e3, "tiles_per_s": len(files) / total,
+                       "note": "the same span with the legs one after the other: preprocess_tile (upload) -> run -> save"},
             "upload_ms": up * 1e3, "upload_GBps": host.nbytes / up / 1e9,
             "kernels_ms": run * 1e3,
             "save_ms": save * 1e3, "save_GBps": written / save / 1e9, "files": len(files), "bytes_written": written,
@@ -204,18 +262,32 @@ def main():
     ap.add_argument("--collective", choices=["library", "torch"], default=None,
                     help="N > 1: who issues the exchange — the library's own RCCL communicator, one grouped collective per "
                          "step (default with the nccl backend), or torch.distributed (gloo test hook)")
-    ap.add_argument("--result", choices=["replicated", "distributed"], default=None,
-                    help="N > 1: replicated = every rank ends with the full atlas; distributed (default for the planar job) = the "
-                         "finest LOD stays on the rank that computed it, only the two parent LODs are exchanged (a quarter of "
-                         "the bytes), every rank still holds every lower LOD")
-    ap.add_argument("--pipeline", type=int, default=2,
-                    help="N = 1: independent jobs in flight — P contexts (HIP streams) with an atlas each over the same resident "
-                         "source, steps issued round-robin, so the short serial tail of one job runs beside the main kernel "
-                         "of the next (1 = a single stream; N > 1 always uses 1)")
+    ap.add_argument("--result", choices=["replicated", "distributed"], default="replicated",
+                    help="N > 1, the headline pass: replicated (default) = every rank ends with the full atlas (BASELINE config 4); "
+                         "distributed = the finest LOD stays on the rank that computed it, only the two parent LODs are exchanged "
+                         "(a quarter of the bytes), every rank still holds every lower LOD.  The other one is timed as an extra.")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="N = 1: independent jobs in flight in the HEADLINE pass — P contexts (HIP streams) with an atlas each over "
+                         "the same resident source, steps issued round-robin (default 1: one job on one stream, the definition "
+                         "that also holds at N > 1, which always uses 1)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra passes (N = 1: two jobs in flight; N > 1: kernels only, collective only, the other result mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host raster -> files on disk measurement")
-    ap.add_argument("--verify", action="store_true", help="byte-compare all tiles with the oracle run of cpu_baseline")
+    ap.add_argument("--verify", action="store_true", help="byte-compare all tiles with the checker's run of the same job (oracle/_ref when built)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1)
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     import torch
 
@@ -236,13 +308,19 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    ranks_seen = 1
+    if world > 1:  # every rank answers: the line reports how many did
+        ones = torch.ones(1, device="cuda") if backend == "nccl" else torch.ones(1)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        assert ranks_seen == world, f"{ranks_seen} ranks answered, expected {world}"
 
     import bevy_terrain_amd as bt
 
     device = bt.Device(local_rank)
     cube = args.config == "cube"
     collective = args.collective or ("library" if backend == "nccl" else "torch")
-    result = args.result or ("replicated" if cube else "distributed")
+    result = "replicated" if cube else args.result
     if cube:
         size, lod_count, paths = 8192, 5, [f"synthetic/face{f}" for f in range(6)]
         faces = [device.synth_fbm_r16(size, size, 7 + f) for f in range(6)]
@@ -295,8 +373,9 @@ def main():
     # its main kernel run beside the main kernel of the next.  (Deferring only the tail to a second stream while the main
     # kernels stay in order was measured and is slower: the tail's workgroups displace persistent main workgroups.)
     depth = max(1, args.pipeline) if job is None else 1
+    extras = not args.no_extras
     lanes = [(device, atlas, pre)]
-    for _ in range(1, depth):
+    for _ in range(1, max(depth, 2 if (job is None and extras) else 1)):
         d = bt.Device(local_rank)
         a = bt.TileAtlas.new(cfg, d)
         q = bt.Preprocessor.new().clear_attachment(0, a)
@@ -307,11 +386,11 @@ def main():
         lanes.append((d, a, q))
     issued = [0]
 
-    def step(profile=False, lane=None):
+    def step(profile=False, lane=None, width=None):
         if job is not None:
             job.step(profile)
             return
-        _, a, q = lanes[issued[0] % depth if lane is None else lane]
+        _, a, q = lanes[issued[0] % (width or depth) if lane is None else lane]
         issued[0] += 1
         q.run(a, generic=args.generic, keep_queue=True, sync=False, profile=profile)
 
@@ -346,7 +425,7 @@ def main():
         # the kernel, the durations come from the one-stream pass below
         step(profile=depth == 1 and (i % 4 == 0) and not os.environ.get("BT_BENCH_NO_LAUNCH_EVENTS"))
     stops = []
-    for d, _, _ in lanes:  # the K steps are over when the last lane's stream has drained
+    for d, _, _ in lanes[:depth]:  # the K steps are over when the last lane's stream has drained
         e = torch.cuda.Event(enable_timing=True)
         e.record(d.torch_stream)
         stops.append(e)
@@ -359,20 +438,71 @@ def main():
         ms = float(t.item())
     ms_per_step = ms / args.steps
 
-    # N > 1: the same K steps once more without the collectives — kernels only (SURVEY §8e asks for both)
-    compute_only_ms = None
-    if job is not None:
+    def timed_pass(fn, on_stream=None):
+        """K calls of fn between two events on `on_stream`, fenced on both sides, max over ranks; ms per call"""
+        st = on_stream or stream
+        fence()
+        start.record(st)
+        for i in range(args.steps):
+            fn(i)
+        stop.record(st)
+        fence()
+        t = start.elapsed_time(stop)
+        if world > 1:
+            tt = torch.tensor([t], device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = float(tt.item())
+        return t / args.steps
+
+    # N > 1 extras: the same K steps without the collectives (kernels only), the collectives without the kernels, and the
+    # other result mode (SURVEY §8e asks for compute and compute + collective separately)
+    compute_only_ms = exchange_only_ms = None
+    other_result = None
+    if job is not None and extras:
+        compute_only_ms = timed_pass(lambda i: job.step(False, gather=False))
+        job.step(False)  # a complete atlas again
+        exchange_only_ms = timed_pass(lambda i: job.exchange())
+        job.step(False)  # leave a complete atlas behind (--verify)
+        fence()
+        if not cube:
+            # the other result mode on a second atlas / queue / communicator of this rank; every rank must agree that it came up
+            other = "distributed" if result == "replicated" else "replicated"
+            ok, job2 = 1, None
+            try:
+                atlas2 = bt.TileAtlas.new(cfg, device)
+                pre2 = bt.Preprocessor.new().clear_attachment(0, atlas2)
+                job2 = ShardedPreprocess(pre2, atlas2, server, paths, range(0, lod_count), rank, world, generic=args.generic, collective=collective, result=other)
+            except Exception as e:
+                print(f"[rank {rank}] extra pass ({other}) unavailable: {e!r}", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                for _ in range(3):
+                    job2.step(False)
+                t_other = timed_pass(lambda i: job2.step(False))
+                other_result = {"result": other, "ms_per_step": t_other, "tiles_per_s": job2.stats()["tiles"] / (t_other / 1e3),
+                                "all_gather_bytes_per_rank": job2.gather_bytes}
+            if job2 is not None:
+                job2.close()
+
+    # N = 1 extra: two independent jobs in flight (two contexts / streams, an atlas each): the tail, the todo launch and the
+    # drain of one job's main kernel run beside the main kernel of the next
+    two_in_flight_ms = None
+    if job is None and depth == 1 and extras and len(lanes) >= 2:
+        for _ in range(8):
+            step(width=2)
         fence()
         start.record(stream)
         for _ in range(args.steps):
-            job.step(False, gather=False)
-        stop.record(stream)
+            step(width=2)
+        ends = []
+        for d, _, _ in lanes[:2]:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(d.torch_stream)
+            ends.append(e)
         fence()
-        t = torch.tensor([start.elapsed_time(stop)], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        compute_only_ms = float(t.item()) / args.steps
-        job.step(False)  # leave a complete atlas behind (--verify)
-        fence()
+        two_in_flight_ms = max(start.elapsed_time(e) for e in ends) / args.steps
 
     # N = 1 with several jobs in flight: the same K steps once more on ONE stream — the step time without overlap, and the
     # undisturbed per-launch durations the roofline is computed from (HIP events on that stream, every 4th step)
@@ -411,13 +541,18 @@ def main():
                                 f"synthetic {SIZE}x{SIZE} fBm R16 heightmap (seed {SEED}), T={TEXTURE_SIZE}, b={BORDER}, "
                                 f"lod_count={LOD_COUNT}: split + pyramid + stitch into {tiles} tiles"),
                    "path": "generic (batched split/downsample/stitch)" if stats["fused_jobs"] == 0 else "fused",
-                   "jobs_in_flight": depth,  # contexts (streams) + atlases the K steps rotate over; the source is shared
-                   "ms_per_step_one_stream": one_stream_ms,
+                   "jobs_in_flight": depth,  # contexts (streams) + atlases the K steps of the headline rotate over
+                   "ranks_seen": ranks_seen,
+                   "ms_per_step_one_stream": one_stream_ms if depth > 1 else ms_per_step,
+                   "ms_per_step_two_in_flight": two_in_flight_ms,  # N = 1 extra pass: two contexts (streams + atlases), steps round-robin
+                   "tiles_per_s_two_in_flight": (tiles / (two_in_flight_ms / 1e3)) if two_in_flight_ms else None,
                    "kernels_per_step": stats["kernel_launches"],  # fused_main, fused_todo, fused_tail: what rocprofv3 --stats counts
                    "algorithmic_bytes_per_step": stats["algorithmic_bytes"],
                    "whole_step_GBps": stats["algorithmic_bytes"] / (ms_per_step / 1e3) / 1e9,
                    "host_wall_ms_per_step": wall_ms / args.steps,
                    "kernels_only_ms_per_step": compute_only_ms,  # N > 1: without the all-gathers
+                   "collective_only_ms_per_step": exchange_only_ms,  # N > 1: the grouped collective alone
+                   "other_result_mode": other_result,  # N > 1: the same job with the other --result, timed in the same run
                    "all_gather_bytes_per_rank": (job.gather_bytes if job is not None else 0),
                    "result": (None if job is None else
                               "replicated: every rank ends with the full atlas" if job.held is None else
@@ -457,20 +592,19 @@ def main():
             line["end_to_end"] = end_to_end(device, src_ptr)
         except Exception as e:  # never lose the headline line over a side measurement
             line["end_to_end"] = {"error": repr(e)}
-    if rank == 0 and ((world == 1 and not args.no_cpu_baseline) or args.verify):
-        baseline, oracle, shape = cpu_baseline(device, src_ptr)
-        if world == 1:
-            line["cpu_baseline"] = baseline  # reported at N = 1 only
-        if args.verify:
-            held = None
-            if job is not None and job.held is not None:  # distributed result: rank 0 holds its finest pieces + every lower LOD
-                finest = max(c[1] for c, _ in oracle.tiles())
-                held = {i for c, i in oracle.tiles() if c[1] < finest}
-                for piece in job.held:
-                    held.update(range(piece["first_layer"], piece["first_layer"] + piece["layers"]))
-            line["verify_vs_oracle"] = verify_against(atlas, oracle, shape, held)
-            for k, (_, a, _) in enumerate(lanes[1:], 1):  # every lane's atlas holds a complete, identical job
-                line[f"verify_vs_oracle_lane{k}"] = verify_against(a, oracle, shape)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(device, src_ptr)  # reported at N = 1 only
+    if rank == 0 and args.verify:
+        oracle, shape, line["verify_checker"] = oracle_atlas(device, src_ptr)
+        held = None
+        if job is not None and job.held is not None:  # distributed result: rank 0 holds its finest pieces + every lower LOD
+            finest = max(c[1] for c, _ in oracle.tiles())
+            held = {i for c, i in oracle.tiles() if c[1] < finest}
+            for piece in job.held:
+                held.update(range(piece["first_layer"], piece["first_layer"] + piece["layers"]))
+        line["verify_vs_oracle"] = verify_against(atlas, oracle, shape, held)
+        for k, (_, a, _) in enumerate(lanes[1:], 1):  # every lane's atlas holds a complete, identical job
+            line[f"verify_vs_oracle_lane{k}"] = verify_against(a, oracle, shape)
     if world > 1:
         dist.barrier()  # the other ranks wait for rank 0's oracle run before tearing the group down
     if rank == 0 and world == 1:

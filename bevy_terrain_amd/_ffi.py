@@ -16,7 +16,7 @@ INVALID_ATLAS_INDEX = 0xFFFFFFFF
 MAX_ATTACHMENTS = 8
 
 BT_OK = 0
-RUN_AUTO, RUN_GENERIC, RUN_KEEP_QUEUE, RUN_PROFILE, RUN_SHARD_LOCAL, RUN_SHARD_FINISH, RUN_SHARD_DISTRIBUTED = 0, 1, 2, 4, 8, 16, 32
+RUN_AUTO, RUN_GENERIC, RUN_KEEP_QUEUE, RUN_PROFILE, RUN_SHARD_LOCAL, RUN_SHARD_FINISH, RUN_SHARD_DISTRIBUTED, RUN_SHARD_EXCHANGE = 0, 1, 2, 4, 8, 16, 32, 64
 
 
 class BtError(RuntimeError):
@@ -203,7 +203,15 @@ PROTOTYPES = {
     "bt_tile_tree_view_state": (_i32, [_vp, _P(ViewStateC)]),
     "bt_selftest": (_i32, [_vp, _P(_u32)]),
     "bt_synth_fbm_r16": (_i32, [_vp, _vp, _u32, _u32, _u64, _u32, _u32, _u32, _u32, _u32]),
+    "bt_preprocessor_run_streamed": (_i32, [_vp, _vp, C.c_char_p, _u32, _vp]),
 }
+
+
+class StreamStatsC(C.Structure):
+    _fields_ = [("streamed", C.c_uint32), ("bands", C.c_uint32)]
+
+
+RASTER_HOST_DEFERRED = 2
 
 _lib = None
 

@@ -33,14 +33,19 @@ struct Rccl {
 const Rccl& rccl() {
     static Rccl r = [] {
         Rccl t;
-        void* handle = nullptr;
-        if (dlsym(RTLD_DEFAULT, "ncclAllGather")) {
-            handle = RTLD_DEFAULT;
-        } else {
+        // RTLD_DEFAULT is ((void*)0) on glibc: "found in the process" needs its own flag, not a non-null handle.  When RCCL
+        // is already visible (a host that links it — the bt_comm_adopt case) its symbols MUST come from that instance,
+        // which is what the default search order gives.
+        void* handle = RTLD_DEFAULT;
+        bool found = dlsym(RTLD_DEFAULT, "ncclAllGather") != nullptr;
+        if (!found) {
             for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
-                if ((handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+                if ((handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) {
+                    found = true;
+                    break;
+                }
         }
-        if (!handle) return t;
+        if (!found) return t;
         auto sym = [&](const char* n) { return dlsym(handle, n); };
         t.GetUniqueId = (decltype(t.GetUniqueId))sym("ncclGetUniqueId");
         t.CommInitRank = (decltype(t.CommInitRank))sym("ncclCommInitRank");
@@ -185,11 +190,17 @@ bt_status bt_preprocessor_run_sharded(bt_preprocessor* p, bt_atlas* a, bt_comm* 
     }
     const uint32_t pass = flags & (BT_RUN_GENERIC | BT_RUN_PROFILE);
     const bool local_only = (flags & BT_RUN_SHARD_LOCAL) && !(flags & BT_RUN_SHARD_FINISH);
+    const bool exchange_only = (flags & BT_RUN_SHARD_EXCHANGE) != 0;  // timing: the grouped collective of the compiled plan alone
+    if (exchange_only && (local_only || comm->world == 1 || (p->shard_ranges.empty() && p->shard_pieces.empty()))) {
+        set_error("BT_RUN_SHARD_EXCHANGE needs a sharded queue that has run once (and no BT_RUN_SHARD_LOCAL)");
+        return BT_ERR_INVALID_ARGUMENT;
+    }
     if (comm->world == 1) {
         // a world of one: nothing to exchange; the sharded entry point still runs both halves
         if (bt_status s = bt_preprocessor_run(p, a, pass | BT_RUN_KEEP_QUEUE)) return s;
     } else {
-        if (bt_status s = bt_preprocessor_run(p, a, pass | BT_RUN_KEEP_QUEUE | BT_RUN_SHARD_LOCAL | (flags & BT_RUN_SHARD_DISTRIBUTED))) return s;
+        if (!exchange_only)
+            if (bt_status s = bt_preprocessor_run(p, a, pass | BT_RUN_KEEP_QUEUE | BT_RUN_SHARD_LOCAL | (flags & BT_RUN_SHARD_DISTRIBUTED))) return s;
         if (!local_only) {
             hipStream_t stream = p->ctx->stream;
             const Rccl& R = rccl();
@@ -217,7 +228,8 @@ bt_status bt_preprocessor_run_sharded(bt_preprocessor* p, bt_atlas* a, bt_comm* 
             const int end = R.GroupEnd();
             if (rc) return nccl_fail(rc, "grouped collective");
             if (end) return nccl_fail(end, "ncclGroupEnd");
-            if (bt_status s = bt_preprocessor_run(p, a, (flags & (BT_RUN_GENERIC | BT_RUN_SHARD_DISTRIBUTED)) | BT_RUN_KEEP_QUEUE | BT_RUN_SHARD_FINISH)) return s;
+            if (!exchange_only)
+                if (bt_status s = bt_preprocessor_run(p, a, (flags & (BT_RUN_GENERIC | BT_RUN_SHARD_DISTRIBUTED)) | BT_RUN_KEEP_QUEUE | BT_RUN_SHARD_FINISH)) return s;
         }
     }
     if (!(flags & BT_RUN_KEEP_QUEUE)) return release_queue(p);

@@ -1689,6 +1689,8 @@ struct FusedJobDev {  // one fused launch of a compiled queue
     uint32_t main_runs = 0;  // parity selects the todo list
     uint32_t lds_pad = 0;    // profiling build only (BT_FUSED_LDS_PAD at plan time): extra dynamic LDS per workgroup
     bool dma = false;        // fused_main stages through LDS-DMA (every raster of the job 16-byte aligned in base and pitch)
+    std::vector<MainItem> host_items;  // fused_main's items as uploaded (tile-row order): streamed runs cut them into bands
+    float tly = 0.0f, bry = 1.0f;
 };
 
 // the fused path's per-queue state, owned by the bt_preprocessor that compiled it (bt_preprocessor::fused)
@@ -2012,6 +2014,9 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         main_job.args.lod = lod_hi;
         main_job.args.levels = main_levels;
         main_job.args.item_count = uint32_t(items.size());
+        main_job.host_items = items;
+        main_job.tly = args.tly;
+        main_job.bry = args.bry;
         {
             const uint32_t chunks = (m.center_size + kMainRows - 1) / kMainRows;
             // 4 workgroups of 4 waves per CU (128 VGPRs each) = 1024 resident: pick the number of parts per tile so
@@ -2193,7 +2198,51 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
     return true;
 }
 
-bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
+bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, uint32_t item_begin, uint32_t item_count);
+bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) { return fused_launch_range(p, a, l, 0u, 0xFFFFFFFFu); }
+
+// Bands of whole tile rows of a fused main launch, with the last source row each band's kernels read (the bottom apron rows
+// of its last tile row are evaluated with the next tile row's formula: same f32 operations as the kernel's row tables).
+bool fused_stream_bands(bt_preprocessor* p, const Launch& l, uint32_t tile_rows_per_band, int32_t* raster, std::vector<StreamBand>* bands) {
+    if (l.kind != kLaunchFusedMain || !p->fused || l.aux0 >= p->fused->jobs.size() || tile_rows_per_band == 0) return false;
+    const FusedJobDev& job = p->fused->jobs[l.aux0];
+    const std::vector<MainItem>& items = job.host_items;
+    if (items.empty() || job.args.lds_rows == 0) return false;
+    for (const MainItem& it : items)
+        if (it.side != items[0].side || it.raster != items[0].raster) return false;  // one face, one source
+    const RasterDev& r = p->rasters[items[0].raster].dev;
+    const uint32_t c = job.args.m.center_size, b = job.args.m.border_size, n = 1u << job.args.lod;
+    const float scale = float(n);
+    auto axis = [&](uint32_t tile, uint32_t row) { return split_axis(row, c, tile, scale, job.tly, job.bry, r.height); };
+    *raster = int32_t(items[0].raster);
+    bands->clear();
+    size_t i = 0;
+    while (i < items.size()) {
+        StreamBand band{};
+        band.item_begin = uint32_t(i);
+        band.tile_y_begin = items[i].y;
+        uint32_t rows = 0, y = items[i].y;
+        while (i < items.size() && (items[i].y == y || rows + 1 < tile_rows_per_band)) {
+            if (items[i].y != y) {
+                if (items[i].y < y) return false;  // not in tile-row order
+                y = items[i].y;
+                rows++;
+            }
+            i++;
+        }
+        band.item_count = uint32_t(i) - band.item_begin;
+        band.tile_y_end = y + 1;
+        const int hi = y + 1 < n ? axis(y + 1, b - 1).i1 : axis(y, c - 1).i1;
+        band.source_row_end = uint32_t(std::min<int64_t>(int64_t(r.height), int64_t(hi) + 1));
+        bands->push_back(band);
+    }
+    // source rows must not decrease from band to band (they do not for a dataset rectangle with top < bottom)
+    for (size_t k = 1; k < bands->size(); k++)
+        if ((*bands)[k].source_row_end < (*bands)[k - 1].source_row_end) return false;
+    return true;
+}
+
+bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, uint32_t item_begin, uint32_t item_count) {
     (void)a;
     if (!p->fused || l.aux0 >= p->fused->jobs.size()) {
         set_error("fused launch without a plan");
@@ -2203,6 +2252,10 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
     FusedJobDev job = jobs[l.aux0];
     if (l.kind == kLaunchFusedMain && (jobs[l.aux0].main_runs++ & 1u)) std::swap(job.args.todo, job.args.todo_next);
     job.args.rasters = p->rasters_dev;
+    if (l.kind == kLaunchFusedMain && item_begin < job.args.item_count) {  // a band of the item list (streamed runs); default: all
+        job.args.items += item_begin;
+        job.args.item_count = std::min(item_count, job.args.item_count - item_begin);
+    }
     if (l.kind == kLaunchFusedDirect) {
         const uint32_t blocks_per_tile = (job.args.m.center_size + kDirectRows - 1) / kDirectRows;
         const uint32_t wgs_per_tile = (blocks_per_tile + job.args.groups - 1) / job.args.groups;

@@ -13,7 +13,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <tuple>
@@ -213,6 +215,9 @@ void bt_ctx_destroy(bt_ctx* ctx) {
     if (ctx->ev_begin) hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) hipEventDestroy(ctx->ev_end);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->spare_raster) hipFree(ctx->spare_raster);
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+    if (ctx->save_stream) hipStreamDestroy(ctx->save_stream);
     delete ctx;
 }
 
@@ -604,74 +609,125 @@ class FileWriters {
     std::string error_;
 };
 
-// Download + write the given tiles of one attachment: D2H through three pinned buffers on the context's stream
-// (runs of consecutive layers are one copy), files written by the writer threads while the next chunk downloads.
-bt_status save_tiles(bt_atlas* a, uint32_t ai, const char* directory, std::vector<std::pair<uint32_t, bt_tile_coordinate>> tiles) {
-    const Attachment& at = a->attachments[ai];
-    if (bt_status s = make_dirs(directory)) return s;
-    std::sort(tiles.begin(), tiles.end(), [](const auto& l, const auto& r) { return l.first < r.first; });
-    tiles.erase(std::unique(tiles.begin(), tiles.end(), [](const auto& l, const auto& r) { return l.first == r.first && operator_eq(l.second, r.second); }),
-                tiles.end());
-    if (tiles.empty()) return BT_OK;
-    BT_HIP(hipSetDevice(a->ctx->device));
-    constexpr uint32_t kBuffers = bt_ctx::kStagingBuffers;
-    const uint32_t chunk = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (32ull << 20) / at.tile_bytes)));
-    if (bt_status s = ctx_staging(a->ctx, std::max<size_t>(32ull << 20, at.tile_bytes))) return s;
-    void** pinned = a->ctx->staging;
-    hipEvent_t copied[kBuffers] = {};
-    bt_status rc = BT_OK;
-    for (uint32_t k = 0; k < kBuffers && rc == BT_OK; k++) {
-        hipError_t e = hipEventCreateWithFlags(&copied[k], hipEventDisableTiming);
-        if (e != hipSuccess) rc = hip_fail(e, "save events");
+// Download + write tiles of one attachment: D2H through three pinned buffers on `stream` (runs of consecutive layers are one
+// copy), files written by the writer threads while the next chunk downloads.  add() may be called several times (the
+// streamed run hands over band after band); the tiles of one add() are written in atlas-index order.
+class TileSaver {
+  public:
+    TileSaver(bt_atlas* a, uint32_t ai, std::string directory, hipStream_t stream) : a_(a), ai_(ai), dir_(std::move(directory)), stream_(stream) {}
+    ~TileSaver() {
+        if (writers_)
+            for (uint32_t k = 0; k < kBuffers; k++) writers_->wait_buffer(k);
+        for (uint32_t k = 0; k < kBuffers; k++)
+            if (copied_[k]) hipEventDestroy(copied_[k]);
     }
-    if (rc == BT_OK) {
+    bt_status begin() {
+        const Attachment& at = a_->attachments[ai_];
+        if (bt_status s = make_dirs(dir_)) return s;
+        BT_HIP(hipSetDevice(a_->ctx->device));
+        chunk_ = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (32ull << 20) / at.tile_bytes)));
+        if (bt_status s = ctx_staging(a_->ctx, std::max<size_t>(32ull << 20, at.tile_bytes))) return s;
+        for (uint32_t k = 0; k < kBuffers; k++) {
+            hipError_t e = hipEventCreateWithFlags(&copied_[k], hipEventDisableTiming);
+            if (e != hipSuccess) return hip_fail(e, "save events");
+        }
         // 16 writers: measured on tmpfs and the overlay disk, 6 / 8 / 12 / 16 / 24 / 32 / 64 / 128 threads write at 29 / 34 / 42 /
         // 46-49 / 46 / 35 / 4 / 5 GB/s — beyond ~24 the page-cache allocation lock dominates
         uint32_t threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 #ifdef BT_DEBUG_HOOKS
         if (const char* e = getenv("BT_SAVE_THREADS")) threads = std::max(1, atoi(e));  // tools build only: writer-count experiments
 #endif
-        FileWriters writers(threads, kBuffers);
-        const size_t n = tiles.size(), chunks = (n + chunk - 1) / chunk;
-        auto hand_over = [&](size_t c) -> bt_status {  // chunk c has been enqueued: wait for its copies, queue its files
-            const uint32_t k = uint32_t(c % kBuffers);
-            hipError_t e = hipEventSynchronize(copied[k]);
-            if (e != hipSuccess) return hip_fail(e, "tile download");
-            std::vector<FileWriters::Job> jobs;
-            for (size_t i = c * chunk; i < std::min(n, (c + 1) * chunk); i++) {
-                char name[64];
-                bt_tile_name(tiles[i].second, name, sizeof name);
-                jobs.push_back({std::string(directory) + "/" + name + ".bin", (const uint8_t*)pinned[k] + at.tile_bytes * (i - c * chunk),
-                                size_t(at.tile_bytes), k});
-            }
-            writers.push(std::move(jobs));
-            return BT_OK;
-        };
-        for (size_t c = 0; c < chunks && rc == BT_OK; c++) {
-            const uint32_t k = uint32_t(c % kBuffers);
-            writers.wait_buffer(k);
-            const size_t lo = c * chunk, hi = std::min(n, lo + chunk);
-            for (size_t i = lo; i < hi && rc == BT_OK;) {
+        writers_.reset(new FileWriters(threads, kBuffers));
+        return BT_OK;
+    }
+    // max_chunk: tiles per pinned buffer for this call (smaller chunks at the very end shorten the writers' tail)
+    bt_status add(std::vector<std::pair<uint32_t, bt_tile_coordinate>> tiles, uint32_t max_chunk = 0xFFFFFFFFu) {
+        const Attachment& at = a_->attachments[ai_];
+        void** pinned = a_->ctx->staging;
+        std::sort(tiles.begin(), tiles.end(), [](const auto& l, const auto& r) { return l.first < r.first; });
+        tiles.erase(std::unique(tiles.begin(), tiles.end(), [](const auto& l, const auto& r) { return l.first == r.first && operator_eq(l.second, r.second); }),
+                    tiles.end());
+        const size_t n = tiles.size();
+        const size_t step = std::max<size_t>(1, std::min<size_t>(chunk_, max_chunk));
+        for (size_t lo = 0; lo < n; lo += step) {
+            const size_t hi = std::min(n, lo + step);
+            const uint32_t k = uint32_t(chunks_++ % kBuffers);
+            writers_->wait_buffer(k);
+            // runs of consecutive layers; equally long runs at a constant layer stride (a band of tile rows in the x-major
+            // atlas order: 4 layers every 32) travel as ONE pitched copy instead of one call per run
+            std::vector<std::pair<size_t, size_t>> runs;  // (first tile of the chunk, length)
+            for (size_t i = lo; i < hi;) {
                 size_t run = 1;
                 while (i + run < hi && tiles[i + run].first == tiles[i].first + run) run++;
-                hipError_t e = hipMemcpyAsync((uint8_t*)pinned[k] + at.tile_bytes * (i - lo), (const uint8_t*)at.level0 + at.tile_bytes * tiles[i].first,
-                                              at.tile_bytes * run, hipMemcpyDeviceToHost, a->ctx->stream);
-                if (e != hipSuccess) rc = hip_fail(e, "tile download");
+                runs.push_back({i, run});
                 i += run;
             }
-            if (rc == BT_OK) {
-                hipError_t e = hipEventRecord(copied[k], a->ctx->stream);
-                if (e != hipSuccess) rc = hip_fail(e, "tile download");
+            bool regular = runs.size() >= 2;
+            const uint64_t stride = regular ? uint64_t(tiles[runs[1].first].first) - tiles[runs[0].first].first : 0;
+            for (size_t q = 1; regular && q < runs.size(); q++)
+                regular = runs[q].second == runs[0].second && uint64_t(tiles[runs[q].first].first) - tiles[runs[q - 1].first].first == stride;
+            if (regular) {
+                hipError_t e = hipMemcpy2DAsync(pinned[k], at.tile_bytes * runs[0].second, (const uint8_t*)at.level0 + at.tile_bytes * tiles[lo].first,
+                                                at.tile_bytes * stride, at.tile_bytes * runs[0].second, runs.size(), hipMemcpyDeviceToHost, stream_);
+                if (e != hipSuccess) return hip_fail(e, "tile download");
+            } else {
+                for (const auto& [i, run] : runs) {
+                    hipError_t e = hipMemcpyAsync((uint8_t*)pinned[k] + at.tile_bytes * (i - lo), (const uint8_t*)at.level0 + at.tile_bytes * tiles[i].first,
+                                                  at.tile_bytes * run, hipMemcpyDeviceToHost, stream_);
+                    if (e != hipSuccess) return hip_fail(e, "tile download");
+                }
             }
-            if (rc == BT_OK && c > 0) rc = hand_over(c - 1);
+            hipError_t e = hipEventRecord(copied_[k], stream_);
+            if (e != hipSuccess) return hip_fail(e, "tile download");
+            if (bt_status s = hand_over()) return s;  // the chunk enqueued BEFORE this one: wait for its copies, queue its files
+            in_flight_.assign(tiles.begin() + lo, tiles.begin() + hi);
+            in_flight_buffer_ = k;
+            have_in_flight_ = true;
         }
-        if (rc == BT_OK) rc = hand_over(chunks - 1);
-        for (uint32_t k = 0; k < kBuffers; k++) writers.wait_buffer(k);
-        if (rc == BT_OK) rc = writers.status();
+        return BT_OK;
     }
-    for (uint32_t k = 0; k < kBuffers; k++)
-        if (copied[k]) hipEventDestroy(copied[k]);
-    return rc;
+    bt_status finish() {
+        if (bt_status s = hand_over()) return s;
+        for (uint32_t k = 0; k < kBuffers; k++) writers_->wait_buffer(k);
+        return writers_->status();
+    }
+
+  private:
+    static constexpr uint32_t kBuffers = bt_ctx::kStagingBuffers;
+    bt_status hand_over() {
+        if (!have_in_flight_) return BT_OK;
+        have_in_flight_ = false;
+        const Attachment& at = a_->attachments[ai_];
+        hipError_t e = hipEventSynchronize(copied_[in_flight_buffer_]);
+        if (e != hipSuccess) return hip_fail(e, "tile download");
+        std::vector<FileWriters::Job> jobs;
+        for (size_t i = 0; i < in_flight_.size(); i++) {
+            char name[64];
+            bt_tile_name(in_flight_[i].second, name, sizeof name);
+            jobs.push_back({dir_ + "/" + name + ".bin", (const uint8_t*)a_->ctx->staging[in_flight_buffer_] + at.tile_bytes * i, size_t(at.tile_bytes), in_flight_buffer_});
+        }
+        writers_->push(std::move(jobs));
+        return BT_OK;
+    }
+    bt_atlas* a_;
+    uint32_t ai_;
+    std::string dir_;
+    hipStream_t stream_;
+    uint32_t chunk_ = 1;
+    size_t chunks_ = 0;
+    hipEvent_t copied_[kBuffers] = {};
+    std::unique_ptr<FileWriters> writers_;
+    std::vector<std::pair<uint32_t, bt_tile_coordinate>> in_flight_;
+    uint32_t in_flight_buffer_ = 0;
+    bool have_in_flight_ = false;
+};
+
+bt_status save_tiles(bt_atlas* a, uint32_t ai, const char* directory, std::vector<std::pair<uint32_t, bt_tile_coordinate>> tiles) {
+    if (tiles.empty()) return make_dirs(directory);
+    TileSaver saver(a, ai, directory, a->ctx->stream);
+    if (bt_status s = saver.begin()) return s;
+    if (bt_status s = saver.add(std::move(tiles))) return s;
+    return saver.finish();
 }
 
 }  // namespace
@@ -1029,7 +1085,16 @@ bt_status bt_preprocessor_create(bt_ctx* ctx, bt_preprocessor** out) {
 
 static void release_rasters(bt_preprocessor* p) {
     for (Raster& r : p->rasters)
-        if (r.owned && r.dev.data) hipFree((void*)r.dev.data);
+        if (r.owned && r.dev.data) {
+            // keep the largest released buffer for the next queue's raster (bt_ctx::spare_raster)
+            if (r.alloc_bytes > p->ctx->spare_raster_bytes) {
+                if (p->ctx->spare_raster) hipFree(p->ctx->spare_raster);
+                p->ctx->spare_raster = (void*)r.dev.data;
+                p->ctx->spare_raster_bytes = r.alloc_bytes;
+            } else {
+                hipFree((void*)r.dev.data);
+            }
+        }
     p->rasters.clear();
 }
 
@@ -1096,17 +1161,35 @@ bt_status add_raster(bt_preprocessor* p, const bt_atlas* a, uint32_t ai, const b
     r.format = fmt;
     r.owned = false;
     r.dev = {src->data, src->width, src->height, pitch};
-    if (!src->on_device) {
+    if (src->on_device > BT_RASTER_HOST_DEFERRED) {
+        set_error("bt_raster.on_device = %u", src->on_device);
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    if (src->on_device != 1u) {
         void* dev = nullptr;
         BT_HIP(hipSetDevice(p->ctx->device));
         // the caller's buffer ends with the last texel of the last row, not with a whole pitch
         const uint64_t bytes = pitch * (src->height - 1) + uint64_t(src->width) * px;
-        BT_HIP(hipMalloc(&dev, pitch * src->height));
-        hipError_t e = hipMemcpyAsync(dev, src->data, bytes, hipMemcpyHostToDevice, p->ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
-        if (e != hipSuccess) {
-            hipFree(dev);
-            return hip_fail(e, "raster upload");
+        if (p->ctx->spare_raster && p->ctx->spare_raster_bytes >= pitch * src->height) {  // the buffer the previous queue released
+            dev = p->ctx->spare_raster;
+            p->ctx->spare_raster = nullptr;
+            r.alloc_bytes = p->ctx->spare_raster_bytes;
+            p->ctx->spare_raster_bytes = 0;
+        } else {
+            BT_HIP(hipMalloc(&dev, pitch * src->height));
+            r.alloc_bytes = pitch * src->height;
+        }
+        if (src->on_device == BT_RASTER_HOST_DEFERRED) {  // copied when the queue runs; the caller keeps the rows alive until then
+            r.host = src->data;
+            r.host_bytes = bytes;
+            r.pending = true;
+        } else {
+            hipError_t e = hipMemcpyAsync(dev, src->data, bytes, hipMemcpyHostToDevice, p->ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
+            if (e != hipSuccess) {
+                hipFree(dev);
+                return hip_fail(e, "raster upload");
+            }
         }
         r.dev.data = dev;
         r.owned = true;
@@ -1296,6 +1379,192 @@ bt_status bt_preprocessor_save(bt_preprocessor* p, bt_atlas* a, const char* asse
     if (p->shard_world > 1 && p->shard_distributed && p->shard_rank != 0) return BT_OK;  // config.tc: rank 0
     if (bt_status s = make_dirs(terrain)) return s;
     return bt_atlas_save_tile_config(a, (terrain + "/config.tc").c_str());
+}
+
+// ------------------------------------------------------------------------------------------------ streamed run
+}  // extern "C"
+
+namespace bt {
+bt_status upload_pending_rasters(bt_preprocessor* p) {
+    for (Raster& r : p->rasters)
+        if (r.pending) {
+            BT_HIP(hipMemcpyAsync((void*)r.dev.data, r.host, r.host_bytes, hipMemcpyHostToDevice, p->ctx->stream));
+            BT_HIP(hipStreamSynchronize(p->ctx->stream));
+            r.pending = false;
+        }
+    return BT_OK;
+}
+}  // namespace bt
+
+namespace {
+bt_status ctx_side_streams(bt_ctx* ctx) {
+    if (!ctx->copy_stream) BT_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->save_stream) BT_HIP(hipStreamCreateWithFlags(&ctx->save_stream, hipStreamNonBlocking));
+    return BT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+// The reference's own span (preprocessor.rs:363,419: sources loaded -> all saves done) as ONE overlapped pipeline: the source
+// raster travels to the GPU in bands of tile rows on a copy queue, each band's kernels start when its rows (and the few
+// apron rows below it) have landed, and a second thread downloads and writes a band's finished tiles on a third queue while
+// the next bands upload and run: H2D, kernels, D2H and the file system work at the same time (PCIe is full duplex).  The
+// parent LODs are complete only after the last band + the tail launch and are written last, then config.tc.
+bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* a, const char* assets_root, uint32_t flags, bt_stream_stats* out) {
+    if (!p || !a || !assets_root) return BT_ERR_INVALID_ARGUMENT;
+    if (p->ctx != a->ctx) {
+        set_error("preprocessor and atlas belong to different contexts");
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    if (p->shard_world > 1) {
+        set_error("bt_preprocessor_run_streamed: not for sharded preprocessors");
+        return BT_ERR_UNSUPPORTED;
+    }
+    BT_HIP(hipSetDevice(p->ctx->device));
+    bt_stream_stats st{};
+    if (bt_status s = ensure_compiled(p, a, flags & BT_RUN_GENERIC)) return s;
+    // streamable: the plan starts with ONE fused main launch over one deferred host raster (planar job, one attachment)
+    int32_t raster = -1;
+    std::vector<StreamBand> bands;
+    uint32_t rows_per_band = 4;
+#ifdef BT_DEBUG_HOOKS
+    if (const char* e = getenv("BT_STREAM_BAND_ROWS")) rows_per_band = uint32_t(std::max(1, atoi(e)));
+#endif
+    bool streamable = !p->plan.empty() && fused_stream_bands(p, p->plan[0], rows_per_band, &raster, &bands) && bands.size() > 1;
+    uint32_t pending = 0;
+    for (const Raster& r : p->rasters) pending += r.pending;
+    streamable = streamable && pending == 1 && p->rasters[size_t(raster)].pending;
+    for (size_t i = 1; streamable && i < p->plan.size(); i++) streamable = p->plan[i].kind != kLaunchFusedMain && p->plan[i].kind != kLaunchFusedDirect;
+    if (!p->saves_recorded) {
+        for (const Task& t : p->queue)
+            if (t.type == kSave) a->to_save.push_back({t.coord, t.atlas_index, t.attachment_index});
+        p->saves_recorded = true;
+    }
+    if (!streamable) {  // the same result, one leg after the other
+        if (bt_status s = bt_preprocessor_run(p, a, (flags & BT_RUN_GENERIC) | BT_RUN_KEEP_QUEUE)) return s;
+        if (bt_status s = bt_preprocessor_save(p, a, assets_root)) return s;
+        if (out) *out = st;
+        return (flags & BT_RUN_KEEP_QUEUE) ? BT_OK : release_queue(p);
+    }
+    if (bt_status s = ctx_side_streams(p->ctx)) return s;
+    const Launch main = p->plan[0];
+    const uint32_t ai = main.attachment;
+    Raster& r = p->rasters[size_t(raster)];
+    const size_t nb = bands.size();
+    std::vector<hipEvent_t> uploaded(nb, nullptr), computed(nb + 1, nullptr);
+    bt_status rc = BT_OK;
+    auto make_events = [&](std::vector<hipEvent_t>& v) {
+        for (hipEvent_t& e : v)
+            if (rc == BT_OK && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = BT_ERR_DEVICE;
+    };
+    make_events(uploaded);
+    make_events(computed);
+
+    // which tiles to write after which band: the finest tiles of its tile rows; everything else after the last launch
+    const std::string terrain = std::string(assets_root) + "/" + a->config.path;
+    const std::string dir = terrain + "/data/" + a->attachments[ai].cfg.name;
+    const uint32_t finest = [&] { uint32_t l = 0; for (const AtlasTileAttachment& t : a->to_save) l = std::max(l, t.coordinate.lod); return l; }();
+    std::vector<std::vector<std::pair<uint32_t, bt_tile_coordinate>>> band_tiles(nb + 1);
+    for (const AtlasTileAttachment& t : a->to_save) {
+        if (t.attachment_index != ai || t.atlas_index == BT_INVALID_ATLAS_INDEX) continue;
+        size_t slot = nb;
+        if (t.coordinate.lod == finest)
+            for (size_t k = 0; k < nb; k++)
+                if (t.coordinate.y >= bands[k].tile_y_begin && t.coordinate.y < bands[k].tile_y_end) { slot = k; break; }
+        band_tiles[slot].push_back({t.atlas_index, t.coordinate});
+    }
+
+#ifdef BT_DEBUG_HOOKS
+    const bool trace = getenv("BT_STREAM_TRACE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what, size_t k) {
+        if (trace) fprintf(stderr, "[stream] %7.3f ms %s %zu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), what, k);
+    };
+#else
+    auto stamp = [](const char*, size_t) {};
+#endif
+    // the saver: band after band as their kernels are enqueued (host handshake), ordered on the GPU by events
+    std::mutex m;
+    std::condition_variable cv;
+    size_t launched = 0;  // bands (then nb + 1: everything) whose `computed` event has been recorded
+    bool abort_run = false;
+    bt_status save_rc = BT_OK;
+    char save_error[512] = "";
+    std::thread saver([&] {
+        hipSetDevice(p->ctx->device);
+        TileSaver ts(a, ai, dir, p->ctx->save_stream);
+        bt_status s = ts.begin();
+        for (size_t k = 0; k <= nb && s == BT_OK; k++) {
+            {
+                std::unique_lock<std::mutex> lock(m);
+                cv.wait(lock, [&] { return launched > k || abort_run; });
+                if (abort_run) break;
+            }
+            if (hipStreamWaitEvent(p->ctx->save_stream, computed[k], 0) != hipSuccess) s = BT_ERR_DEVICE;
+            stamp("saver: band enqueued by the launcher", k);
+            if (s == BT_OK && !band_tiles[k].empty()) s = ts.add(std::move(band_tiles[k]), k == nb ? 24u : 0xFFFFFFFFu);
+            stamp("saver: band's copies issued, previous chunks handed to the writers", k);
+        }
+        if (s == BT_OK) s = ts.finish();
+        if (s != BT_OK) {
+            snprintf(save_error, sizeof save_error, "%s", bt_last_error());
+            save_rc = s;
+        }
+    });
+
+    // this thread: upload band k (a pageable copy holds the host until it is done; the GPU meanwhile runs band k - 1), launch it
+    const uint8_t* host = (const uint8_t*)r.host;
+    uint8_t* dev = (uint8_t*)r.dev.data;
+    uint64_t done_rows = 0;
+    auto publish = [&](size_t n) {
+        { std::lock_guard<std::mutex> lock(m); launched = n; }
+        cv.notify_all();
+    };
+    for (size_t k = 0; k < nb && rc == BT_OK; k++) {
+        const uint64_t end_row = k + 1 == nb ? r.dev.height : bands[k].source_row_end;
+        if (end_row > done_rows) {
+            const uint64_t off = done_rows * r.dev.pitch, end = std::min<uint64_t>(r.host_bytes, end_row * r.dev.pitch);
+            stamp("upload begin", k);
+            if (hipMemcpyAsync(dev + off, host + off, end - off, hipMemcpyHostToDevice, p->ctx->copy_stream) != hipSuccess) rc = BT_ERR_DEVICE;
+            stamp("upload call returned", k);
+            done_rows = end_row;
+        }
+        if (rc == BT_OK && hipEventRecord(uploaded[k], p->ctx->copy_stream) != hipSuccess) rc = BT_ERR_DEVICE;
+        if (rc == BT_OK && hipStreamWaitEvent(p->ctx->stream, uploaded[k], 0) != hipSuccess) rc = BT_ERR_DEVICE;
+        if (rc == BT_OK) rc = fused_launch_range(p, a, main, bands[k].item_begin, bands[k].item_count);
+        if (rc == BT_OK && hipEventRecord(computed[k], p->ctx->stream) != hipSuccess) rc = BT_ERR_DEVICE;
+        if (rc == BT_OK) publish(k + 1);
+    }
+    r.pending = false;
+    for (size_t i = 1; i < p->plan.size() && rc == BT_OK; i++) rc = run_plan_entry(p, a, p->plan[i]);
+    if (rc == BT_OK && hipEventRecord(computed[nb], p->ctx->stream) != hipSuccess) rc = BT_ERR_DEVICE;
+    if (rc == BT_OK) publish(nb + 1);
+    else {
+        { std::lock_guard<std::mutex> lock(m); abort_run = true; }
+        cv.notify_all();
+    }
+    stamp("all launched", nb);
+    saver.join();
+    stamp("saver done", nb);
+    hipStreamSynchronize(p->ctx->stream);
+    for (hipEvent_t e : uploaded) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : computed) if (e) hipEventDestroy(e);
+    if (rc == BT_ERR_DEVICE) set_error("bt_preprocessor_run_streamed: HIP call failed (%s)", hipGetErrorString(hipGetLastError()));
+    if (rc != BT_OK) return rc;
+    if (save_rc != BT_OK) {
+        set_error("%s", save_error);
+        return save_rc;
+    }
+    // tiles of other attachments (none in a streamable plan) and config.tc, as bt_preprocessor_save does
+    a->to_save.clear();
+    p->saves_recorded = false;
+    if (bt_status s = make_dirs(terrain)) return s;
+    if (bt_status s = bt_atlas_save_tile_config(a, (terrain + "/config.tc").c_str())) return s;
+    st.streamed = 1;
+    st.bands = uint32_t(nb);
+    if (out) *out = st;
+    return (flags & BT_RUN_KEEP_QUEUE) ? BT_OK : release_queue(p);
 }
 
 bt_status bt_preprocessor_last_run_stats(const bt_preprocessor* p, bt_run_stats* out) {

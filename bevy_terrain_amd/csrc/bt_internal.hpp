@@ -116,6 +116,12 @@ struct Raster {
     RasterDev dev;
     uint32_t format;
     bool owned;
+    // bt_raster.on_device == BT_RASTER_HOST_DEFERRED: the device buffer exists, the caller's rows are copied when the queue runs
+    // (all at once by bt_preprocessor_run, band by band next to the kernels by bt_preprocessor_run_streamed)
+    const void* host = nullptr;
+    uint64_t host_bytes = 0;
+    bool pending = false;
+    uint64_t alloc_bytes = 0;  // size of the owned device allocation
 };
 
 }  // namespace bt
@@ -130,6 +136,12 @@ struct bt_ctx {
     static constexpr uint32_t kStagingBuffers = 3;
     void* staging[kStagingBuffers] = {};
     size_t staging_bytes = 0;
+    // streamed runs: uploads and downloads on their own queues beside the kernels' stream (created on first use)
+    hipStream_t copy_stream = nullptr, save_stream = nullptr;
+    // one released raster allocation is kept for the next queue (hipMalloc + hipFree of a 512 MB source cost ~1.5 ms of the
+    // end-to-end span; a host that preprocesses dataset after dataset pays them once)
+    void* spare_raster = nullptr;
+    uint64_t spare_raster_bytes = 0;
 };
 
 namespace bt {
@@ -182,6 +194,19 @@ struct FusedState;
 void fused_release(struct ::bt_preprocessor* p);
 
 bt_status release_queue(struct ::bt_preprocessor* p);  // bt_run.cpp
+bt_status ensure_compiled(struct ::bt_preprocessor* p, struct ::bt_atlas* a, uint32_t mode);  // bt_run.cpp: queue -> launch plan
+bt_status run_plan_entry(struct ::bt_preprocessor* p, struct ::bt_atlas* a, const Launch& l);  // bt_run.cpp: one launch of the plan
+bt_status upload_pending_rasters(struct ::bt_preprocessor* p);  // bt_host.cpp: deferred host rasters, all at once
+
+// streamed run (bt_host.cpp drives it): a fused main launch cut into bands of whole tile rows
+struct StreamBand {
+    uint32_t item_begin, item_count;  // into the job's item list (tile-row order)
+    uint32_t tile_y_begin, tile_y_end;
+    uint32_t source_row_end;          // the band's kernels read source rows below this one (exclusive)
+};
+// true when plan entry `l` is a fused main launch over ONE planar raster that can run band by band
+bool fused_stream_bands(struct ::bt_preprocessor* p, const Launch& l, uint32_t tile_rows_per_band, int32_t* raster, std::vector<StreamBand>* bands);
+bt_status fused_launch_range(struct ::bt_preprocessor* p, struct ::bt_atlas* a, const Launch& l, uint32_t item_begin, uint32_t item_count);
 
 // coordinate math (bt_host.cpp)
 void tile_children(bt_tile_coordinate c, bt_tile_coordinate out[4]);

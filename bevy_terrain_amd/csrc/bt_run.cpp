@@ -20,6 +20,8 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l);
 
 namespace {
 
+constexpr uint32_t kMaxProfiledRuns = 256;  // events kept until bt_preprocessor_profile reads them
+
 TaskDev to_device_task(const Task& t) {
     TaskDev d{};
     d.atlas_index = t.atlas_index;
@@ -103,15 +105,9 @@ bt_status ensure_device_array(void** ptr, size_t* cap, size_t bytes) {
 
 }  // namespace
 
-extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32_t flags) {
-    if (!p || !a) return BT_ERR_INVALID_ARGUMENT;
-    if (p->ctx != a->ctx) {
-        set_error("preprocessor and atlas belong to different contexts");
-        return BT_ERR_INVALID_ARGUMENT;
-    }
-    BT_HIP(hipSetDevice(p->ctx->device));
-    const uint32_t mode = flags & BT_RUN_GENERIC;
-
+namespace bt {
+// queue -> launch plan (once per queue and mode)
+bt_status ensure_compiled(bt_preprocessor* p, bt_atlas* a, uint32_t mode) {
     if (!p->compiled || p->compiled_flags != mode) {
         std::vector<TaskDev> tasks;
         p->plan.clear();
@@ -157,8 +153,40 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
         p->events.clear();
         p->profiled_runs = 0;
     }
+    return BT_OK;
+}
 
-    const bool profile = (flags & BT_RUN_PROFILE) != 0 && p->profiled_runs < 256;
+bt_status run_plan_entry(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
+    const Attachment& at = a->attachments[l.attachment];
+    switch (l.kind) {
+        case kLaunchSplit:
+            return launch_split(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count, p->rasters_dev);
+        case kLaunchDownsample:
+            return launch_downsample(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count);
+        case kLaunchStitch:
+            return launch_stitch(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count, l.aux0 == 1u);
+        default:
+            return fused_launch(p, a, l);
+    }
+}
+}  // namespace bt
+
+extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32_t flags) {
+    if (!p || !a) return BT_ERR_INVALID_ARGUMENT;
+    if (p->ctx != a->ctx) {
+        set_error("preprocessor and atlas belong to different contexts");
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    BT_HIP(hipSetDevice(p->ctx->device));
+    const uint32_t mode = flags & BT_RUN_GENERIC;
+    if (bt_status s = upload_pending_rasters(p)) return s;  // rasters handed over with BT_RASTER_HOST_DEFERRED
+    if (bt_status s = ensure_compiled(p, a, mode)) return s;
+
+    if ((flags & BT_RUN_PROFILE) != 0 && p->profiled_runs >= kMaxProfiledRuns) {
+        set_error("BT_RUN_PROFILE: %u profiled runs are pending; read them with bt_preprocessor_profile() first", kMaxProfiledRuns);
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    const bool profile = (flags & BT_RUN_PROFILE) != 0;
     auto record = [&](void) -> bt_status {
         hipEvent_t e;
         BT_HIP(hipEventCreate(&e));
@@ -190,23 +218,7 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
                 if (bt_status s2 = record()) return s2;
             continue;
         }
-        const Attachment& at = a->attachments[l.attachment];
-        bt_status s = BT_OK;
-        switch (l.kind) {
-            case kLaunchSplit:
-                s = launch_split(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count, p->rasters_dev);
-                break;
-            case kLaunchDownsample:
-                s = launch_downsample(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count);
-                break;
-            case kLaunchStitch:
-                s = launch_stitch(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count, l.aux0 == 1u);
-                break;
-            default:
-                s = fused_launch(p, a, l);
-                break;
-        }
-        if (s) return s;
+        if (bt_status s = run_plan_entry(p, a, l)) return s;
         if (profile)
             if (bt_status s2 = record()) return s2;
     }
@@ -228,7 +240,16 @@ bt_status release_queue(bt_preprocessor* p) {
     BT_HIP(hipStreamSynchronize(p->ctx->stream));  // borrowed rasters may be released by the caller afterwards
     p->queue.clear();
     for (Raster& r : p->rasters)
-        if (r.owned && r.dev.data) hipFree((void*)r.dev.data);
+        if (r.owned && r.dev.data) {
+            // keep the largest released buffer for the next queue's raster (bt_ctx::spare_raster)
+            if (r.alloc_bytes > p->ctx->spare_raster_bytes) {
+                if (p->ctx->spare_raster) hipFree(p->ctx->spare_raster);
+                p->ctx->spare_raster = (void*)r.dev.data;
+                p->ctx->spare_raster_bytes = r.alloc_bytes;
+            } else {
+                hipFree((void*)r.dev.data);
+            }
+        }
     p->rasters.clear();
     p->jobs = 0;
     p->compiled = false;
@@ -238,7 +259,7 @@ bt_status release_queue(bt_preprocessor* p) {
 }  // namespace bt
 
 extern "C" bt_status bt_preprocessor_profile(bt_preprocessor* p, bt_launch_profile* out, uint32_t cap, uint32_t* count) {
-    if (!p || !count) return BT_ERR_INVALID_ARGUMENT;
+    if (!p || !count || (!out && cap)) return BT_ERR_INVALID_ARGUMENT;
     const uint32_t n = uint32_t(p->plan.size());
     *count = n;
     BT_HIP(hipStreamSynchronize(p->ctx->stream));

@@ -81,7 +81,7 @@ class SphericalDataset:  # preprocessor.rs:29-33
     lod_range: range = range(0, 1)
 
 
-def _raster_struct(raster, fmt: AttachmentFormat, keep: list) -> _ffi.RasterC:
+def _raster_struct(raster, fmt: AttachmentFormat, keep: list, defer_upload: bool = False) -> _ffi.RasterC:
     r = _ffi.RasterC()
     r.format = fmt.id()
     if isinstance(raster, tuple):  # (device_ptr, width, height[, row_pitch])
@@ -107,7 +107,7 @@ def _raster_struct(raster, fmt: AttachmentFormat, keep: list) -> _ffi.RasterC:
     keep.append(a)
     r.data, r.height, r.width = a.ctypes.data, a.shape[0], a.shape[1]
     r.row_pitch = 0
-    r.on_device = 0
+    r.on_device = _ffi.RASTER_HOST_DEFERRED if defer_upload else 0  # deferred: the rows stay ours (kept alive) until the queue has run
     return r
 
 
@@ -136,9 +136,13 @@ class Preprocessor:
         _ffi.check(_ffi.lib().bt_preprocessor_clear_attachment(self._handle(tile_atlas), tile_atlas._h, attachment_index, d))
         return self
 
-    def preprocess_tile(self, dataset: PreprocessDataset, asset_server: AssetServer, tile_atlas: TileAtlas) -> "Preprocessor":
+    def preprocess_tile(self, dataset: PreprocessDataset, asset_server: AssetServer, tile_atlas: TileAtlas, *,
+                        defer_upload: bool = False) -> "Preprocessor":
+        """defer_upload: a host raster is not copied to the GPU by this call but when the queue runs — band by band beside the
+        kernels and the downloads with run_streamed()"""
         fmt = tile_atlas.config.attachments[dataset.attachment_index].format
-        raster = _raster_struct(asset_server.load(dataset.path, fmt) if isinstance(asset_server, AssetServer) else asset_server.load(dataset.path), fmt, self._keep)
+        raster = _raster_struct(asset_server.load(dataset.path, fmt) if isinstance(asset_server, AssetServer) else asset_server.load(dataset.path), fmt, self._keep,
+                                defer_upload)
         d = _ffi.PreprocessDatasetC(dataset.attachment_index, dataset.side, (C.c_float * 2)(*dataset.top_left),
                                     (C.c_float * 2)(*dataset.bottom_right), dataset.lod_range.start, dataset.lod_range.stop)
         _ffi.check(_ffi.lib().bt_preprocessor_preprocess_tile(self._handle(tile_atlas), tile_atlas._h, C.byref(d), C.byref(raster)))
@@ -167,6 +171,16 @@ class Preprocessor:
         if not keep_queue:
             self._keep.clear()
         return self
+
+    def run_streamed(self, tile_atlas: TileAtlas, assets_root: str = "assets", *, generic: bool = False, keep_queue: bool = False) -> dict:
+        """run() + save() as one overlapped pipeline (bt_preprocessor_run_streamed): upload of deferred host rasters, kernels,
+        downloads and file writes at the same time where the plan allows it.  Returns {"streamed": bool, "bands": n}."""
+        st = _ffi.StreamStatsC()
+        flags = (_ffi.RUN_GENERIC if generic else 0) | (_ffi.RUN_KEEP_QUEUE if keep_queue else 0)
+        _ffi.check(_ffi.lib().bt_preprocessor_run_streamed(self._handle(tile_atlas), tile_atlas._h, assets_root.encode(), flags, C.byref(st)))
+        if not keep_queue:
+            self._keep.clear()
+        return {"streamed": bool(st.streamed), "bands": st.bands}
 
     def stats(self) -> Dict[str, int]:
         s = _ffi.RunStatsC()

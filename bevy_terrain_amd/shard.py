@@ -156,6 +156,20 @@ class ShardedPreprocess:
                     broadcast_pieces(self.storage, self.tile_bytes, self._pieces, self.dist)
         self._run(_ffi.RUN_SHARD_FINISH)
 
+    def exchange(self):
+        """Only the exchange of a step (no kernels): the collective-only leg of the bench.  The queue must have run once."""
+        import torch
+
+        self._layout()
+        if self._comm is not None:
+            _ffi.check(_ffi.lib().bt_preprocessor_run_sharded(self.pre._h, self.atlas._h, self._comm, self.flags | _ffi.RUN_SHARD_EXCHANGE))
+            return
+        with torch.cuda.stream(self.stream):
+            if self._ranges:
+                all_gather_ranges(self.storage, self.tile_bytes, self._ranges, self.rank, self.world, self.dist)
+            else:
+                broadcast_pieces(self.storage, self.tile_bytes, self._pieces, self.dist)
+
     def stats(self):
         return self.pre.stats()
 

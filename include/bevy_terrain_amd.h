@@ -94,8 +94,11 @@ typedef struct bt_raster {
     uint64_t row_pitch;  /* bytes; 0 = tightly packed */
     uint32_t format;     /* BT_FORMAT_R16 or BT_FORMAT_RGBA8; must equal the attachment's */
     uint32_t on_device;  /* 0: host memory (copied to the GPU by the call), 1: device pointer (borrowed
-                            until the preprocessor has run) */
+                            until the preprocessor has run), BT_RASTER_HOST_DEFERRED: host memory that stays the
+                            caller's until the queue has run — copied by bt_preprocessor_run (all at once) or by
+                            bt_preprocessor_run_streamed (band by band, beside the kernels and the downloads) */
 } bt_raster;
+#define BT_RASTER_HOST_DEFERRED 2u
 
 /* A decoded source image in host memory, ready to be handed over as a bt_raster (on_device = 0).  Replaces
  * `asset_server.load(path)` + preprocessor_load_tile (preprocessor.rs:240, 401-422; formats/tiff.rs:14-62): a 16-bit
@@ -264,6 +267,8 @@ enum {
                                     * two parent LODs travel (a quarter of the bytes), every rank still ends with every
                                     * lower LOD.  bt_preprocessor_save then writes this rank's share only.  Jobs with more
                                     * than one side (cube seams read neighbour tiles of the finest LOD): BT_ERR_UNSUPPORTED. */
+    BT_RUN_SHARD_EXCHANGE = 64,    /* bt_preprocessor_run_sharded only: issue just the grouped collective of the compiled plan
+                                    * (no kernels) — lets a benchmark time the exchange alone */
 };
 /* Replaces select_ready_tasks + GpuPreprocessor::prepare + TerrainPreprocessNode::run for the whole
  * queue: enqueues every kernel on the context's stream and returns (asynchronous).  Save tasks are
@@ -272,6 +277,17 @@ bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* atlas, uint32_t flag
 /* Executes the pending Save tasks: "{assets_root}/{config.path}/data/{name}/{coord}.bin" and, like
  * select_ready_tasks on completion (:358-371), "{assets_root}/{config.path}/config.tc". */
 bt_status bt_preprocessor_save(bt_preprocessor* p, bt_atlas* atlas, const char* assets_root);
+/* The reference's whole span (preprocessor.rs:363,419: all sources loaded -> all saves done) as one overlapped pipeline:
+ * = bt_preprocessor_run + bt_preprocessor_save, but for a queue whose plan is one fused job over one
+ * BT_RASTER_HOST_DEFERRED raster the source travels to the GPU in bands of tile rows, each band's kernels start when its
+ * rows have landed, and its finished tiles are downloaded and written while later bands upload and run (three HIP queues,
+ * one extra host thread).  Other queues run the legs one after the other.  Files are byte-identical either way.
+ * Synchronous: returns when every file is written.  flags: BT_RUN_GENERIC / BT_RUN_KEEP_QUEUE. */
+typedef struct bt_stream_stats {
+    uint32_t streamed; /* 1: the overlapped pipeline ran; 0: upload, kernels and save ran one after the other */
+    uint32_t bands;
+} bt_stream_stats;
+bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* atlas, const char* assets_root, uint32_t flags, bt_stream_stats* out);
 /* Launch statistics of the last bt_preprocessor_run: kernels launched, algorithmic bytes
  * (source texels read once + tile texels written once), tiles produced. */
 typedef struct bt_run_stats {

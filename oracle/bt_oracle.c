@@ -771,6 +771,92 @@ int orc_run(orc_atlas* a, int threads) {
     return 0;
 }
 
+/* ---- the bench's CPU baseline leg ------------------------------------------------------------------------
+ * Same tasks, same per-pixel functions, same results as orc_run — scheduled for many cores: the units of a phase are
+ * (task, block of `rows_per_block` tile rows) instead of whole tasks, so the top of the pyramid (phases of 64, 16, 4 and 1
+ * tasks) still spreads over the machine, and every pixel is written straight into the atlas (all three kernels only read
+ * texels the phase does not change: split its own previous texel, downsample the children, stitch the centres).
+ * phase_seconds / phase_tasks (cap entries) receive wall time and task count of every phase. */
+#include <time.h>
+static double now_seconds(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void run_task_rows(orc_atlas* a, const task* k, uint32_t y0, uint32_t y1) {
+    attachment* at = &a->att[k->attachment_index];
+    uint32_t T = at->cfg.texture_size, b = at->cfg.border_size, fmt = at->cfg.format;
+    uint8_t* dst = at->data + (size_t)k->atlas_index * T * T * at->pixel_size;
+    for (uint32_t py = y0; py < y1 && py < T; py++)
+        for (uint32_t px = 0; px < T; px++) {
+            vec4 v;
+            if (k->type == TASK_SPLIT) {
+                vec4 prev = atlas_load(a, at, px, py, k->atlas_index);
+                v = split_pixel_value(fmt, T, b, k->coord, k->top_left, k->bottom_right, k->src, k->src_w, k->src_h, px, py, prev);
+            } else if (k->type == TASK_DOWNSAMPLE) {
+                v = downsample_pixel_value(a, at, k, px, py);
+            } else {
+                v = stitch_pixel_value(a, at, k, px, py);
+            }
+            store_pixel(fmt, dst, T, px, py, v);
+        }
+}
+
+int orc_run_blocks(orc_atlas* a, int threads, uint32_t rows_per_block, double* phase_seconds, uint32_t* phase_tasks, uint32_t cap,
+                   uint32_t* n_phases) {
+    if (a->backend || rows_per_block == 0) return -1;
+    if (threads < 1) threads = 1;
+    uint32_t T_max = 1;
+    for (uint32_t i = 0; i < a->n_att; i++)
+        if (a->att[i].cfg.texture_size > T_max) T_max = a->att[i].cfg.texture_size;
+    const long blocks = (long)((T_max + rows_per_block - 1) / rows_per_block);
+    uint32_t phase = 0;
+    size_t i = 0;
+    while (i < a->n_tasks) {
+        size_t j = i;
+        while (j < a->n_tasks && a->tasks[j].type != TASK_BARRIER) j++;
+        const long n = (long)(j - i);
+        uint32_t work = 0;
+        for (long t = 0; t < n; t++) work += a->tasks[i + (size_t)t].type != TASK_SAVE;
+        const double t0 = now_seconds();
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) schedule(dynamic, 1) num_threads(threads) if (threads > 1)
+#endif
+        for (long t = 0; t < n; t++)
+            for (long blk = 0; blk < blocks; blk++) {
+                const task* k = &a->tasks[i + (size_t)t];
+                if (k->type == TASK_SAVE) continue;
+                run_task_rows(a, k, (uint32_t)blk * rows_per_block, ((uint32_t)blk + 1) * rows_per_block);
+            }
+        if (work) {
+            if (phase < cap) {
+                if (phase_seconds) phase_seconds[phase] = now_seconds() - t0;
+                if (phase_tasks) phase_tasks[phase] = work;
+            }
+            phase++;
+        }
+        i = j + 1;
+    }
+    if (n_phases) *n_phases = phase;
+    a->n_tasks = 0;
+    return 0;
+}
+
+/* first touch of every atlas page by the threads that will work on it (the allocation is calloc'ed: untouched pages
+ * would otherwise be faulted in inside the timed region) */
+void orc_atlas_touch(orc_atlas* a, int threads) {
+    if (threads < 1) threads = 1;
+    for (uint32_t i = 0; i < a->n_att; i++) {
+        uint8_t* base = a->att[i].data;
+        const long pages = (long)(((size_t)a->atlas_size * orc_tile_bytes(a, i) + 4095) / 4096);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
+#endif
+        for (long pg = 0; pg < pages; pg++) ((volatile uint8_t*)base)[(size_t)pg * 4096] = 0;
+    }
+}
+
 void orc_split_pixel(uint32_t format, uint32_t T, uint32_t b, orc_coord tile, const float tl[2],
                      const float br[2], const void* src, uint32_t w, uint32_t h, uint32_t px, uint32_t py,
                      const uint32_t prev[4], uint32_t out[4]) {

@@ -84,6 +84,11 @@ int orc_preprocess_spherical(orc_atlas* a, uint32_t attachment_index, uint32_t l
  * threads<=1 -> scalar, else OpenMP over the tasks between two barriers. */
 int orc_run(orc_atlas* a, int threads);
 uint32_t orc_task_count(const orc_atlas* a, uint32_t counts[5]);
+/* The bench's CPU-baseline schedule of the same queue (identical results): units = (task, block of rows), in-place stores,
+ * wall time and task count per phase.  orc_atlas_touch first-touches the atlas pages outside the timed region. */
+int orc_run_blocks(orc_atlas* a, int threads, uint32_t rows_per_block, double* phase_seconds, uint32_t* phase_tasks, uint32_t cap,
+                   uint32_t* n_phases);
+void orc_atlas_touch(orc_atlas* a, int threads);
 
 uint32_t orc_tile_count(const orc_atlas* a); /* existing_tiles.len() */
 /* existing tiles in atlas-index order + their atlas indices */

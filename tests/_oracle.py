@@ -84,6 +84,25 @@ class TreeEntry(C.Structure):
     _fields_ = [("atlas_index", C.c_uint32), ("atlas_lod", C.c_uint32)]
 
 
+def usable_cores() -> int:
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (a container sees all 256 hardware
+    threads of the GPU box in os.cpu_count() but is throttled to its quota — more threads than that only buy stalls)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())  # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def build(force: bool = False) -> str:
     sources = [os.path.join(ORACLE_DIR, n) for n in ("bt_oracle.c", "bt_oracle_tree.c", "bt_oracle.h", "Makefile")]
     stale = not os.path.exists(_LIB_PATH) or any(

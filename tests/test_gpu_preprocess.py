@@ -222,7 +222,7 @@ def test_config5_cube_8k_faces_full_size(device):
     pre.run(atlas)
     assert pre.stats()["fused_jobs"] >= 1 and pre.stats()["tiles"] == 2046
     oracle = K.reference_kernels(O.OracleAtlas(lods, 2048, True, [(512, 2, 1, O.FORMAT_R16)]))  # the reference's WGSL, executed
-    oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(os.cpu_count() or 8)
+    oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(O.usable_cores())
     assert [((c.side, c.lod, c.x, c.y), i) for c, i in atlas.tiles()] == oracle.tiles()
     for first in range(0, 2046, 128):
         count = min(128, 2046 - first)
@@ -404,7 +404,7 @@ def test_config3_16k_single_gpu_all_tiles(device, masked):
     st = pre.stats()
     assert st["fused_jobs"] == 1 and st["tiles"] == 1365 and st["algorithmic_bytes"] == 1252524032
     oracle = K.reference_kernels(O.OracleAtlas(lods, 2048, False, [(512, 2, 1, O.FORMAT_R16)]))  # the reference's WGSL, executed
-    oracle.clear_attachment(0).preprocess_tile(0, src, (0, lods)).run(os.cpu_count() or 8)
+    oracle.clear_attachment(0).preprocess_tile(0, src, (0, lods)).run(O.usable_cores())
     assert [((c.side, c.lod, c.x, c.y), i) for c, i in atlas.tiles()] == oracle.tiles()
     for first in range(0, 1365, 128):
         count = min(128, 1365 - first)
@@ -570,3 +570,61 @@ def test_direct_rgba8_several_row_blocks_per_workgroup(device, T, b, lod_count, 
     atlas, pre = K.product_planar(device, src, lod_count, T, b, O.FORMAT_RGBA8, atlas_size=2048)
     assert pre.stats()["fused_jobs"] == 1
     assert K.assert_atlas_equal(atlas, K.oracle_planar(src, lod_count, T, b, O.FORMAT_RGBA8, atlas_size=2048)) == tiles
+
+
+@pytest.mark.parametrize("holes", [False, True])
+def test_streamed_run_writes_the_same_files(device, tmp_path, holes):
+    """bt_preprocessor_run_streamed (upload in bands of tile rows || kernels || download + file writes) against run() + save()
+    of the same job, file by file, and against the oracle's atlas: 8192^2 R16, lod_count 5 -> 256 finest tiles in 4 bands of 4
+    tile rows; with no-data patches (fused_todo runs band by band) and without."""
+    size, lods = 8192, 5
+    src = K.smooth_raster(size, size, seed=91, device=device)
+    if holes:
+        src[700:900, 3000:3400] = 0
+        src[2040:2056, 100:8000] = 0  # across a band seam (tile rows 3 | 4)
+        src[8000:8192, 8100:8192] = 0
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=512, path="terrains/streamed", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=512, border_size=2, format=bt.AttachmentFormat.R16))
+    roots = []
+    for streamed in (False, True):
+        root = str(tmp_path / ("streamed" if streamed else "serial"))
+        atlas = bt.TileAtlas.new(cfg, device)
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas, root)
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="src", lod_range=range(0, lods)), bt.AssetServer().insert("src", src), atlas,
+                            defer_upload=streamed)
+        if streamed:
+            st = pre.run_streamed(atlas, root)
+            assert st == {"streamed": True, "bands": 4}
+        else:
+            pre.run(atlas)
+            pre.save(atlas, root)
+        roots.append((root, atlas))
+    d0, d1 = (a.attachment_directory(r, 0) for r, a in roots)
+    names = sorted(os.listdir(d0))
+    assert names == sorted(os.listdir(d1)) and len(names) == 341
+    for n in names:
+        assert open(os.path.join(d0, n), "rb").read() == open(os.path.join(d1, n), "rb").read(), n
+    assert open(os.path.join(roots[0][0], "terrains/streamed/config.tc"), "rb").read() == open(os.path.join(roots[1][0], "terrains/streamed/config.tc"), "rb").read()
+    oracle = O.OracleAtlas(lods, 512, False, [(512, 2, 1, O.FORMAT_R16)])
+    oracle.clear_attachment(0).preprocess_tile(0, src, (0, lods)).run(O.usable_cores())
+    assert K.assert_atlas_equal(roots[1][1], oracle) == 341
+
+
+def test_streamed_run_falls_back_for_queues_it_cannot_band(device, tmp_path):
+    """a device-resident raster, a generic-plan job and a cube job are not streamable: the same call still runs and saves"""
+    src = K.random_raster(O.FORMAT_R16, 300, 300, seed=93, holes=0.05)
+    cfg = bt.TerrainConfig(lod_count=3, atlas_size=64, path="terrains/fallback", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=64, border_size=2, format=bt.AttachmentFormat.R16))
+    for generic, defer in ((False, False), (True, True), (False, True)):
+        root = str(tmp_path / f"r{int(generic)}{int(defer)}")
+        atlas = bt.TileAtlas.new(cfg, device)
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas, root)
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="src", lod_range=range(0, 3)), bt.AssetServer().insert("src", src), atlas, defer_upload=defer)
+        st = pre.run_streamed(atlas, root, generic=generic)
+        assert st["streamed"] in (False, True)
+        files = os.listdir(atlas.attachment_directory(root, 0))
+        assert len(files) == 21
+        oracle = K.oracle_planar(src, 3, 64, 2, O.FORMAT_R16)
+        for c, i in oracle.tiles():
+            data = np.fromfile(os.path.join(atlas.attachment_directory(root, 0), f"{c[0]}_{c[1]}_{c[2]}_{c[3]}.bin"), dtype=np.uint16).reshape(64, 64)
+            assert np.array_equal(data, oracle.tile(0, i)), c

@@ -182,3 +182,41 @@ def test_sample_tile_known_answers():
     rgba[...] = (255, 128, 1, 77)
     s = O.sample_tile(O.FORMAT_RGBA8, b, rgba, (0.3, 0.9))
     assert np.array_equal(s, (np.array([255, 128, 1, 77], dtype=np.float32) / np.float32(255)).astype(np.float32))
+
+
+def test_block_schedule_and_native_build_give_the_same_bytes(tmp_path):
+    """bench.py's CPU-baseline leg runs the oracle with another schedule (units = (task, 32-row block), in-place stores:
+    orc_run_blocks) and another build (-O3 -march=native, still -ffp-contract=off): neither may change one byte"""
+    import ctypes as C
+    import os
+    import subprocess
+
+    src = np.random.default_rng(5).integers(0, 65536, size=(300, 280), dtype=np.uint16)
+    src[src < 3000] = 0
+    ref = run_planar(src, 4, 32, 2, O.FORMAT_R16)
+    native = os.path.join(O.ORACLE_DIR, "libbt_oracle_native.so")
+    subprocess.check_call(["make", "-C", O.ORACLE_DIR, "-s", "-B", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for path in (O._LIB_PATH, native):
+        L = C.CDLL(path)
+        vp, u32 = C.c_void_p, C.c_uint32
+        L.orc_atlas_new.argtypes = [u32, u32, C.c_int, u32, C.POINTER(O.AttachmentConfig)]
+        L.orc_atlas_new.restype = vp
+        L.orc_preprocess_tile.argtypes = [vp, C.POINTER(O.Dataset), vp, u32, u32]
+        L.orc_run_blocks.argtypes = [vp, C.c_int, u32, C.POINTER(C.c_double), C.POINTER(u32), u32, C.POINTER(u32)]
+        L.orc_atlas_touch.argtypes = [vp, C.c_int]
+        L.orc_tile_data.argtypes = [vp, u32, u32]
+        L.orc_tile_data.restype = vp
+        L.orc_atlas_free.argtypes = [vp]
+        for threads, rows in ((1, 32), (4, 7), (3, 64)):
+            cfg = (O.AttachmentConfig * 1)(O.AttachmentConfig(32, 2, 1, O.FORMAT_R16))
+            h = L.orc_atlas_new(4, 128, 0, 1, cfg)
+            d = O.Dataset(0, 0, (C.c_float * 2)(0.0, 0.0), (C.c_float * 2)(1.0, 1.0), 0, 4)
+            assert L.orc_preprocess_tile(h, C.byref(d), src.ctypes.data, src.shape[1], src.shape[0]) == 0
+            L.orc_atlas_touch(h, threads)
+            secs, tasks, n = (C.c_double * 16)(), (u32 * 16)(), u32()
+            assert L.orc_run_blocks(h, threads, rows, secs, tasks, 16, C.byref(n)) == 0
+            assert [tasks[i] for i in range(n.value)] == [64, 16, 4, 1, 1, 4, 16, 64]  # split, 3 x downsample, 4 x stitch
+            for coord, idx in ref.tiles():
+                got = np.frombuffer((C.c_uint8 * 2048).from_address(L.orc_tile_data(h, 0, idx)), dtype=np.uint16).reshape(32, 32)
+                assert np.array_equal(got, ref.tile(0, idx)), (path, threads, rows, coord)
+            L.orc_atlas_free(h)

@@ -84,7 +84,7 @@ def test_config2_product_vs_8bit_sampler():
     for name, src, fmt in (("height", height, O.FORMAT_R16), ("albedo", albedo, O.FORMAT_RGBA8)):
         atlas, _ = K.product_planar(device, src, 4, 512, 2, fmt, atlas_size=128)
         with O.sampler_model(8, 0):
-            snapped = K.oracle_planar(src, 4, 512, 2, fmt, atlas_size=128, threads=os.cpu_count() or 8)
+            snapped = K.oracle_planar(src, 4, 512, 2, fmt, atlas_size=128, threads=O.usable_cores())
         ours = atlas.download_tiles(0, 0, 85)
         diffs = per_lod_max_diff(snapped.tiles(), lambda i: ours[i], lambda i: snapped.tile(0, i))
         contrast = adjacent_contrast(src)
@@ -103,7 +103,7 @@ def test_config3_product_vs_8bit_sampler():
     src = K.smooth_raster(16384, 16384, seed=42, device=device)
     atlas, _ = K.product_planar(device, src, 6, 512, 2, O.FORMAT_R16, atlas_size=2048)
     with O.sampler_model(8, 0):
-        snapped = K.oracle_planar(src, 6, 512, 2, O.FORMAT_R16, atlas_size=2048, threads=os.cpu_count() or 8)
+        snapped = K.oracle_planar(src, 6, 512, 2, O.FORMAT_R16, atlas_size=2048, threads=O.usable_cores())
     diffs = {}
     tiles = snapped.tiles()
     for first in range(0, 1365, 128):

@@ -173,26 +173,35 @@ def test_nccl_single_rank_group_runs_the_sharded_step():
 @pytest.mark.gpu
 @pytest.mark.parametrize("result,held_tiles", [("replicated", 1365), ("distributed", 512 + 341)])
 def test_bench_two_ranks_end_to_end_on_one_gpu(result, held_tiles):
-    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), except that both
-    ranks share GPU 0 and the collective is gloo (RCCL refuses two ranks on one device): every rank preprocesses its
+    """`python bench.py --gpus 2` — the plain command, which re-executes itself under torch.distributed.run (one process per
+    rank) — except that both ranks share GPU 0 and the collective is gloo (RCCL refuses two ranks on one device): every rank preprocesses its
     column strip of the 16k job, the in-place all-gathers assemble the atlas, and rank 0's atlas must equal the
     oracle's for all 1365 tiles."""
     import json
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BT_BENCH_BACKEND="gloo", BT_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--spinup-ms", "20", "--verify", "--result", result]
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(BT_BENCH_BACKEND="gloo", BT_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    # the PLAIN command (no torch.distributed.run in front): bench.py starts its two ranks itself
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup-ms", "20", "--verify", "--result", result]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["collective_backend"] == "gloo"
+    assert line["config"]["ranks_seen"] == 2 and line["config"]["jobs_in_flight"] == 1
     # replicated: rank 0 ends with all 1365 tiles; distributed: with its half of the 1024 finest tiles + the 341 below
     assert line["verify_vs_oracle"] == {"tiles": held_tiles, "identical": held_tiles, "index_contract": True}
     assert line["config"]["result"].startswith(result)
     assert "cpu_baseline" not in line
+    # the extras of the same run: kernels alone, the exchange alone, the other result mode
+    cfg = line["config"]
+    assert cfg["kernels_only_ms_per_step"] > 0 and cfg["collective_only_ms_per_step"] > 0
+    other = cfg["other_result_mode"]
+    assert other["result"] == ("distributed" if result == "replicated" else "replicated") and other["ms_per_step"] > 0
+    full, quarter = 1024 * 524288 + 256 * 524288 + 64 * 524288, 256 * 524288 + 64 * 524288
+    assert cfg["all_gather_bytes_per_rank"] == (full if result == "replicated" else quarter)
+    assert other["all_gather_bytes_per_rank"] == (quarter if result == "replicated" else full)
 
 
 def _unit_pieces(tiles, sides, lod_hi, world):
@@ -340,7 +349,7 @@ def test_cube_job_sharded_over_emulated_ranks(world):
         return atlas, pre
 
     oracle = O.OracleAtlas(lods, 2048, True, [(T, b, 1, O.FORMAT_R16)])
-    oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(os.cpu_count() or 8)
+    oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(O.usable_cores())
     pieces = _emulate_ranks(device, world, make_job, 2046, oracle, lods - 1, T, b, sides=6)
     assert pieces == [dict(p, attachment_index=0) for p in _unit_pieces(oracle.tiles(), 6, lods - 1, world)]
     assert len({p["owner_rank"] for p in pieces}) == world
@@ -414,10 +423,10 @@ def test_random_jobs_sharded_over_emulated_ranks(seed):
         faces = [K.random_raster(fmt, W, W, seed=300 + 10 * seed + s, holes=holes) for s in range(6)]
         paths = [f"face{s}" for s in range(6)]
         oracle = O.OracleAtlas(lods, size, True, [(T, b, 1, fmt)])
-        oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(os.cpu_count() or 8)
+        oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(O.usable_cores())
     else:
         src = K.random_raster(fmt, W, W + 7, seed=300 + seed, holes=holes)
-        oracle = K.oracle_planar(src, lods, T, b, fmt, atlas_size=size, threads=os.cpu_count() or 8)
+        oracle = K.oracle_planar(src, lods, T, b, fmt, atlas_size=size, threads=O.usable_cores())
 
     def make_job():
         cfg = bt.TerrainConfig(lod_count=lods, atlas_size=size, path="terrains/sweep",
