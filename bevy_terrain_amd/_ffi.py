@@ -186,6 +186,7 @@ PROTOTYPES = {
     "bt_tiling_prepass_create": (_i32, [_vp, _u32, _P(_vp)]),
     "bt_tiling_prepass_destroy": (None, [_vp]),
     "bt_tiling_prepass_run": (_i32, [_vp, _P(ViewStateC)]),
+    "bt_tiling_prepass_run_plain": (_i32, [_vp, _P(ViewStateC)]),
     "bt_tiling_prepass_buffers": (_i32, [_vp, _P(_vp), _P(_vp)]),
     "bt_tiling_prepass_read": (_i32, [_vp, _P(TileCoordinateC), _u32, _P(_u32), _P(IndirectC)]),
     "bt_terrain_view_config_default": (None, [_P(TerrainViewConfigC)]),

@@ -24,6 +24,7 @@ struct bt_tiling_prepass {
     bt_tile_coordinate* final_tiles = nullptr;
     bt_indirect* indirect = nullptr;
     uint32_t* counters = nullptr;  // [0] final count, [1] overflow flag, [2] tiles visited, [3] passes
+    unsigned long long* bits = nullptr;  // divide bits of every (side, lod) window (allocated on first use)
 };
 
 namespace bt {
@@ -121,11 +122,65 @@ __device__ bool should_be_divided(const bt_view_state& v, const bt_tile_coordina
     return view_distance < v.subdivision_distance * inv_tc;
 }
 
+// ---- the divide test of every tile that can matter, computed up front ------------------------------------------------
+// The schedule is a chain of up to refinement_count + 1 dependent passes, and a pass of the single-workgroup kernel costs
+// ~2.5 us of pure latency: tile load (L2) -> ~200 dependent VALU instructions of should_be_divided -> ballot / scan /
+// barrier.  But should_be_divided(tile) depends on the tile and the view alone, not on the pass: so a first launch
+// evaluates it SPECULATIVELY for every tile inside a (2K+1)^2 window around the view's tile at every LOD of every side
+// (tiles only divide close to the view: the criterion scales with the tile size) — ~1.3 k workgroups, one evaluation per
+// thread, all independent — and leaves one bit per tile.  The ordered kernel then reads bits (from LDS) instead of running
+// the arithmetic, keeps its frontier in LDS while it fits, and a pass shrinks to a few hundred nanoseconds.  A tile outside
+// its window (possible, rare) is evaluated in place with the same function: the result is the same list in the same order.
+constexpr int kWinK = 28;  // window radius in tiles: tiles DIVIDE within ~10 tiles of the view, so tiles EXIST within ~2 x 10 + 2 (more under the cube-sphere warp)
+constexpr uint32_t kWinW = 2 * kWinK + 1, kWinBits = kWinW * kWinW;
+constexpr uint32_t kWinChunks = (kWinBits + 255) / 256;      // 256-thread workgroups per (side, lod)
+constexpr uint32_t kWinWords = kWinChunks * 4;               // 64-bit words per (side, lod): one per wave
+constexpr uint32_t kMaxLods = 32;
+constexpr uint32_t kFrontierCap = 2048;                      // tiles of a pass kept in LDS
+
+// first tile (x, y) of the window of (side, lod): centred on the view's tile of that LOD, clamped into the face
+__device__ __forceinline__ void window_origin(const bt_view_state& v, uint32_t side, uint32_t lod, int& ox, int& oy) {
+    Coordinate vc{side, v.origin_lod, uint32_t(v.sides[side].view_xy[0]), uint32_t(v.sides[side].view_xy[1]), v.sides[side].view_uv[0], v.sides[side].view_uv[1]};
+    coordinate_change_lod(vc, lod);
+    const int last = int((1u << lod) - 1u);  // lod <= 31
+    const int cx = min(max(int(vc.x), 0), last), cy = min(max(int(vc.y), 0), last);
+    ox = cx - kWinK;
+    oy = cy - kWinK;
+}
+
+// lods: LODs 0 .. lods - 1 get their bits (the host's estimate of how deep this view can refine; anything deeper is
+// evaluated in place by the ordered kernel — an estimate can only cost time, never change the result)
+__global__ __launch_bounds__(256) void tiling_divide_bits_kernel(bt_view_state view, uint32_t lods, unsigned long long* __restrict__ bits) {
+    const uint32_t chunk = blockIdx.x % kWinChunks, lod = (blockIdx.x / kWinChunks) % lods, side = blockIdx.x / (kWinChunks * lods);
+    if (lod > view.refinement_count) return;
+    int ox, oy;
+    window_origin(view, side, lod, ox, oy);
+    const uint32_t b = chunk * 256u + threadIdx.x;
+    const int tx = ox + int(b % kWinW), ty = oy + int(b / kWinW), last = int((1u << lod) - 1u);
+    bool divide = false;
+    if (b < kWinBits && tx >= 0 && ty >= 0 && tx <= last && ty <= last) divide = should_be_divided(view, bt_tile_coordinate{side, lod, uint32_t(tx), uint32_t(ty)});
+    const unsigned long long word = __ballot(divide);
+    if ((threadIdx.x & 63u) == 0) bits[(size_t(side) * kMaxLods + lod) * kWinWords + chunk * 4u + (threadIdx.x >> 6)] = word;
+}
+
+// kAssist = false: the whole schedule from the arithmetic alone (the plain kernel: checker, and fallback for odd views).
+// kAssist = true: `bits` holds tiling_divide_bits_kernel's answers; dynamic LDS = bits of every (side, lod) + the origin
+// table + two frontier buffers.
+// __syncthreads() also drains the wave's global stores (one memory counter): with the frontier in LDS nothing a pass stores to
+// global memory is read back inside the kernel, so its barriers only have to order LDS — the store latency (~1.5 us per
+// barrier) then stays off the chain of passes
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <bool kAssist>
 __global__ __launch_bounds__(kThreads) void tiling_prepass_kernel(bt_view_state view, uint32_t capacity,
                                                                   bt_tile_coordinate* __restrict__ temporary_tiles,
                                                                   bt_tile_coordinate* __restrict__ final_tiles,
                                                                   bt_indirect* __restrict__ indirect,
-                                                                  uint32_t* __restrict__ counters) {
+                                                                  uint32_t* __restrict__ counters, const unsigned long long* __restrict__ bits, uint32_t assist_lods) {
     // The pass state (Parameters, types.wgsl:43-48) is uniform and kept in registers by every thread; only the
     // per-wave counts of a sweep go through LDS (double-buffered by sweep parity: ONE barrier per sweep).
     __shared__ uint32_t s_divide[2][kWaves], s_final[2][kWaves];
@@ -138,9 +193,27 @@ __global__ __launch_bounds__(kThreads) void tiling_prepass_kernel(bt_view_state 
     uint32_t tile_count = view.spherical ? 6u : 1u, visited = 0, sweep = 0;
     bool overflow = false;
     if (tid < tile_count) temporary_tiles[tid] = {tid, 0u, 0u, 0u};
+    // kAssist: the answers of every window, the window origins and the LDS frontier
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    const uint32_t sides = view.spherical ? 6u : 1u;
+    unsigned long long* s_bits = reinterpret_cast<unsigned long long*>(s_dyn);
+    int2* s_origin = reinterpret_cast<int2*>(s_bits + size_t(sides) * kMaxLods * kWinWords);
+    bt_tile_coordinate* s_tiles = reinterpret_cast<bt_tile_coordinate*>(s_origin + sides * kMaxLods);  // [2][kFrontierCap]
+    if constexpr (kAssist) {
+        for (uint32_t i = tid; i < sides * kMaxLods * kWinWords; i += kThreads)
+            if ((i / kWinWords) % kMaxLods < assist_lods) s_bits[i] = bits[i];
+        if (tid < sides * kMaxLods) {
+            int ox, oy;
+            window_origin(view, tid / kMaxLods, tid % kMaxLods, ox, oy);
+            s_origin[tid] = int2{ox, oy};
+        }
+        if (tid < tile_count) s_tiles[tid] = {tid, 0u, 0u, 0u};
+    }
     __syncthreads();
 
     for (uint32_t pass = 0; pass <= view.refinement_count; pass++) {
+        const bool from_lds = kAssist && tile_count <= kFrontierCap;  // this pass's parents all sit in s_tiles[pass & 1]
+        uint32_t pass_children = 0;                                    // children appended so far in this pass
         // refine_tiles (refine_tiles.wgsl:33-44), 1024 invocation ids per sweep
         for (uint32_t base = 0; base < tile_count; base += kThreads, sweep++) {
             const uint32_t id = base + tid;
@@ -149,8 +222,19 @@ __global__ __launch_bounds__(kThreads) void tiling_prepass_kernel(bt_view_state 
             bool divide = false;
             if (active) {
                 const int parent_index = (N - 1) * (counter > 0 ? 1 : 0) - int(id) * counter;  // :9-11
-                tile = temporary_tiles[parent_index];
-                divide = should_be_divided(view, tile);
+                tile = from_lds ? s_tiles[(pass & 1u) * kFrontierCap + id] : temporary_tiles[parent_index];
+                if constexpr (kAssist) {
+                    const int2 o = s_origin[tile.side * kMaxLods + tile.lod];
+                    const int bx = int(tile.x) - o.x, by = int(tile.y) - o.y;
+                    if (bx >= 0 && by >= 0 && bx < int(kWinW) && by < int(kWinW) && tile.lod < assist_lods) {
+                        const uint32_t b = uint32_t(by) * kWinW + uint32_t(bx);
+                        divide = (s_bits[(tile.side * kMaxLods + tile.lod) * kWinWords + (b >> 6)] >> (b & 63u)) & 1ull;
+                    } else {
+                        divide = should_be_divided(view, tile);  // outside its window: the same function, in place
+                    }
+                } else {
+                    divide = should_be_divided(view, tile);
+                }
             }
             const bool fin = active && !divide;
             const unsigned long long ballot_d = __ballot(divide), ballot_f = __ballot(fin);
@@ -158,7 +242,8 @@ __global__ __launch_bounds__(kThreads) void tiling_prepass_kernel(bt_view_state 
                 s_divide[sweep & 1u][wave] = uint32_t(__popcll(ballot_d));
                 s_final[sweep & 1u][wave] = uint32_t(__popcll(ballot_f));
             }
-            __syncthreads();
+            if constexpr (kAssist) lds_barrier();  // (the counts are LDS; this pass reads no global data it wrote)
+            else __syncthreads();
             uint32_t before_d = 0, before_f = 0, total_d = 0, total_f = 0;
 #pragma unroll
             for (uint32_t w = 0; w < kWaves; w++) {
@@ -174,14 +259,19 @@ __global__ __launch_bounds__(kThreads) void tiling_prepass_kernel(bt_view_state 
 #pragma unroll
                 for (uint32_t i = 0; i < 4; i++) {
                     const int ci = child_index + counter * (4 * rank + int(i));
-                    if (ci >= 0 && ci < N)
-                        temporary_tiles[ci] = {tile.side, tile.lod + 1u, (tile.x << 1) + (i & 1u), (tile.y << 1) + ((i >> 1) & 1u)};
+                    const bt_tile_coordinate child = {tile.side, tile.lod + 1u, (tile.x << 1) + (i & 1u), (tile.y << 1) + ((i >> 1) & 1u)};
+                    if (ci >= 0 && ci < N) temporary_tiles[ci] = child;
+                    if constexpr (kAssist) {  // the same order (append order = the next pass's id order)
+                        const uint32_t li = pass_children + 4u * uint32_t(rank) + i;
+                        if (li < kFrontierCap) s_tiles[((pass + 1u) & 1u) * kFrontierCap + li] = child;
+                    }
                 }
             }
             if (fin) {
                 const int fi = final_index + int(before_f + uint32_t(__popcll(ballot_f & below)));
                 if (fi < N) final_tiles[fi] = tile;
             }
+            pass_children += 4u * total_d;
             child_index += counter * 4 * int(total_d);
             final_index += int(total_f);
             visited += min(kThreads, tile_count - base);
@@ -201,7 +291,9 @@ __global__ __launch_bounds__(kThreads) void tiling_prepass_kernel(bt_view_state 
         }
         counter = -counter;
         if (tile_count == 0) break;  // nothing left to refine: the remaining passes of the reference are no-ops
-        __syncthreads();  // orders this pass's child stores before the next pass's parent loads
+        // orders this pass's child stores before the next pass's parent loads: LDS when the next pass reads its parents there
+        if (kAssist && tile_count <= kFrontierCap) lds_barrier();
+        else __syncthreads();
     }
 
     // prepare_render (prepare_prepass.wgsl:38-44)
@@ -248,6 +340,7 @@ void bt_tiling_prepass_destroy(bt_tiling_prepass* t) {
     if (t->final_tiles) hipFree(t->final_tiles);
     if (t->indirect) hipFree(t->indirect);
     if (t->counters) hipFree(t->counters);
+    if (t->bits) hipFree(t->bits);
     delete t;
 }
 
@@ -260,8 +353,54 @@ bt_status bt_tiling_prepass_run(bt_tiling_prepass* t, const bt_view_state* view)
     if (view->origin_lod > 31) return BT_ERR_INVALID_ARGUMENT;
     BT_HIP(hipSetDevice(t->ctx->device));
     const uint32_t capacity = std::min(t->capacity, view->geometry_tile_count ? view->geometry_tile_count : t->capacity);
-    tiling_prepass_kernel<<<1, kThreads, 0, t->ctx->stream>>>(*view, capacity, t->temporary_tiles, t->final_tiles, t->indirect,
-                                                               t->counters);
+    const uint32_t sides = view->spherical ? 6u : 1u;
+    const size_t lds = size_t(sides) * kMaxLods * (kWinWords * sizeof(unsigned long long) + sizeof(int2)) + 2 * size_t(kFrontierCap) * sizeof(bt_tile_coordinate);
+    if (!t->bits) {
+        BT_HIP(hipMalloc((void**)&t->bits, 6 * size_t(kMaxLods) * kWinWords * sizeof(unsigned long long)));
+        BT_HIP(hipMemsetAsync(t->bits, 0, 6 * size_t(kMaxLods) * kWinWords * sizeof(unsigned long long), t->ctx->stream));
+        BT_HIP(hipFuncSetAttribute((const void*)tiling_prepass_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, int(6 * kMaxLods * (kWinWords * 8 + 8) + 2 * kFrontierCap * 16)));
+    }
+    // How deep can this view refine?  A tile of LOD l divides only within subdivision_distance / 2^l of the view, and nothing is
+    // closer to the view than its height over the (approximate) surface: beyond l = log2(subdivision_distance / height) no tile
+    // divides.  An ESTIMATE (f32 on the host, the surface taken as the unit sphere / plane of the mesh transform): it only
+    // decides how many LODs get their bits up front and whether the two-launch form pays at all — shallow views (few
+    // hundred tiles) are faster in the plain kernel, which saves them the second launch.
+    uint32_t lods = kMaxLods;
+    {
+        const float* m = view->world_from_local;
+        const float* it = view->local_from_world_transpose;
+        const float d[3] = {view->world_position[0] - m[9], view->world_position[1] - m[10], view->world_position[2] - m[11]};
+        float local[3];
+        for (int i = 0; i < 3; i++) local[i] = it[3 * i] * d[0] + it[3 * i + 1] * d[1] + it[3 * i + 2] * d[2];
+        const float sx = sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]), sy = sqrtf(m[3] * m[3] + m[4] * m[4] + m[5] * m[5]);
+        const float height = view->spherical ? (sqrtf(local[0] * local[0] + local[1] * local[1] + local[2] * local[2]) - 1.0f) * std::min(sx, sy) : local[1] * sy;
+        const float clearance = 0.5f * fabsf(height - view->approximate_height);
+        if (clearance > 0.0f && view->subdivision_distance > 0.0f && std::isfinite(clearance)) {
+            const float deepest = log2f(view->subdivision_distance / clearance);
+            if (deepest < 30.0f) lods = uint32_t(std::max(0.0f, ceilf(deepest))) + 2u;
+        }
+        lods = std::min(std::min(lods, kMaxLods), view->refinement_count + 1u);
+    }
+    if (lods < 12u) return bt_tiling_prepass_run_plain(t, view);
+    // launch 1: every divide test that can matter (independent, chip-wide); launch 2: the ordered schedule over the bits
+    tiling_divide_bits_kernel<<<sides * lods * kWinChunks, 256, 0, t->ctx->stream>>>(*view, lods, t->bits);
+    tiling_prepass_kernel<true><<<1, kThreads, lds, t->ctx->stream>>>(*view, capacity, t->temporary_tiles, t->final_tiles, t->indirect, t->counters, t->bits, lods);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "tiling_prepass_kernel");
+    return BT_OK;
+}
+
+// The plain form: one launch, every divide test evaluated inside the pass that needs it.  Same list, same order; kept as the
+// checker of the two-launch form above (tests) and for hosts that want a single kernel.
+bt_status bt_tiling_prepass_run_plain(bt_tiling_prepass* t, const bt_view_state* view) {
+    if (!t || !view) return BT_ERR_INVALID_ARGUMENT;
+    if (view->refinement_count > 31 || view->origin_lod > 31) {
+        set_error("refinement_count %u / origin_lod %u > 31 (tile x/y are u32)", view->refinement_count, view->origin_lod);
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    BT_HIP(hipSetDevice(t->ctx->device));
+    const uint32_t capacity = std::min(t->capacity, view->geometry_tile_count ? view->geometry_tile_count : t->capacity);
+    tiling_prepass_kernel<false><<<1, kThreads, 0, t->ctx->stream>>>(*view, capacity, t->temporary_tiles, t->final_tiles, t->indirect, t->counters, nullptr, 0u);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "tiling_prepass_kernel");
     return BT_OK;

@@ -388,8 +388,14 @@ typedef struct bt_indirect {
 bt_status bt_tiling_prepass_create(bt_ctx* ctx, uint32_t geometry_tile_count, bt_tiling_prepass** out);
 void bt_tiling_prepass_destroy(bt_tiling_prepass* t);
 /* TilingPrepassNode::run (:204-272): prepare_root, refinement_count x (refine_tiles, prepare_next),
- * refine_tiles, prepare_render — as ONE persistent launch.  Asynchronous on the context's stream. */
+ * refine_tiles, prepare_render — as one persistent launch behind one chip-wide launch that precomputes the divide tests
+ * (see bt_tiling_prepass_run_plain).  Asynchronous on the context's stream. */
 bt_status bt_tiling_prepass_run(bt_tiling_prepass* t, const bt_view_state* view);
+/* bt_tiling_prepass_run is two launches: every divide test that can matter is evaluated up front, chip-wide (a window of
+ * tiles around the view at every LOD and side; the test depends on tile and view only), then the ordered schedule runs over
+ * those bits out of LDS.  This is the single-launch form that evaluates each test inside its pass: the same list in the
+ * same order, ~3x the worst-case latency; the checker of the two-launch form. */
+bt_status bt_tiling_prepass_run_plain(bt_tiling_prepass* t, const bt_view_state* view);
 /* Device buffers a renderer binds: final_tiles (bt_tile_coordinate[]), indirect args, counters. */
 bt_status bt_tiling_prepass_buffers(const bt_tiling_prepass* t, void** final_tiles_device, void** indirect_device);
 /* Synchronises and copies the final tile list (in the reference's sequential append order). */

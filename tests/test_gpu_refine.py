@@ -127,3 +127,43 @@ def test_random_views_equal_the_oracle_list(device, seed):
         if len(ours) < 3000:
             final, dropped, _ = R.refine(v)
             assert np.array_equal(ours, final) or len(dropped) > 0, (seed, frame)
+
+
+@pytest.mark.parametrize("kind", ["planar", "sphere", "ellipsoid"])
+def test_two_launch_form_equals_the_plain_kernel_and_the_oracle(device, kind):
+    """bt_tiling_prepass_run (divide bits of every window up front, then the ordered schedule out of LDS) against
+    bt_tiling_prepass_run_plain (every test evaluated inside its pass) and the oracle: the same LIST in the same order, the same
+    indirect args — from far out (a handful of tiles) to 17 k tiles, cameras over face edges and cube corners, views whose
+    tiles leave their windows (huge subdivision tolerance), and small LDS-overflowing / LDS-resident passes"""
+    if kind == "planar":
+        model = bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 250.0)
+        positions = list(spiral(20, 700.0, 900.0, 20.0)) + [(3.0, 260.0, -7.0), (5000.0, 10000.0, 0.0), (-499.9, 1.0, 499.9), (2000.0, 5.0, 0.0)]
+    else:
+        model = (bt.TerrainModel.sphere((0.0, 0.0, 0.0), 6371000.0, -12000.0, 9000.0) if kind == "sphere"
+                 else bt.TerrainModel.ellipsoid((10.0, -20.0, 30.0), 6378137.0, 6356752.314245, -12000.0, 9000.0))
+        positions = []
+        rng = np.random.default_rng(8)
+        for k in range(16):
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            positions.append(tuple(d * (6371000.0 + 10 ** rng.uniform(1.5, 7.2))))
+        r = 6371000.0 + 500.0
+        positions += [(r / math.sqrt(3),) * 3, (r / math.sqrt(2), r / math.sqrt(2), 0.0), (0.0, r, 0.0), (-r, 30.0, -40.0)]  # corner, edge, face centres
+    total = outside_hits = 0
+    for tolerance, cfg_tiles in ((0.1, 400000), (3.0, 900000)):  # tolerance 3: tiles divide up to ~35 tiles from the view — beyond the windows
+        cfg = bt.TerrainViewConfig(geometry_tile_count=cfg_tiles, subdivision_tolerance=tolerance)
+        prepass = bt.TilingPrepass(device, cfg.geometry_tile_count)
+        for pos in positions[:: 1 if tolerance == 0.1 else 3]:
+            v = bt.make_view_state(model, cfg, pos)
+            prepass.run(v, plain=True)
+            plain, plain_indirect = prepass.read()
+            plain = plain.copy()
+            for _ in range(2):
+                prepass.run(v)
+                ours, indirect = prepass.read()
+                assert np.array_equal(ours, plain) and tuple(indirect) == tuple(plain_indirect), (kind, pos, tolerance)
+            exp, exp_indirect, _ = O.refine(oracle_view(v))
+            assert np.array_equal(ours, exp) and list(indirect) == exp_indirect, (kind, pos, tolerance)
+            total += len(ours)
+        prepass.close()
+    assert total > 20000

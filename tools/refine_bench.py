@@ -38,6 +38,17 @@ def measure(device):
             ms.append(device.timer_end())
             tiles, _ = prepass.read()
             counts.append(len(tiles))
+        # the plain single-launch form (every divide test inside its pass): the checker, and what rounds 1-2 shipped
+        for v in views[:4]:
+            prepass.run(v, plain=True)
+        device.synchronize()
+        ms_p, same = [], True
+        for v, n in zip(views, counts):
+            device.timer_begin()
+            prepass.run(v, plain=True)
+            ms_p.append(device.timer_end())
+            tiles, _ = prepass.read()
+            same = same and len(tiles) == n
         # the CPU side of the same frame in the reference (TileTree::update over sides x lods x tree_size^2 nodes, f64):
         # here one launch + the read-back of the request / release lists (host wall time per update, synchronous)
         lods = 12
@@ -58,7 +69,10 @@ def measure(device):
                                      "us_per_update_max_host_wall": float(np.max(tree_us)), "requests_plus_releases_avg": float(np.mean(requests))}
         out[name] = {"frames": len(views), "us_per_frame_avg": 1e3 * float(np.mean(ms)), "us_per_frame_max": 1e3 * float(np.max(ms)),
                      "final_tiles_avg": float(np.mean(counts)), "final_tiles_max": int(np.max(counts)),
-                     "launches_per_frame": 1, "reference_dispatches_per_frame": 2 * cfg.refinement_count + 3}
+                     "launches_per_frame": 2, "reference_dispatches_per_frame": 2 * cfg.refinement_count + 3,
+                     "plain_single_launch": {"us_per_frame_avg": 1e3 * float(np.mean(ms_p)), "us_per_frame_max": 1e3 * float(np.max(ms_p)), "launches_per_frame": 1,
+                                             "same_tile_counts": bool(same),
+                                             "note": "bt_tiling_prepass_run_plain: every divide test evaluated inside the pass that needs it"}}
     return out
 
 
