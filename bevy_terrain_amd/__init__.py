@@ -20,3 +20,5 @@ __all__ = [
     "TilingPrepass", "make_view_state",
     "TileTree", "sample_attachment", "sample_height", "view_state_from_config",
 ]
+
+from ._ffi import BtError  # noqa: E402,F401  (status + text of a failed C call)

@@ -1828,7 +1828,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         const uint32_t world = p->shard_world, rank = p->shard_rank;
         const uint32_t nlods_all = lod_hi - lod_lo + 1, main_levels_all = std::min(3u, nlods_all);
         const uint32_t strips = 1u << (lod_hi - (main_levels_all - 1)), units = sides * strips;
-        bool shard = world > 1 && units % world == 0 && !hybrid && !direct;
+        bool shard = world > 1 && units % world == 0 && !hybrid;  // (fused_direct shards like fused_main: finest tiles complete from the source, parent centres inside a strip, everything else after the exchange)
         std::vector<bt_shard_range> ranges;
         std::vector<bt_shard_piece> pieces;
         if (shard) {

@@ -356,7 +356,12 @@ bt_status bt_atlas_get_tile(bt_atlas* a, bt_tile_coordinate c, bt_atlas_tile* ou
     return BT_OK;
 }
 
-// allocate_tile (tile_atlas.rs:383-389): the oldest unused slot; whatever tile was cached in it is forgotten
+// allocate_tile (tile_atlas.rs:383-389): the oldest unused slot; whatever tile was cached in it is forgotten.
+// DELIBERATE DEVIATION: called from request_tile the reference has already mem::take()n tile_states, so ITS
+// `tile_states.remove(evicted)` is a no-op there and the evicted tile's stale TileState (an atlas_index that now belongs to
+// another tile) survives until something overwrites it; get_best_tile / a re-request of the evicted tile then see it.
+// Here the evicted tile's state is erased on every path — the sane behaviour the reference's own get_or_allocate path has;
+// the oracle (oracle/bt_oracle_tree.c) encodes the same choice.
 static bt_status allocate_tile(bt_atlas* a, uint32_t* atlas_index) {
     if (a->unused_tiles.empty()) {
         set_error("Atlas out of indices (atlas_size %u)", a->config.atlas_size);

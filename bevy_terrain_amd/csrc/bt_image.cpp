@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -80,7 +82,11 @@ bool inflate_raw(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t
     static const uint16_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
     BitReader br{src, n};
     if (expected) out.reserve(expected);
+    // `expected` (when given) bounds the output: a stream that goes on past what the image holds is cut there — a hostile
+    // file cannot make the decoder allocate more than the header-derived (and capped) image size
+    const size_t limit = expected ? expected : size_t(-1);
     for (;;) {
+        if (out.size() >= limit) return true;
         const uint32_t last = br.get(1), type = br.get(2);
         if (br.fail) return false;
         if (type == 0) {
@@ -89,7 +95,7 @@ bool inflate_raw(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t
             const uint32_t len = src[br.pos] | (src[br.pos + 1] << 8), nlen = src[br.pos + 2] | (src[br.pos + 3] << 8);
             br.pos += 4;
             if ((len ^ 0xFFFFu) != nlen || br.pos + len > n) return false;
-            out.insert(out.end(), src + br.pos, src + br.pos + len);
+            out.insert(out.end(), src + br.pos, src + br.pos + std::min<size_t>(len, limit - out.size()));
             br.pos += len;
         } else if (type == 1 || type == 2) {
             Huffman lit, dist;
@@ -137,6 +143,7 @@ bool inflate_raw(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t
             for (;;) {
                 const int sym = lit.decode(br);
                 if (sym < 0) return false;
+                if (out.size() >= limit) return true;
                 if (sym < 256) {
                     out.push_back(uint8_t(sym));
                 } else if (sym == 256) {
@@ -149,7 +156,7 @@ bool inflate_raw(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t
                     const uint32_t d = kDistBase[ds] + br.get(kDistExtra[ds]);
                     if (br.fail || d > out.size()) return false;
                     size_t from = out.size() - d;
-                    for (uint32_t k = 0; k < len; k++) out.push_back(out[from + k]);
+                    for (uint32_t k = 0; k < len && out.size() < limit; k++) out.push_back(out[from + k]);
                 }
             }
         } else {
@@ -165,6 +172,13 @@ bool inflate_zlib(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_
 }
 
 // ------------------------------------------------------------------------------------------- decoded image -> raster
+// Header fields come from the file: everything derived from them is capped before it sizes an allocation or a loop
+constexpr uint32_t kMaxSide = 1u << 20;
+constexpr uint64_t kMaxImageBytes = 1ull << 34;  // 16 GiB decoded
+inline bool dimensions_ok(uint64_t w, uint64_t h, uint64_t bytes_per_pixel) {
+    return w != 0 && h != 0 && w <= kMaxSide && h <= kMaxSide && w * h * bytes_per_pixel <= kMaxImageBytes;
+}
+
 struct Decoded {
     uint32_t width = 0, height = 0, channels = 0, bits = 0;  // interleaved samples; 16-bit samples in HOST byte order
     std::vector<uint8_t> data;
@@ -241,6 +255,10 @@ bt_status decode_png(const uint8_t* p, size_t n, Decoded& d) {
     if (!have_header || d.width == 0 || d.height == 0) {
         set_error("PNG: no IHDR");
         return BT_ERR_IO;
+    }
+    if (!dimensions_ok(d.width, d.height, 8)) {
+        set_error("PNG: %u x %u is beyond what this decoder accepts (%u per side, %llu bytes per image)", d.width, d.height, kMaxSide, (unsigned long long)kMaxImageBytes);
+        return BT_ERR_UNSUPPORTED;
     }
     if (interlace) {
         set_error("PNG: Adam7 interlacing is not supported");
@@ -453,6 +471,15 @@ bt_status decode_tiff(const uint8_t* p, size_t n, Decoded& d) {
         return BT_ERR_UNSUPPORTED;
     }
     const size_t bps = d.bits / 8, px = bps * spp;
+    if (!dimensions_ok(d.width, d.height, px)) {
+        set_error("TIFF: %u x %u is beyond what this decoder accepts (%u per side, %llu bytes per image)", d.width, d.height, kMaxSide, (unsigned long long)kMaxImageBytes);
+        return BT_ERR_UNSUPPORTED;
+    }
+    if ((tile_w != 0) != (tile_h != 0) || tile_w > kMaxSide || tile_h > kMaxSide || rows_per_strip == 0 ||
+        (tile_w != 0 && uint64_t(tile_w) * tile_h * px > (1ull << 31))) {
+        set_error("TIFF: bad strip / tile geometry (RowsPerStrip %u, TileWidth %u, TileLength %u)", rows_per_strip, tile_w, tile_h);
+        return BT_ERR_IO;
+    }
     const bool tiled = tile_w != 0 && tile_h != 0;
     const uint32_t cw = tiled ? tile_w : d.width, ch = tiled ? tile_h : std::min(rows_per_strip, d.height);
     const uint32_t across = tiled ? (d.width + cw - 1) / cw : 1, down = (d.height + ch - 1) / ch;
@@ -471,7 +498,11 @@ bt_status decode_tiff(const uint8_t* p, size_t n, Decoded& d) {
                 return BT_ERR_IO;
             }
             const uint32_t rows = tiled ? ch : std::min(ch, d.height - cy * ch);
-            const size_t expected = size_t(cw) * rows * px;
+            const size_t expected = size_t(cw) * rows * px;  // <= 2^20 * 2^20 * 8: no wrap; strips are additionally bounded by the image cap
+            if (expected == 0 || expected > kMaxImageBytes) {
+                set_error("TIFF: chunk %zu has an impossible size", i);
+                return BT_ERR_IO;
+            }
             const uint8_t* src = p + offsets[i];
             chunk.clear();
             bool ok = true;
@@ -526,16 +557,25 @@ bt_status bt_image_decode(const void* bytes, size_t n, uint32_t format, bt_image
     *out = {nullptr, 0, 0, 0, 0};
     const uint8_t* p = (const uint8_t*)bytes;
     static const uint8_t kPng[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
-    Decoded d;
-    bt_status s;
-    if (n >= 8 && !memcmp(p, kPng, 8)) s = decode_png(p, n, d);
-    else if (n >= 8 && ((p[0] == 'I' && p[1] == 'I') || (p[0] == 'M' && p[1] == 'M'))) s = decode_tiff(p, n, d);
-    else {
-        set_error("neither a PNG nor a TIFF file");
-        return BT_ERR_UNSUPPORTED;
+    // nothing may leave an extern "C" function by exception: a file that asks for more memory than there is becomes a status
+    try {
+        Decoded d;
+        bt_status s;
+        if (n >= 8 && !memcmp(p, kPng, 8)) s = decode_png(p, n, d);
+        else if (n >= 8 && ((p[0] == 'I' && p[1] == 'I') || (p[0] == 'M' && p[1] == 'M'))) s = decode_tiff(p, n, d);
+        else {
+            set_error("neither a PNG nor a TIFF file");
+            return BT_ERR_UNSUPPORTED;
+        }
+        if (s) return s;
+        return to_raster(d, format, out);
+    } catch (const std::bad_alloc&) {
+        set_error("image decode: out of memory");
+        return BT_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception& e) {
+        set_error("image decode: %s", e.what());
+        return BT_ERR_OUT_OF_MEMORY;
     }
-    if (s) return s;
-    return to_raster(d, format, out);
 }
 
 bt_status bt_image_load(const char* path, uint32_t format, bt_image* out) {

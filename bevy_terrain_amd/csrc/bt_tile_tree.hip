@@ -474,14 +474,16 @@ bt_status bt_tile_tree_requests(const bt_tile_tree* t, const bt_tile_coordinate*
 
 bt_status bt_tile_tree_apply_requests(bt_tile_tree* t, bt_atlas* a) {
     if (!t || !a) return BT_ERR_INVALID_ARGUMENT;
-    // tile_atlas.rs:590-600: all releases of the tree, then all its requests
-    for (uint32_t i = 0; i < t->released_count; i++)
-        if (bt_status s = bt_atlas_release_tile(a, t->h_released[i])) return s;
+    // tile_atlas.rs:590-600: all releases of the tree, then all its requests.  The reference DRAINS both lists whatever
+    // happens (mem::take); here too: an entry is consumed when it is applied and, on an error (e.g. "Atlas out of indices"),
+    // the rest of both lists is dropped — a retry can neither release twice nor count a request twice.  The failing entry's
+    // status is returned; tiles not requested because of it are requested again by a later update() if still wanted.
+    bt_status first = BT_OK;
+    for (uint32_t i = 0; i < t->released_count && first == BT_OK; i++) first = bt_atlas_release_tile(a, t->h_released[i]);
+    for (uint32_t i = 0; i < t->requested_count && first == BT_OK; i++) first = bt_atlas_request_tile(a, t->h_requested[i]);
     t->released_count = 0;
-    for (uint32_t i = 0; i < t->requested_count; i++)
-        if (bt_status s = bt_atlas_request_tile(a, t->h_requested[i])) return s;
     t->requested_count = 0;
-    return BT_OK;
+    return first;
 }
 
 bt_status bt_tile_tree_adjust_to_tile_atlas(bt_tile_tree* t, const bt_atlas* a) {

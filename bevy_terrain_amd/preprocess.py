@@ -41,8 +41,16 @@ class AssetServer:
             raise FileNotFoundError(f"source raster {path!r} neither registered nor found at {full}")
         if full.endswith(".npy"):
             return np.load(full)
-        # PNG / TIFF: decoded by the library (bt_image_load), into the attachment's processing format
-        return decode_image(full, fmt or AttachmentFormat.R16)
+        # PNG / TIFF: decoded by the library (bt_image_load), into the attachment's processing format; without one the file
+        # decides: 16-bit grayscale -> R16, anything 8-bit -> Rgba8
+        if fmt is not None:
+            return decode_image(full, fmt)
+        try:
+            return decode_image(full, AttachmentFormat.R16)
+        except _ffi.BtError as e:
+            if e.status != _ffi.BT_ERR_UNSUPPORTED:
+                raise
+            return decode_image(full, AttachmentFormat.Rgba8)
 
 
 def decode_image(path_or_bytes, fmt: AttachmentFormat) -> np.ndarray:
@@ -150,7 +158,10 @@ class Preprocessor:
 
     def preprocess_spherical(self, dataset: SphericalDataset, asset_server: AssetServer, tile_atlas: TileAtlas) -> "Preprocessor":
         fmt = tile_atlas.config.attachments[dataset.attachment_index].format
-        rasters = (_ffi.RasterC * 6)(*[_raster_struct(asset_server.load(p, fmt), fmt, self._keep) for p in dataset.paths])
+        def load(path):  # (duck-typed asset servers predate the `fmt` argument: same guard as preprocess_tile)
+            return asset_server.load(path, fmt) if isinstance(asset_server, AssetServer) else asset_server.load(path)
+
+        rasters = (_ffi.RasterC * 6)(*[_raster_struct(load(p), fmt, self._keep) for p in dataset.paths])
         d = _ffi.SphericalDatasetC(dataset.attachment_index, dataset.lod_range.start, dataset.lod_range.stop)
         _ffi.check(_ffi.lib().bt_preprocessor_preprocess_spherical(self._handle(tile_atlas), tile_atlas._h, C.byref(d), rasters))
         return self

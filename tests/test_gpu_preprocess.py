@@ -628,3 +628,41 @@ def test_streamed_run_falls_back_for_queues_it_cannot_band(device, tmp_path):
         for c, i in oracle.tiles():
             data = np.fromfile(os.path.join(atlas.attachment_directory(root, 0), f"{c[0]}_{c[1]}_{c[2]}_{c[3]}.bin"), dtype=np.uint16).reshape(64, 64)
             assert np.array_equal(data, oracle.tile(0, i)), c
+
+
+def test_config5_cube_albedo_full_size(device):
+    """BASELINE config 5's second attachment at full size: 6 cube faces of 8192^2 Rgba8 (albedo), lod_count 5, T = 512 -> 2046
+    tiles of 1 MiB through the plan the product picks (fused_direct + tail + cube seams), every tile compared with the
+    reference's own WGSL executed on the CPU (oracle/_ref)."""
+    W, lods = 8192, 5
+    faces = []
+    for s in range(6):
+        h = K.smooth_raster(W, W, seed=17 + s, device=device)
+        rgba = np.empty((W, W, 4), np.uint8)
+        rgba[..., 0] = np.maximum(h >> 8, 1)
+        rgba[..., 1] = h & 255
+        rgba[..., 2] = (h >> 3) & 255
+        rgba[..., 3] = 255
+        rgba[3000 + 41 * s:3100 + 41 * s, 2000:2400, 0] = 0  # a no-data patch (red = 0) on every face
+        faces.append(rgba)
+        del h
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=2048, path="terrains/spherical")
+    cfg.add_attachment(bt.AttachmentConfig(name="albedo", texture_size=512, border_size=2, format=bt.AttachmentFormat.Rgba8))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer()
+    paths = [f"albedo{s}" for s in range(6)]
+    for p, f in zip(paths, faces):
+        server.insert(p, f)
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_spherical(
+        bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lods)), server, atlas)
+    pre.run(atlas)
+    st = pre.stats()
+    assert st["fused_jobs"] >= 1 and st["tiles"] == 2046
+    oracle = K.reference_kernels(O.OracleAtlas(lods, 2048, True, [(512, 2, 1, O.FORMAT_RGBA8)]))
+    oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(O.usable_cores())
+    assert [((c.side, c.lod, c.x, c.y), i) for c, i in atlas.tiles()] == oracle.tiles()
+    for first in range(0, 2046, 64):
+        count = min(64, 2046 - first)
+        data = atlas.download_tiles(0, first, count)
+        for k in range(count):
+            assert np.array_equal(data[k], oracle.tile(0, first + k)), (first + k, oracle.tiles()[first + k])

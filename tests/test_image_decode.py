@@ -207,3 +207,57 @@ def test_small_and_odd_images(tmp_path):
     with pytest.raises(bt._ffi.BtError) as e:
         decode_image(inter, RGBA8)
     assert e.value.status == -5
+
+
+def _tiff(entries, data=b"", big=False):
+    """a classic TIFF with one IFD: entries = [(tag, type, count, value)] (SHORT = 3, LONG = 4; values inline), `data` appended"""
+    import struct
+
+    e = ">" if big else "<"
+    out = (b"MM\x00\x2a" if big else b"II\x2a\x00") + struct.pack(e + "I", 8)
+    out += struct.pack(e + "H", len(entries))
+    for tag, typ, count, value in entries:
+        out += struct.pack(e + "HHI", tag, typ, count)
+        out += struct.pack(e + "HH", value, 0) if typ == 3 else struct.pack(e + "I", value)
+    out += struct.pack(e + "I", 0)
+    return out + data
+
+
+def _png(width, height, idat, bits=16, color=0):
+    import struct
+    import zlib
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, bits, color, 0, 0, 0)) + chunk(b"IDAT", idat) + chunk(b"IEND", b"")
+
+
+def test_hostile_headers_are_statuses_not_crashes():
+    """every size a file states is validated before it sizes an allocation or a loop, the decompressors stop at
+    the image's size, and nothing leaves bt_image_decode by exception"""
+    import zlib
+
+    base = 8 + 2 + 12 * 9 + 4  # where `data` starts in the 9-entry IFDs below
+    good = [(256, 4, 1, 4), (257, 4, 1, 4), (258, 3, 1, 16), (259, 3, 1, 1), (262, 3, 1, 1), (273, 4, 1, base), (277, 3, 1, 1), (278, 4, 1, 4), (279, 4, 1, 32)]
+    ok = _tiff(good, bytes(range(32)))
+    assert decode_image(ok, R16).shape == (4, 4)
+
+    def with_(tag, value, typ=4):
+        return _tiff([(t, ty if t != tag else typ, c, v if t != tag else value) for t, ty, c, v in good], bytes(range(32)))
+
+    for bad in (with_(278, 0),                       # RowsPerStrip = 0: used to divide by zero
+                with_(256, 0x7FFFFFFF), with_(257, 0x7FFFFFFF),  # absurd dimensions
+                with_(256, 1 << 21),
+                _tiff(good[:-2] + [(322, 4, 1, 0x7FFFFFF0), (323, 4, 1, 0x7FFFFFF0), (324, 4, 1, base), (325, 4, 1, 32)][:2] + good[-2:], bytes(32)),  # TileWidth without offsets
+                _tiff([e for e in good if e[0] not in (278,)] + [(322, 4, 1, 1 << 30), (323, 4, 1, 1 << 30)], bytes(32)),   # tile area wraps 32 bits
+                _tiff([e for e in good if e[0] not in (278,)] + [(322, 4, 1, 16), (323, 4, 1, 0)], bytes(32))):              # TileLength = 0
+        with pytest.raises(bt.BtError):
+            decode_image(bad, R16)
+    # PNG: dimensions beyond the cap; a zlib stream that inflates far beyond the image (cut at the image size: the decode
+    # succeeds or fails, but the process neither aborts nor allocates the bomb)
+    with pytest.raises(bt.BtError):
+        decode_image(_png(1 << 24, 1 << 24, zlib.compress(b"\0" * 64)), R16)
+    bomb = zlib.compress(b"\0" * (64 << 20), 9)  # 64 MiB of zeros in ~64 KB
+    out = decode_image(_png(8, 8, bomb), R16)      # an 8 x 8 image: 8 * (1 + 16) bytes are taken, the rest is never produced
+    assert out.shape == (8, 8) and not out.any()

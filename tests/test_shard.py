@@ -549,3 +549,35 @@ def test_distributed_result_is_refused_for_cube_jobs():
     _ffi.check(_ffi.lib().bt_preprocessor_set_shard(pre._h, 1, 4))
     rc = _ffi.lib().bt_preprocessor_run(pre._h, atlas._h, _ffi.RUN_KEEP_QUEUE | _ffi.RUN_SHARD_LOCAL | _ffi.RUN_SHARD_DISTRIBUTED)
     assert rc == -5  # BT_ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rgba8_job_at_tile_size_512_sharded_over_emulated_ranks(world):
+    """An Rgba8 (albedo) job at the reference's tile shape through the sharded path: 16384^2 Rgba8, lod_count 6, T = 512 ->
+    1365 tiles of 1 MiB (fused_direct), 8 units; every emulated rank has its own atlas and runs its strip, rank 0 receives
+    the pieces and finishes; its atlas must equal the checker's (the reference's WGSL executed on the CPU)."""
+    import bevy_terrain_amd as bt
+
+    device = bt.Device(0)
+    T, b, lods, W = 512, 2, 6, 16384
+    rng = np.random.default_rng(77)
+    coarse = rng.integers(1, 256, size=(W // 8, W // 8, 4), dtype=np.uint8)
+    src = np.repeat(np.repeat(coarse, 8, axis=0), 8, axis=1)  # 1 GiB, blocky (cheap to make; every texel still filtered)
+    src[..., 3] = 255
+    src[5000:5200, 9000:9300, 0] = 0
+    src = np.ascontiguousarray(src)
+    ptr = device.upload(src)
+
+    def make_job():
+        cfg = bt.TerrainConfig(lod_count=lods, atlas_size=2048, path="t", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+        cfg.add_attachment(bt.AttachmentConfig(name="albedo", texture_size=T, border_size=b, format=bt.AttachmentFormat.Rgba8))
+        atlas = bt.TileAtlas.new(cfg, device)
+        pre = bt.Preprocessor.new().preprocess_tile(bt.PreprocessDataset(path="s", lod_range=range(0, lods)), bt.AssetServer().insert("s", (ptr, W, W)), atlas)
+        return atlas, pre
+
+    oracle = K.reference_kernels(O.OracleAtlas(lods, 2048, False, [(T, b, 1, O.FORMAT_RGBA8)]))
+    oracle.clear_attachment(0).preprocess_tile(0, src, (0, lods)).run(O.usable_cores())
+    pieces = _emulate_ranks(device, world, make_job, 1365, oracle, lods - 1, T, b)
+    assert len({p["owner_rank"] for p in pieces}) == world
+    device.free(ptr)
