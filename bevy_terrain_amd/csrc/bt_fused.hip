@@ -645,26 +645,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         };
 
 #ifdef BT_DEBUG_HOOKS
-        // (134217728: real-time (100 MHz) stamps of chunks 0, 16, 32, 48 and of the end, per tile, into the atlas's last layer — how far do
-        // the workgroups of a tile row drift apart?  tools/drift_probe.py)
-        if (BT_ABLATE(A, 134217728u) && tid == 0 && (k & 15u) == 0 && k < 64u)
-            reinterpret_cast<unsigned long long*>(A.atlas + uint64_t(A.m.atlas_size - 1u) * tile_texels)[item_index * 8u + (k >> 4)] = __builtin_amdgcn_s_memrealtime();
+#define BT_FUSED_DEBUG_CHUNK_PROBES
+#include "bt_fused_debug.inc"  // (per-chunk time stamps, rotating wave priorities: timing experiments)
+#undef BT_FUSED_DEBUG_CHUNK_PROBES
 #endif
-        // (1073741824, timing experiment: the wave priority rotates with the chunk index, offset by the dispatch rank inside the
-        // XCD.  The CU's arbiters serve the highest-priority wave first and, among equals, the OLDEST — strictly: of the four
-        // resident workgroups of a CU the first-dispatched finishes its tile after 190 us, the last after 275
-        // (tools/drift_probe.py; reversed priorities reverse the staircase).  Rotation makes them finish within 10 us of each
-        // other, one job alone gains 1.3 - 2 %, but jobs in flight behind each other LOSE 3 %: the staircase is what lets the
-        // next job's workgroups move in early.  Aggregate throughput is the memory system's either way.  Not in the product.)
-        if (BT_ABLATE(A, 1073741824u)) {
-            const uint32_t rot_rank = (blockIdx.x / 8u) / 32u + k;
-            switch (rot_rank & 3u) {
-                case 0: __builtin_amdgcn_s_setprio(0); break;
-                case 1: __builtin_amdgcn_s_setprio(1); break;
-                case 2: __builtin_amdgcn_s_setprio(2); break;
-                default: __builtin_amdgcn_s_setprio(3); break;
-            }
-        }
         // a chunk with no-data goes to the generic variant as a whole
         const bool skip_chunk = !kGeneric && has_nodata;
         if (skip_chunk && tid == 0) A.todo[2 + atomicAdd(&A.todo[0], 1u)] = item_index * chunks_per_tile + k;
@@ -696,47 +680,11 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             }
         }
 
-        if (BT_ABLATE(A, 768u) && !is_idle) {  // (ablation 256 / 512, with 16: the chunk's finest / parent stores without any arithmetic — the memory skeleton)
-            // (4096: the same bytes with thread t on dword t of the row — what a texture-aligned thread mapping would store)
-            uint32_t* dst5 = BT_ABLATE(A, 4096u) ? tile5_u32 + (((b + cr0) * T) >> 1) + tid : tile5_u32 + (((b + cr0) * T + px0) >> 1);
-            if (BT_ABLATE(A, 256u)) {
-                if (BT_ABLATE(A, 1048576u)) {  // (1048576: a wave's 4 rows x 256 bytes as ONE 16-byte-per-lane store — what a per-wave transposition would emit)
-                    const uint32_t wave = tid >> 6, lane = tid & 63u;
-#pragma unroll
-                    for (uint32_t quad = 0; quad < kMainRows / 4; quad++) {
-                        uint8_t* row = reinterpret_cast<uint8_t*>(tile5 + (b + cr0 + 4 * quad + (lane >> 4)) * T) + (BT_ABLATE(A, 4096u) ? 0u : 2u * b);
-                        if (wave * 256u + (lane & 15u) * 16u + 16u <= 2u * T - 2u * b)
-                            *reinterpret_cast<u32x4*>(row + wave * 256u + (lane & 15u) * 16u) = u32x4{tid, tid + quad, tid, tid};
-                    }
-                } else {
-#pragma unroll
-                    for (uint32_t i = 0; i < kMainRows; i++) dst5[i * (T / 2)] = tid + i;
-                }
-            }
-            if (do4 && BT_ABLATE(A, 262144u)) {  // (262144: the chunk's four parent rows as 16-byte stores of 32 lanes each — two wave instructions instead of sixteen)
-                const uint32_t wave = tid >> 6, lane = tid & 63u;
-                if (wave < 2) {
-                    uint16_t* row = tile4 + (b + cy4_base + (cr0 >> 1) + 2 * wave + (lane >> 5)) * T + (it.x & 1u) * (T / 2);
-                    reinterpret_cast<u32x4*>(row)[lane & 31u] = u32x4{tid, tid, tid, tid};
-                }
-                if (do3 && !BT_ABLATE(A, 64u) && wave == 2 && lane < 32) {  // and the two grand-parent rows as one
-                    uint16_t* row = tile3 + (b + cy3_base + (cr0 >> 2) + (lane >> 4)) * T + (it.x & 3u) * (T / 4);
-                    reinterpret_cast<u32x4*>(row)[lane & 15u] = u32x4{tid, tid, tid, tid};
-                }
-            } else if (is_centre && do4 && BT_ABLATE(A, 512u)) {
-                if (BT_ABLATE(A, 65536u)) {  // (65536: the parent rows of four chunks in one burst every fourth chunk — same bytes, same addresses)
-                    if ((k & 3u) == 3u) {
-                        uint16_t* dst = tile4 + (b + cy4_base + ((cr0 - 3u * kMainRows) >> 1)) * T + b + cx4;
-#pragma unroll
-                        for (uint32_t j = 0; j < 16; j++) dst[j * T] = uint16_t(tid);
-                    }
-                } else {
-                    uint16_t* dst = tile4 + (b + cy4_base + (cr0 >> 1)) * T + b + cx4;
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; j++) dst[j * T] = uint16_t(tid);
-                }
-            }
-        }
+#ifdef BT_DEBUG_HOOKS
+#define BT_FUSED_DEBUG_SKELETON_STORES
+#include "bt_fused_debug.inc"  // (memory-skeleton store shapes of the profiling build)
+#undef BT_FUSED_DEBUG_SKELETON_STORES
+#endif
         if (!BT_ABLATE(A, 16u) && !skip_chunk) {
             if constexpr (kStaged && !kGeneric) {
                 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -1062,14 +1010,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint32_t k_begin = part * chunks_per_tile / A.groups, k_end = (part + 1) * chunks_per_tile / A.groups;
     if (k_begin >= k_end) return;  // more parts than chunks (tiny tiles)
 #ifdef BT_DEBUG_HOOKS
-    {   // wave priority by dispatch rank inside the XCD (rank = which of the 4 resident workgroups of a CU this one is):
-        // 268435456: rank, 536870912: rank / 2, both: 3 - rank
-        const uint32_t rank = min(3u, (blockIdx.x / 8u) / 32u), mode = (A.ablate >> 28) & 3u;
-        const uint32_t prio = mode == 1u ? rank : (mode == 2u ? rank / 2u : (mode == 3u ? 3u - rank : 0u));
-        if (prio == 1u) __builtin_amdgcn_s_setprio(1);
-        else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
-        else if (prio == 3u) __builtin_amdgcn_s_setprio(3);
-    }
+#define BT_FUSED_DEBUG_ENTRY_PRIORITY
+#include "bt_fused_debug.inc"  // (static wave priority by dispatch rank: timing experiment)
+#undef BT_FUSED_DEBUG_ENTRY_PRIORITY
 #endif
     fused_main_chunks<kStaged, kGeneric, kT, kP, kDma>(A, work / A.groups, k_begin, k_end, smem);
 }

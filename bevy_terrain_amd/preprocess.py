@@ -48,7 +48,7 @@ class AssetServer:
         try:
             return decode_image(full, AttachmentFormat.R16)
         except _ffi.BtError as e:
-            if e.status != _ffi.BT_ERR_UNSUPPORTED:
+            if e.status != -5:  # BT_ERR_UNSUPPORTED: not a 16-bit grayscale image
                 raise
             return decode_image(full, AttachmentFormat.Rgba8)
 

@@ -7,13 +7,15 @@
  * `cpu_baseline` leg of bench.py.  Nothing in the product path
  * (bevy_terrain_amd/, include/) may include, link or call this.
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures
- *  and cannot be built here (no Rust toolchain,
- * un-vendored wgpu/naga).  The arithmetic of the path lives in the
- * reference's own WGSL; this file restates it statement by statement and
- * cites the file:line it follows.  Where the reference delegates to the GPU
- * driver (hardware bilinear sampler, unorm conversions, 0/0) the definition
- * chosen here is written next to the function.
+ * PARITY: pinned to the reference's own shader text since round 3.  The reference ships no tests, golden vectors or
+ * fixtures and its Rust / wgpu host cannot be built here; but the arithmetic of the path is WGSL
+ * text, and oracle/wgsl_ref translates that text mechanically (wgsl2cpp.py) and executes it (oracle/_ref): every Split /
+ * Downsample / Stitch task and the whole tiling prepass of this file are checked bit for bit against it
+ * (tests/test_wgsl_ref.py; orc_set_task_backend below is the seam), and tests/golden/ are its outputs.  What this file
+ * restates from RUST code (queue order and atlas indices, coordinate.rs, the f64 tile tree / terrain model in
+ * bt_oracle_tree.c, generate_mipmaps, bincode) has no executable counterpart and stays restated, statement by statement
+ * with the file:line it follows.  Where the reference delegates to the GPU driver (hardware bilinear sampler, unorm
+ * conversions, 0/0) the definition chosen is written next to the function and is the same in oracle/wgsl_ref.
  */
 #ifndef BT_ORACLE_H
 #define BT_ORACLE_H

@@ -4,14 +4,14 @@
 # writes gpurun_out/<tag>/...; tools/pmc_summary.py then condenses them into profiles/<tag>_*.
 # Counters are collected in their own passes (one --pmc group per run, kernel trace only).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 # the profiled command runs every job on ONE stream (--pipeline 1): a kernel that shares the GPU with another job's has no
 # duration of its own; the roofline of the default (pipelined) bench line is computed from its one-stream pass too
-B="python $R/bench.py --no-cpu-baseline --no-end-to-end --pipeline 1"
+B="python $R/bench.py --no-cpu-baseline --no-end-to-end --no-extras"
 
 python $R/bench.py --verify > $O/bench_n1_verified.json 2> $O/bench.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $B > $O/bench_under_rocprofv3.json 2> $O/stats.log
