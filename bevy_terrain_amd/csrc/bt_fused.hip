@@ -68,6 +68,7 @@ struct FusedArgs {
     uint32_t* todo;       // fused_main: [0] count, [2..] chunks (item * chunks_per_tile + k) left to the generic variant
     uint32_t* todo_next;  // the list of the NEXT run (the two alternate): fused_todo zeroes its count, so no reset protocol
     uint32_t apron_lods;  // fused_tail: LODs lod, lod+1, ... (this many) get their top / bottom apron rows from extra workgroups
+    uint32_t rotate_priority;  // fused_main: wave priority rotates with the chunk index (see fused_main_chunks)
     uint32_t apron_cols;  // fused_tail (Rgba8 after fused_direct, which writes centres only): ... and their left / right apron columns
     uint32_t ablate;      // debug only (env BT_FUSED_ABLATE): 1 no pyramid, 2 no finest stores, 4 no parent stores, 64 no grand-parent stores (static path), 8 no staging loads, 16 prologue only, 256 / 512 finest / parent stores without arithmetic (use with 16); skeleton shapes: 65536 parent rows in bursts of four chunks, 262144 parent rows as 16-byte stores, 1048576 finest rows as 16-byte stores
 };
@@ -301,7 +302,7 @@ constexpr uint32_t kMaxChunks = 64;  // chunks one workgroup may run through (T 
 struct MainShared {  // fixed part of the dynamic LDS block (size is a multiple of 16 bytes)
     // row tables of ALL chunks of the workgroup's run, written once in the prologue; index = (k - k_begin) * kMainRows + row
     int row_y0[kMaxChunks * kMainRows];    // first source row; bit 31: the second source row is the same one (clamped)
-    float row_fy[kMaxChunks * kMainRows];  // y weight (8 consecutive ones = two 16-byte uniform reads)
+    float2 row_fy[kMaxChunks * kMainRows];  // y weights (fy, 1 - fy): read by every lane at one address (a broadcast), used as they arrive
     int win_ymin[kMaxChunks];              // source window of a chunk: first row ...
     uint32_t win_slots[kMaxChunks];        // ... and row count; bit 31: the chunk's rows use source rows y, y+1, ..., y+kMainRows
     uint32_t nodata[2][4];                 // [chunk parity][wave]: the staged window holds a no-data texel; kDma: [parity][0] = some thread of the chunk read one
@@ -366,7 +367,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         if (cr < c) {
             const Axis ay = split_axis(cr, c, it.y, scale, A.tly, A.bry, raster.height);
             S.row_y0[i] = ay.i0 | (ay.i1 == ay.i0 ? int(0x80000000u) : 0);
-            S.row_fy[i] = ay.fr;
+            S.row_fy[i] = float2{ay.fr, 1.0f - ay.fr};
         }
     }
     if (tid >= 32 && tid < 32 + 2 * b) {
@@ -612,7 +613,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
 
     for (uint32_t k = k_begin; k < k_end; k++) {
         const int* row_y0 = S.row_y0 + (k - k_begin) * kMainRows;
-        const float* row_fy = S.row_fy + (k - k_begin) * kMainRows;
+        const float2* row_fy = S.row_fy + (k - k_begin) * kMainRows;
         const uint32_t cr0 = k * kMainRows, nrows = chunk_rows(k);
         uint16_t* s_src = s_buf + (k & 1u) * buf_texels;  // this chunk's staged rows; the other half receives chunk k + 1
         const int cur_ymin = ymin;
@@ -622,7 +623,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         const bool more = k + 1 < k_end;
         if (more) {
             window(k + 1, next_ymin, next_slots);
-            if constexpr (kDma) dma_issue(s_buf + ((k + 1) & 1u) * buf_texels, next_ymin, next_slots);
+            if constexpr (kDma) {
+                if (BT_ABLATE(A, 2048u)) __builtin_amdgcn_s_setprio(3);  // (2048: the DMA issue at top priority — timing experiment)
+                dma_issue(s_buf + ((k + 1) & 1u) * buf_texels, next_ymin, next_slots);
+            }
             else if (kStaged && wide && !BT_ABLATE(A, 8u)) stage_issue(next_ymin, next_slots, pre);
         }
         // kDma: the chunk before this one was flagged by some thread: append it to the todo list (once), clear the flag
@@ -644,6 +648,20 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             }
         };
 
+        // Wave priority rotating with the chunk index, offset by the workgroup's dispatch rank on its CU.  The CU's arbiters serve
+        // the highest-priority wave first and, among equals, the OLDEST — strictly: without this the four resident workgroups
+        // of a CU finish their tiles after 190 / 215 / 243 / 272 us in dispatch order (tools/drift_probe.py; static priorities by
+        // rank reverse the staircase exactly).  Giving every workgroup a quarter of its chunks at each level makes them finish
+        // within 10 us of each other and the kernel 2.3 % shorter (283.4 -> 276.9 us).  Two jobs in flight on two contexts lose
+        // ~3 % with it (the staircase lets the next job's workgroups move in early): the single job is what is optimised.
+        if (A.rotate_priority) {
+            switch (((blockIdx.x / 8u) / 32u + k) & 3u) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
 #ifdef BT_DEBUG_HOOKS
 #define BT_FUSED_DEBUG_CHUNK_PROBES
 #include "bt_fused_debug.inc"  // (per-chunk time stamps, rotating wave priorities: timing experiments)
@@ -719,13 +737,17 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                     // LDS latency hides behind the packed arithmetic.
                     const uint16_t* base = s_src + uint32_t(__builtin_amdgcn_readfirstlane(row_y0[0]) - cur_ymin) * P;  // consecutive: bit 31 clear
                     const uint16_t *pa0 = base + la0, *pa1 = base + la1, *pb0 = base + lb0, *pb1 = base + lb1;
-                    const float* fyt = row_fy;
-                    uint32_t t0 = pa0[0], t1 = pb0[0], t2 = pa1[0], t3 = pb1[0];
-                    uint32_t n0 = pa0[P], n1 = pb0[P], n2 = pa1[P], n3 = pb1[P];
-                    f2 hprev = conv2(t0, t1) * gx + conv2(t2, t3) * fx;
+                    const float2* fyt = row_fy;
+                    // the texels of a source row as two 16-bit PAIRS (columns a | b at i0, at i1): the pairs convert with SDWA selects
+                    // and the no-data test is two packed 16-bit minima per row
+                    u16x2 ta = {pa0[0], pb0[0]}, tb = {pa1[0], pb1[0]};
+                    u16x2 na = {pa0[P], pb0[P]}, nb = {pa1[P], pb1[P]};
+                    auto conv2p = [&](u16x2 t) -> f2 { return conv2(t.x, t.y); };
+                    f2 hprev = conv2p(ta) * gx + conv2p(tb) * fx;
                     uint32_t q[4];
-                    // kDma: smallest raw texel this thread read for the rows of a quad (source rows 4 * quad .. 4 * quad + 4)
-                    uint32_t zq[2] = {min(min(t0, t1), min(t2, t3)), 0xFFFFu}, zp[2] = {1u, 1u};
+                    // kDma: smallest raw texel this thread read for the rows of a quad (source rows 4 * quad .. 4 * quad + 4), per column pair half
+                    u16x2 zmin[2] = {__builtin_elementwise_min(ta, tb), u16x2{0xFFFFu, 0xFFFFu}};
+                    uint32_t zq[2] = {1u, 1u}, zp[2] = {1u, 1u};
                     uint32_t* dst5 = tile5_u32 + (((b + cr0) * T + px0) >> 1);
 #pragma unroll
                     for (uint32_t quad = 0; quad < 2; quad++) {
@@ -733,30 +755,29 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
 #pragma unroll
                         for (uint32_t i = 0; i < 4; i++) {
                             const uint32_t r = 4 * quad + i;  // output row; needs source rows r and r + 1
-                            t0 = n0;
-                            t1 = n1;
-                            t2 = n2;
-                            t3 = n3;
+                            ta = na;
+                            tb = nb;
                             if (r + 2 <= kMainRows) {
-                                n0 = pa0[(r + 2) * P];
-                                n1 = pb0[(r + 2) * P];
-                                n2 = pa1[(r + 2) * P];
-                                n3 = pb1[(r + 2) * P];
+                                na = u16x2{pa0[(r + 2) * P], pb0[(r + 2) * P]};
+                                nb = u16x2{pa1[(r + 2) * P], pb1[(r + 2) * P]};
                             }
                             if constexpr (kDma) {
-                                zq[quad] = min(zq[quad], min(min(t0, t1), min(t2, t3)));
-                                if (quad == 0 && i == 3) zq[1] = min(min(t0, t1), min(t2, t3));  // source row 4 feeds both quads
+                                const u16x2 zrow = __builtin_elementwise_min(ta, tb);
+                                zmin[quad] = __builtin_elementwise_min(zmin[quad], zrow);
+                                if (quad == 0 && i == 3) zmin[1] = zrow;  // source row 4 feeds both quads
                             }
-                            const f2 hnew = conv2(t0, t1) * gx + conv2(t2, t3) * fx;
-                            const float fy = BT_ABLATE(A, 33554432u) ? 0.25f + 0.0625f * float(r)  // (33554432: y weights without the LDS reads — timing only)
-                                                                    : __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fyt[r])));
-                            const f2 fy2 = {fy, fy}, gy2 = {1.0f - fy, 1.0f - fy};
+                            const f2 hnew = conv2p(ta) * gx + conv2p(tb) * fx;
+                            // (fy, 1 - fy) of output row r: one 8-byte LDS read at a workgroup-uniform address, the values stay in
+                            // vector registers (no v_readfirstlane, no subtraction: 16 VALU instructions less per chunk)
+                            const float2 wy = fyt[r];
+                            const f2 fy2 = {wy.x, wy.x}, gy2 = {wy.y, wy.y};
                             const f2 w = quantise(hprev * gy2 + hnew * fy2);
                             hprev = hnew;
                             ua[i] = uint32_t(w.x);
                             ub[i] = uint32_t(w.y);
                         }
                         if constexpr (kDma) {
+                            zq[quad] = min(uint32_t(zmin[quad].x), uint32_t(zmin[quad].y));
                             zp[quad] = pair_min(zq[quad]);
                             dirty |= zp[quad] == 0 ? 1u : 0u;
                         }
@@ -850,7 +871,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                     for (uint32_t i = 0; i < 4; i++) {
                         const int yy = __builtin_amdgcn_readfirstlane(row_y0[q + i]);
                         const int y0 = yy & 0x7fffffff, y1 = y0 + (yy < 0 ? 0 : 1);
-                        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row_fy[q + i])));
+                        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row_fy[q + i].x)));
                         f2 top = hcur;
                         uint32_t ztop = zcur;
                         if (y0 != hy) {
@@ -921,7 +942,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                     for (uint32_t i = 0; i < 4; i++) {
                         const int yy = __builtin_amdgcn_readfirstlane(row_y0[q + i]);
                         const int y0 = yy & 0x7fffffff, y1 = y0 + (yy < 0 ? 0 : 1);
-                        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row_fy[q + i])));
+                        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row_fy[q + i].x)));
                         const Texel4 top = (y0 == cur_y) ? cur : fetch_row(y0);
                         const Texel4 bot = (y1 == y0) ? top : fetch_row(y1);
                         cur = bot;
@@ -2021,6 +2042,10 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             main_job.args.lds_rows = (2 * rows_needed * pitch * 2 <= budget && rows_needed * (pitch / 8) <= 256 * 4 &&
                                       (rows_needed + 1) * max_pitch < (1ull << 31)) ? uint32_t(rows_needed) : 0u;
             main_job.dma = main_job.args.lds_rows != 0;
+            main_job.args.rotate_priority = 1;
+#ifdef BT_DEBUG_HOOKS
+            if (const char* e = getenv("BT_FUSED_ROTATE")) main_job.args.rotate_priority = atoi(e) != 0;
+#endif
             for (const Task* t : splits) {
                 const RasterDev& r = p->rasters[t->raster].dev;
                 if (((reinterpret_cast<uintptr_t>(r.data) | r.pitch) & 15u) != 0) main_job.dma = false;

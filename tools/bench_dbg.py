@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bevy_terrain_amd import _ffi
 
-_ffi.LIB_PATH = os.path.join(ROOT, "tools", "libbevy_terrain_amd_dbg.so")
+_ffi.LIB_PATH = os.environ.get("BT_LIB") or os.path.join(ROOT, "tools", "libbevy_terrain_amd_dbg.so")  # BT_LIB: another build (A/B runs)
 import bench
 
 bench.main()
