@@ -187,6 +187,8 @@ PROTOTYPES = {
     "bt_tiling_prepass_destroy": (None, [_vp]),
     "bt_tiling_prepass_run": (_i32, [_vp, _P(ViewStateC)]),
     "bt_tiling_prepass_run_plain": (_i32, [_vp, _P(ViewStateC)]),
+    "bt_tiling_prepass_run_unordered": (_i32, [_vp, _P(ViewStateC)]),
+    "bt_tiling_prepass_set_window": (_i32, [_vp, _u32]),
     "bt_tiling_prepass_buffers": (_i32, [_vp, _P(_vp), _P(_vp)]),
     "bt_tiling_prepass_read": (_i32, [_vp, _P(TileCoordinateC), _u32, _P(_u32), _P(IndirectC)]),
     "bt_terrain_view_config_default": (None, [_P(TerrainViewConfigC)]),

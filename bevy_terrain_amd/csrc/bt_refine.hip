@@ -23,8 +23,11 @@ struct bt_tiling_prepass {
     bt_tile_coordinate* temporary_tiles = nullptr;
     bt_tile_coordinate* final_tiles = nullptr;
     bt_indirect* indirect = nullptr;
-    uint32_t* counters = nullptr;  // [0] final count, [1] overflow flag, [2] tiles visited, [3] passes
+    uint32_t* counters = nullptr;  // [0] final count, [1] overflow flag, [2] tiles visited, [3] passes; unordered form: [4] ticket, [8..40) tiles visited per LOD, [40..72) dividing tiles per LOD
     unsigned long long* bits = nullptr;  // divide bits of every (side, lod) window (allocated on first use)
+    int window = 0;                      // window radius of the unordered form (0 = the default, kWinK)
+    bool unordered = false;              // the last run was the unordered form: read() derives counters [1..3] from the per-LOD counts
+    uint32_t unordered_capacity = 0;
 };
 
 namespace bt {
@@ -139,28 +142,161 @@ constexpr uint32_t kMaxLods = 32;
 constexpr uint32_t kFrontierCap = 2048;                      // tiles of a pass kept in LDS
 
 // first tile (x, y) of the window of (side, lod): centred on the view's tile of that LOD, clamped into the face
-__device__ __forceinline__ void window_origin(const bt_view_state& v, uint32_t side, uint32_t lod, int& ox, int& oy) {
+__device__ __forceinline__ void window_origin(const bt_view_state& v, uint32_t side, uint32_t lod, int& ox, int& oy, int radius = kWinK) {
     Coordinate vc{side, v.origin_lod, uint32_t(v.sides[side].view_xy[0]), uint32_t(v.sides[side].view_xy[1]), v.sides[side].view_uv[0], v.sides[side].view_uv[1]};
     coordinate_change_lod(vc, lod);
     const int last = int((1u << lod) - 1u);  // lod <= 31
     const int cx = min(max(int(vc.x), 0), last), cy = min(max(int(vc.y), 0), last);
-    ox = cx - kWinK;
-    oy = cy - kWinK;
+    ox = cx - radius;
+    oy = cy - radius;
 }
 
 // lods: LODs 0 .. lods - 1 get their bits (the host's estimate of how deep this view can refine; anything deeper is
 // evaluated in place by the ordered kernel — an estimate can only cost time, never change the result)
-__global__ __launch_bounds__(256) void tiling_divide_bits_kernel(bt_view_state view, uint32_t lods, unsigned long long* __restrict__ bits) {
-    const uint32_t chunk = blockIdx.x % kWinChunks, lod = (blockIdx.x / kWinChunks) % lods, side = blockIdx.x / (kWinChunks * lods);
+constexpr uint32_t kCntTicket = 4, kCntVisited = 8, kCntDivide = 40, kCounterWords = 72;  // (bt_tiling_prepass::counters)
+
+// radius <= kWinK: the window actually used (storage is laid out for kWinK); counters != nullptr: also resets the counters and
+// the indirect arguments the unordered collector (next launch) accumulates into
+__global__ __launch_bounds__(256) void tiling_divide_bits_kernel(bt_view_state view, uint32_t lods, int radius, unsigned long long* __restrict__ bits,
+                                                                 uint32_t* __restrict__ counters, bt_indirect* __restrict__ indirect) {
+    const uint32_t W = 2u * uint32_t(radius) + 1u, chunks = (W * W + 255u) / 256u;
+    const uint32_t chunk = blockIdx.x % chunks, lod = (blockIdx.x / chunks) % lods, side = blockIdx.x / (chunks * lods);
+    if (counters && blockIdx.x == 0) {
+        if (threadIdx.x < kCounterWords) counters[threadIdx.x] = 0;
+        if (threadIdx.x == 0) *indirect = {0u, 1u, 0u, 0u};  // prepare_render's instance_count / bases; the vertex count accumulates
+    }
     if (lod > view.refinement_count) return;
     int ox, oy;
-    window_origin(view, side, lod, ox, oy);
+    window_origin(view, side, lod, ox, oy, radius);
     const uint32_t b = chunk * 256u + threadIdx.x;
-    const int tx = ox + int(b % kWinW), ty = oy + int(b / kWinW), last = int((1u << lod) - 1u);
+    const int tx = ox + int(b % W), ty = oy + int(b / W), last = int((1u << lod) - 1u);
     bool divide = false;
-    if (b < kWinBits && tx >= 0 && ty >= 0 && tx <= last && ty <= last) divide = should_be_divided(view, bt_tile_coordinate{side, lod, uint32_t(tx), uint32_t(ty)});
+    if (b < W * W && tx >= 0 && ty >= 0 && tx <= last && ty <= last) divide = should_be_divided(view, bt_tile_coordinate{side, lod, uint32_t(tx), uint32_t(ty)});
     const unsigned long long word = __ballot(divide);
     if ((threadIdx.x & 63u) == 0) bits[(size_t(side) * kMaxLods + lod) * kWinWords + chunk * 4u + (threadIdx.x >> 6)] = word;
+}
+
+// ---- the unordered form: the final SET straight from the bits ---------------------------------------------------------
+// The reference appends final tiles in the arrival order of global atomics (refine_tiles.wgsl:13-15, 41): its contract is the
+// set, not the order.  With every divide test known, membership needs no passes at all: a tile is visited iff all its
+// ancestors divide, and it is final iff it is visited, does not divide itself and its LOD is a pass that runs
+// (lod <= refinement_count; the children of tiles that still divide in the last pass are dropped, as in the reference).
+// One thread per window tile walks its <= 31 ancestors' bits in LDS; finals are appended with one atomic per wave.  A
+// visited, dividing tile whose child lies outside the child LOD's window (or deeper than the LODs that got bits) owns that
+// child's whole subtree: a stackless depth-first walk evaluating should_be_divided in place, skipping anything that is
+// inside a window (those tiles have their own thread) — so every tile is decided exactly once, whatever the window size.
+// prepare_render's vertex count (prepare_prepass.wgsl:38-44) accumulates with the same reservations; per-LOD visit / divide
+// counts let bt_tiling_prepass_read give the overflow verdict of the reference's buffers (a pass needs parents + children
+// <= N, prepare_prepass.wgsl:25-36; the final list <= N).  No ticket, no fence: a "last workgroup" protocol made ~1500
+// same-address atomics the longest thing in the kernel.
+
+struct WindowBits {
+    const unsigned long long* bits;  // LDS: [lod][kWinWords] of one side
+    const int2* origin;              // LDS: [lod]
+    uint32_t lods;
+    int W;
+    __device__ __forceinline__ bool inside(uint32_t lod, uint32_t x, uint32_t y, uint32_t& b) const {
+        if (lod >= lods) return false;
+        const int bx = int(x) - origin[lod].x, by = int(y) - origin[lod].y;
+        b = uint32_t(by * W + bx);
+        return bx >= 0 && by >= 0 && bx < W && by < W;
+    }
+    __device__ __forceinline__ bool bit(uint32_t lod, uint32_t b) const { return (bits[lod * kWinWords + (b >> 6)] >> (b & 63u)) & 1ull; }
+};
+
+__global__ __launch_bounds__(256) void tiling_collect_kernel(bt_view_state view, uint32_t lods, int radius, uint32_t capacity,
+                                                             const unsigned long long* __restrict__ bits, bt_tile_coordinate* __restrict__ final_tiles,
+                                                             bt_indirect* __restrict__ indirect, uint32_t* __restrict__ counters) {
+    __shared__ unsigned long long s_bits[kMaxLods * kWinWords];
+    __shared__ int2 s_origin[kMaxLods];
+    const uint32_t W = 2u * uint32_t(radius) + 1u, chunks = (W * W + 255u) / 256u;
+    const uint32_t chunk = blockIdx.x % chunks, lod = (blockIdx.x / chunks) % lods, side = blockIdx.x / (chunks * lods);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, rc = view.refinement_count;
+    if (lod > rc) return;
+    {
+        if (tid < lods) {
+            int ox, oy;
+            window_origin(view, side, tid, ox, oy, radius);
+            s_origin[tid] = int2{ox, oy};
+        }
+        const uint32_t words = min(lod + 2u, lods) * kWinWords;  // ancestors, the tile itself, its children's window
+        for (uint32_t i = tid; i < words; i += 256u) s_bits[i] = bits[size_t(side) * kMaxLods * kWinWords + i];
+    }
+    __syncthreads();
+    {
+        const WindowBits wb{s_bits, s_origin, lods, int(W)};
+        const uint32_t b = chunk * 256u + tid;
+        const int tx = s_origin[lod].x + int(b % W), ty = s_origin[lod].y + int(b / W), last = int((1u << lod) - 1u);
+        bool reach = b < W * W && tx >= 0 && ty >= 0 && tx <= last && ty <= last;
+        for (uint32_t a = lod; reach && a-- > 0;) {  // all ancestors divide (order is irrelevant; an ancestor outside its window is evaluated in place)
+            const uint32_t ax = uint32_t(tx) >> (lod - a), ay = uint32_t(ty) >> (lod - a);
+            uint32_t ab;
+            reach = wb.inside(a, ax, ay, ab) ? wb.bit(a, ab) : should_be_divided(view, bt_tile_coordinate{side, a, ax, ay});
+        }
+        const bool divide = reach && wb.bit(lod, b);
+        const bool fin = reach && !divide;
+        // finals: one reservation per wave
+        const unsigned long long ballot_f = __ballot(fin), ballot_r = __ballot(reach), ballot_d = __ballot(divide);
+        uint32_t base = 0;
+        if (lane == 0) {
+            if (ballot_f) {
+                base = atomicAdd(&counters[0], uint32_t(__popcll(ballot_f)));
+                atomicAdd(&indirect->vertex_count, view.vertices_per_tile * uint32_t(__popcll(ballot_f)));
+            }
+            if (ballot_r) atomicAdd(&counters[kCntVisited + lod], uint32_t(__popcll(ballot_r)));
+            if (ballot_d) atomicAdd(&counters[kCntDivide + lod], uint32_t(__popcll(ballot_d)));
+        }
+        base = __shfl(base, 0);
+        if (fin) {
+            const uint32_t fi = base + uint32_t(__popcll(ballot_f & ((1ull << lane) - 1ull)));
+            if (fi < capacity) final_tiles[fi] = bt_tile_coordinate{side, lod, uint32_t(tx), uint32_t(ty)};
+        }
+        // children no thread owns: their subtrees, depth first, without a stack (child order 0..3 = (x & 1) | (y & 1) << 1)
+        if (divide && lod < rc) {
+            for (uint32_t i = 0; i < 4; i++) {
+                uint32_t nl = lod + 1u, nx = (uint32_t(tx) << 1) + (i & 1u), ny = (uint32_t(ty) << 1) + (i >> 1), nb;
+                if (wb.inside(nl, nx, ny, nb)) continue;
+                for (;;) {
+                    bool descend = false;
+                    if (!wb.inside(nl, nx, ny, nb)) {
+                        atomicAdd(&counters[kCntVisited + nl], 1u);
+                        const bt_tile_coordinate node{side, nl, nx, ny};
+                        if (should_be_divided(view, node)) {
+                            atomicAdd(&counters[kCntDivide + nl], 1u);
+                            descend = nl < rc;
+                        } else {
+                            const uint32_t fi = atomicAdd(&counters[0], 1u);
+                            atomicAdd(&indirect->vertex_count, view.vertices_per_tile);
+                            if (fi < capacity) final_tiles[fi] = node;
+                        }
+                    }
+                    if (descend) {
+                        nl++;
+                        nx <<= 1;
+                        ny <<= 1;
+                        continue;
+                    }
+                    bool done = false;
+                    for (;;) {  // next sibling, or up until there is one; back at the start level: finished
+                        if (nl == lod + 1u) {
+                            done = true;
+                            break;
+                        }
+                        const uint32_t c = (nx & 1u) | ((ny & 1u) << 1);
+                        if (c < 3u) {
+                            nx = (nx & ~1u) | ((c + 1u) & 1u);
+                            ny = (ny & ~1u) | ((c + 1u) >> 1);
+                            break;
+                        }
+                        nl--;
+                        nx >>= 1;
+                        ny >>= 1;
+                    }
+                    if (done) break;
+                }
+            }
+        }
+    }
 }
 
 // kAssist = false: the whole schedule from the arithmetic alone (the plain kernel: checker, and fallback for odd views).
@@ -323,8 +459,8 @@ bt_status bt_tiling_prepass_create(bt_ctx* ctx, uint32_t geometry_tile_count, bt
     hipError_t e = hipMalloc((void**)&t->temporary_tiles, sizeof(bt_tile_coordinate) * size_t(geometry_tile_count));
     if (e == hipSuccess) e = hipMalloc((void**)&t->final_tiles, sizeof(bt_tile_coordinate) * size_t(geometry_tile_count));
     if (e == hipSuccess) e = hipMalloc((void**)&t->indirect, sizeof(bt_indirect));
-    if (e == hipSuccess) e = hipMalloc((void**)&t->counters, 16 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemsetAsync(t->counters, 0, 16 * sizeof(uint32_t), ctx->stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&t->counters, kCounterWords * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(t->counters, 0, kCounterWords * sizeof(uint32_t), ctx->stream);
     if (e != hipSuccess) {
         bt_tiling_prepass_destroy(t);
         return hip_fail(e, "tiling prepass buffers");
@@ -344,49 +480,83 @@ void bt_tiling_prepass_destroy(bt_tiling_prepass* t) {
     delete t;
 }
 
-bt_status bt_tiling_prepass_run(bt_tiling_prepass* t, const bt_view_state* view) {
+namespace {
+// How deep can this view refine?  A tile of LOD l divides only within subdivision_distance / 2^l of the view, and nothing is
+// closer to the view than its height over the (approximate) surface: beyond l = log2(subdivision_distance / height) no tile
+// divides.  An ESTIMATE (f32 on the host, the surface taken as the unit sphere / plane of the mesh transform): it only
+// decides how many LODs get their bits up front — anything deeper is evaluated in place, so it can cost time, never change
+// the result.
+uint32_t estimate_lods(const bt_view_state* view) {
+    uint32_t lods = kMaxLods;
+    const float* m = view->world_from_local;
+    const float* it = view->local_from_world_transpose;
+    const float d[3] = {view->world_position[0] - m[9], view->world_position[1] - m[10], view->world_position[2] - m[11]};
+    float local[3];
+    for (int i = 0; i < 3; i++) local[i] = it[3 * i] * d[0] + it[3 * i + 1] * d[1] + it[3 * i + 2] * d[2];
+    const float sx = sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]), sy = sqrtf(m[3] * m[3] + m[4] * m[4] + m[5] * m[5]);
+    const float height = view->spherical ? (sqrtf(local[0] * local[0] + local[1] * local[1] + local[2] * local[2]) - 1.0f) * std::min(sx, sy) : local[1] * sy;
+    const float clearance = 0.5f * fabsf(height - view->approximate_height);
+    if (clearance > 0.0f && view->subdivision_distance > 0.0f && std::isfinite(clearance)) {
+        const float deepest = log2f(view->subdivision_distance / clearance);
+        if (deepest < 30.0f) lods = uint32_t(std::max(0.0f, ceilf(deepest))) + 2u;
+    }
+    return std::min(std::min(lods, kMaxLods), view->refinement_count + 1u);
+}
+
+bt_status prepass_check(bt_tiling_prepass* t, const bt_view_state* view) {
     if (!t || !view) return BT_ERR_INVALID_ARGUMENT;
-    if (view->refinement_count > 31) {
-        set_error("refinement_count %u > 31 (tile x/y are u32)", view->refinement_count);
+    if (view->refinement_count > 31 || view->origin_lod > 31) {
+        set_error("refinement_count %u / origin_lod %u > 31 (tile x/y are u32)", view->refinement_count, view->origin_lod);
         return BT_ERR_INVALID_ARGUMENT;
     }
-    if (view->origin_lod > 31) return BT_ERR_INVALID_ARGUMENT;
     BT_HIP(hipSetDevice(t->ctx->device));
-    const uint32_t capacity = std::min(t->capacity, view->geometry_tile_count ? view->geometry_tile_count : t->capacity);
-    const uint32_t sides = view->spherical ? 6u : 1u;
-    const size_t lds = size_t(sides) * kMaxLods * (kWinWords * sizeof(unsigned long long) + sizeof(int2)) + 2 * size_t(kFrontierCap) * sizeof(bt_tile_coordinate);
     if (!t->bits) {
         BT_HIP(hipMalloc((void**)&t->bits, 6 * size_t(kMaxLods) * kWinWords * sizeof(unsigned long long)));
         BT_HIP(hipMemsetAsync(t->bits, 0, 6 * size_t(kMaxLods) * kWinWords * sizeof(unsigned long long), t->ctx->stream));
         BT_HIP(hipFuncSetAttribute((const void*)tiling_prepass_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, int(6 * kMaxLods * (kWinWords * 8 + 8) + 2 * kFrontierCap * 16)));
     }
-    // How deep can this view refine?  A tile of LOD l divides only within subdivision_distance / 2^l of the view, and nothing is
-    // closer to the view than its height over the (approximate) surface: beyond l = log2(subdivision_distance / height) no tile
-    // divides.  An ESTIMATE (f32 on the host, the surface taken as the unit sphere / plane of the mesh transform): it only
-    // decides how many LODs get their bits up front and whether the two-launch form pays at all — shallow views (few
-    // hundred tiles) are faster in the plain kernel, which saves them the second launch.
-    uint32_t lods = kMaxLods;
-    {
-        const float* m = view->world_from_local;
-        const float* it = view->local_from_world_transpose;
-        const float d[3] = {view->world_position[0] - m[9], view->world_position[1] - m[10], view->world_position[2] - m[11]};
-        float local[3];
-        for (int i = 0; i < 3; i++) local[i] = it[3 * i] * d[0] + it[3 * i + 1] * d[1] + it[3 * i + 2] * d[2];
-        const float sx = sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]), sy = sqrtf(m[3] * m[3] + m[4] * m[4] + m[5] * m[5]);
-        const float height = view->spherical ? (sqrtf(local[0] * local[0] + local[1] * local[1] + local[2] * local[2]) - 1.0f) * std::min(sx, sy) : local[1] * sy;
-        const float clearance = 0.5f * fabsf(height - view->approximate_height);
-        if (clearance > 0.0f && view->subdivision_distance > 0.0f && std::isfinite(clearance)) {
-            const float deepest = log2f(view->subdivision_distance / clearance);
-            if (deepest < 30.0f) lods = uint32_t(std::max(0.0f, ceilf(deepest))) + 2u;
-        }
-        lods = std::min(std::min(lods, kMaxLods), view->refinement_count + 1u);
-    }
+    return BT_OK;
+}
+}  // namespace
+
+bt_status bt_tiling_prepass_run(bt_tiling_prepass* t, const bt_view_state* view) {
+    if (bt_status s = prepass_check(t, view)) return s;
+    const uint32_t capacity = std::min(t->capacity, view->geometry_tile_count ? view->geometry_tile_count : t->capacity);
+    const uint32_t sides = view->spherical ? 6u : 1u;
+    const size_t lds = size_t(sides) * kMaxLods * (kWinWords * sizeof(unsigned long long) + sizeof(int2)) + 2 * size_t(kFrontierCap) * sizeof(bt_tile_coordinate);
+    // shallow views (few hundred tiles) are faster in the plain kernel, which saves them the second launch
+    const uint32_t lods = estimate_lods(view);
     if (lods < 12u) return bt_tiling_prepass_run_plain(t, view);
     // launch 1: every divide test that can matter (independent, chip-wide); launch 2: the ordered schedule over the bits
-    tiling_divide_bits_kernel<<<sides * lods * kWinChunks, 256, 0, t->ctx->stream>>>(*view, lods, t->bits);
+    tiling_divide_bits_kernel<<<sides * lods * kWinChunks, 256, 0, t->ctx->stream>>>(*view, lods, kWinK, t->bits, nullptr, nullptr);
     tiling_prepass_kernel<true><<<1, kThreads, lds, t->ctx->stream>>>(*view, capacity, t->temporary_tiles, t->final_tiles, t->indirect, t->counters, t->bits, lods);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "tiling_prepass_kernel");
+    t->unordered = false;
+    return BT_OK;
+}
+
+// The unordered form: the same SET of final tiles and the same indirect arguments, in whatever order the waves arrive (the
+// reference's own order is the arrival order of its atomics).  Two chip-wide launches, no pass chain: flat ~10 us whatever the
+// frame.  temporary_tiles is not written.
+bt_status bt_tiling_prepass_run_unordered(bt_tiling_prepass* t, const bt_view_state* view) {
+    if (bt_status s = prepass_check(t, view)) return s;
+    const uint32_t capacity = std::min(t->capacity, view->geometry_tile_count ? view->geometry_tile_count : t->capacity);
+    const uint32_t sides = view->spherical ? 6u : 1u, lods = estimate_lods(view);
+    const int radius = t->window ? t->window : kWinK;
+    const uint32_t W = 2u * uint32_t(radius) + 1u, chunks = (W * W + 255u) / 256u;
+    tiling_divide_bits_kernel<<<sides * lods * chunks, 256, 0, t->ctx->stream>>>(*view, lods, radius, t->bits, t->counters, t->indirect);
+    tiling_collect_kernel<<<sides * lods * chunks, 256, 0, t->ctx->stream>>>(*view, lods, radius, capacity, t->bits, t->final_tiles, t->indirect, t->counters);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "tiling_collect_kernel");
+    t->unordered = true;
+    t->unordered_capacity = capacity;
+    return BT_OK;
+}
+
+bt_status bt_tiling_prepass_set_window(bt_tiling_prepass* t, uint32_t radius) {
+    if (!t || radius > uint32_t(kWinK)) return BT_ERR_INVALID_ARGUMENT;
+    t->window = int(radius);
     return BT_OK;
 }
 
@@ -403,6 +573,7 @@ bt_status bt_tiling_prepass_run_plain(bt_tiling_prepass* t, const bt_view_state*
     tiling_prepass_kernel<false><<<1, kThreads, 0, t->ctx->stream>>>(*view, capacity, t->temporary_tiles, t->final_tiles, t->indirect, t->counters, nullptr, 0u);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "tiling_prepass_kernel");
+    t->unordered = false;
     return BT_OK;
 }
 
@@ -415,10 +586,15 @@ bt_status bt_tiling_prepass_buffers(const bt_tiling_prepass* t, void** final_til
 
 bt_status bt_tiling_prepass_read(bt_tiling_prepass* t, bt_tile_coordinate* out, uint32_t cap, uint32_t* count, bt_indirect* indirect) {
     if (!t || !count) return BT_ERR_INVALID_ARGUMENT;
-    uint32_t counters[4] = {0, 0, 0, 0};
+    uint32_t counters[kCounterWords] = {0};
     BT_HIP(hipMemcpyAsync(counters, t->counters, sizeof counters, hipMemcpyDeviceToHost, t->ctx->stream));
     if (indirect) BT_HIP(hipMemcpyAsync(indirect, t->indirect, sizeof(bt_indirect), hipMemcpyDeviceToHost, t->ctx->stream));
     BT_HIP(hipStreamSynchronize(t->ctx->stream));
+    if (t->unordered) {  // the reference's buffers: a pass needs its parents + the children appended, the final list its tiles
+        counters[1] = counters[0] > t->unordered_capacity;
+        for (uint32_t l = 0; l < kMaxLods; l++)
+            if (uint64_t(counters[kCntVisited + l]) + 4ull * counters[kCntDivide + l] > t->unordered_capacity) counters[1] = 1;
+    }
     *count = counters[0];
     if (counters[1]) {
         set_error("tiling prepass overflowed its %u-entry tile buffers", t->capacity);

@@ -74,14 +74,21 @@ class TilingPrepass:
         _ffi.check(_ffi.lib().bt_tiling_prepass_create(device._h, geometry_tile_count, C.byref(h)))
         self._h = h
 
-    def run(self, view: _ffi.ViewStateC, *, plain: bool = False):
-        """plain=False: two launches — the divide tests of every tile near the view at every LOD up front (chip-wide), then the
-        ordered schedule over those bits.  plain=True: one launch that evaluates each test inside its pass.  Same list, same
-        order (that of the reference run with invocations taken in id order)."""
-        if plain:
+    def run(self, view: _ffi.ViewStateC, *, plain: bool = False, unordered: bool = False):
+        """default: two launches — the divide tests of every tile near the view at every LOD up front (chip-wide), then the
+        ordered schedule over those bits.  plain=True: one launch that evaluates each test inside its pass.  Both: the list in
+        the order of the reference run with invocations taken in id order.  unordered=True: the same SET (the reference's
+        contract: its order is the arrival order of an atomic) from two chip-wide launches without the chain of passes."""
+        if unordered:
+            _ffi.check(_ffi.lib().bt_tiling_prepass_run_unordered(self._h, C.byref(view)))
+        elif plain:
             _ffi.check(_ffi.lib().bt_tiling_prepass_run_plain(self._h, C.byref(view)))
         else:
             _ffi.check(_ffi.lib().bt_tiling_prepass_run(self._h, C.byref(view)))
+
+    def set_window(self, radius: int):
+        """window radius of the unordered form (1..28, 0 = default): a tuning / test knob, results do not depend on it"""
+        _ffi.check(_ffi.lib().bt_tiling_prepass_set_window(self._h, radius))
 
     def read(self) -> Tuple[np.ndarray, Tuple[int, int, int, int]]:
         """(final tiles as an (n, 4) uint32 array [side, lod, x, y] in append order, indirect draw args)."""

@@ -396,9 +396,20 @@ bt_status bt_tiling_prepass_run(bt_tiling_prepass* t, const bt_view_state* view)
  * those bits out of LDS.  This is the single-launch form that evaluates each test inside its pass: the same list in the
  * same order, ~3x the worst-case latency; the checker of the two-launch form. */
 bt_status bt_tiling_prepass_run_plain(bt_tiling_prepass* t, const bt_view_state* view);
+/* The reference's contract is the SET of final tiles: refine_tiles appends them in the arrival order of a global atomic
+ * (shaders/tiling_prepass/refine_tiles.wgsl:13-15, 41).  This form produces that set (and the same indirect arguments and
+ * overflow verdict) in arrival order too, without the chain of passes: after the chip-wide divide tests a second chip-wide
+ * launch decides every tile from its ancestors' bits.  Flat ~10 us per frame whatever the view; temporary_tiles is not
+ * written.  The two entries above additionally reproduce the order of a run with invocations taken in id order. */
+bt_status bt_tiling_prepass_run_unordered(bt_tiling_prepass* t, const bt_view_state* view);
+/* Window radius (tiles around the view's tile at every LOD that get their divide test up front) of the unordered form:
+ * 1..28, 0 = default (28).  A tuning / test knob: results do not depend on it (tiles outside the windows are evaluated
+ * in place). */
+bt_status bt_tiling_prepass_set_window(bt_tiling_prepass* t, uint32_t radius);
 /* Device buffers a renderer binds: final_tiles (bt_tile_coordinate[]), indirect args, counters. */
 bt_status bt_tiling_prepass_buffers(const bt_tiling_prepass* t, void** final_tiles_device, void** indirect_device);
-/* Synchronises and copies the final tile list (in the reference's sequential append order). */
+/* Synchronises and copies the final tile list (bt_tiling_prepass_run / _run_plain: in the reference's sequential append
+ * order; _run_unordered: arrival order). */
 bt_status bt_tiling_prepass_read(bt_tiling_prepass* t, bt_tile_coordinate* final_tiles_host, uint32_t cap,
                                  uint32_t* count, bt_indirect* indirect);
 

@@ -129,12 +129,7 @@ def test_random_views_equal_the_oracle_list(device, seed):
             assert np.array_equal(ours, final) or len(dropped) > 0, (seed, frame)
 
 
-@pytest.mark.parametrize("kind", ["planar", "sphere", "ellipsoid"])
-def test_two_launch_form_equals_the_plain_kernel_and_the_oracle(device, kind):
-    """bt_tiling_prepass_run (divide bits of every window up front, then the ordered schedule out of LDS) against
-    bt_tiling_prepass_run_plain (every test evaluated inside its pass) and the oracle: the same LIST in the same order, the same
-    indirect args — from far out (a handful of tiles) to 17 k tiles, cameras over face edges and cube corners, views whose
-    tiles leave their windows (huge subdivision tolerance), and small LDS-overflowing / LDS-resident passes"""
+def form_positions(kind):
     if kind == "planar":
         model = bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 250.0)
         positions = list(spiral(20, 700.0, 900.0, 20.0)) + [(3.0, 260.0, -7.0), (5000.0, 10000.0, 0.0), (-499.9, 1.0, 499.9), (2000.0, 5.0, 0.0)]
@@ -149,6 +144,85 @@ def test_two_launch_form_equals_the_plain_kernel_and_the_oracle(device, kind):
             positions.append(tuple(d * (6371000.0 + 10 ** rng.uniform(1.5, 7.2))))
         r = 6371000.0 + 500.0
         positions += [(r / math.sqrt(3),) * 3, (r / math.sqrt(2), r / math.sqrt(2), 0.0), (0.0, r, 0.0), (-r, 30.0, -40.0)]  # corner, edge, face centres
+    return model, positions
+
+
+def sorted_rows(a):
+    return a[np.lexsort(a.T[::-1])]
+
+
+@pytest.mark.parametrize("radius", [0, 9, 2])
+@pytest.mark.parametrize("kind", ["planar", "sphere", "ellipsoid"])
+def test_unordered_form_is_the_same_set(device, kind, radius):
+    """bt_tiling_prepass_run_unordered (every tile decided from its ancestors' divide bits, no passes; the reference's
+    contract is the set — its own order is the arrival order of an atomic, refine_tiles.wgsl:13-15) against the oracle's
+    sequential run: the same tiles, each exactly once, the same indirect arguments.  Window radius 0 = the default (28);
+    9 and 2 push most of the tree through the in-place depth-first walk of the tiles no window covers."""
+    model, positions = form_positions(kind)
+    total = 0
+    for tolerance, cfg_tiles in ((0.1, 400000), (3.0, 900000)):
+        cfg = bt.TerrainViewConfig(geometry_tile_count=cfg_tiles, subdivision_tolerance=tolerance)
+        prepass = bt.TilingPrepass(device, cfg.geometry_tile_count)
+        prepass.set_window(radius)
+        step = (1 if tolerance == 0.1 else 3) * (1 if radius != 2 else 2)
+        for pos in positions[::step]:
+            v = bt.make_view_state(model, cfg, pos)
+            exp, exp_indirect, _ = O.refine(oracle_view(v))
+            for _ in range(2):
+                prepass.run(v, unordered=True)
+                ours, indirect = prepass.read()
+                assert len(ours) == len(exp) and np.array_equal(sorted_rows(ours), sorted_rows(exp)), (kind, pos, tolerance, radius)
+                assert list(indirect) == exp_indirect
+            total += len(ours)
+        prepass.close()
+    assert total > 5000
+
+
+def test_unordered_form_keeps_the_pass_limit_and_the_overflow_verdict(device):
+    """refinement_count bounds the LODs and drops the children of tiles that still divide in the last pass; the overflow
+    verdict (a pass's parents + children, or the final list, exceed the buffers) is the ordered kernel's for every capacity"""
+    model = bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 0.0)
+    cfg = bt.TerrainViewConfig(geometry_tile_count=100000, refinement_count=3, morph_distance=1.0)
+    v = bt.make_view_state(model, cfg, (10.0, 5.0, 10.0))
+    prepass = bt.TilingPrepass(device, cfg.geometry_tile_count)
+    prepass.run(v, unordered=True)
+    ours, indirect = prepass.read()
+    exp, exp_indirect, passes = O.refine(oracle_view(v))
+    assert np.array_equal(sorted_rows(ours), sorted_rows(exp)) and list(indirect) == exp_indirect
+    assert ours[:, 1].max() <= 3 and len(ours) < sum(passes)
+    prepass.close()
+
+    cfg = bt.TerrainViewConfig(geometry_tile_count=100000)
+    v_full = bt.make_view_state(model, cfg, (40.0, 30.0, -20.0))
+    exp, _, passes = O.refine(oracle_view(v_full))
+    assert 100 < len(exp) < 20000
+    verdicts = []
+    for capacity in list(range(8, 2 * len(exp) + 64, max(13, len(exp) // 37))):
+        prepass = bt.TilingPrepass(device, capacity)
+        cfg_n = bt.TerrainViewConfig(geometry_tile_count=capacity)
+        v = bt.make_view_state(model, cfg_n, (40.0, 30.0, -20.0))
+        got = []
+        for unordered in (False, True):
+            prepass.run(v, unordered=unordered)
+            try:
+                tiles, _ = prepass.read()
+                got.append(len(tiles))
+            except bt.BtError as e:
+                assert e.status == -7
+                got.append(None)
+        assert got[0] == got[1], (capacity, got)
+        verdicts.append(got[0] is None)
+        prepass.close()
+    assert any(verdicts) and not all(verdicts)
+
+
+@pytest.mark.parametrize("kind", ["planar", "sphere", "ellipsoid"])
+def test_two_launch_form_equals_the_plain_kernel_and_the_oracle(device, kind):
+    """bt_tiling_prepass_run (divide bits of every window up front, then the ordered schedule out of LDS) against
+    bt_tiling_prepass_run_plain (every test evaluated inside its pass) and the oracle: the same LIST in the same order, the same
+    indirect args — from far out (a handful of tiles) to 17 k tiles, cameras over face edges and cube corners, views whose
+    tiles leave their windows (huge subdivision tolerance), and small LDS-overflowing / LDS-resident passes"""
+    model, positions = form_positions(kind)
     total = outside_hits = 0
     for tolerance, cfg_tiles in ((0.1, 400000), (3.0, 900000)):  # tolerance 3: tiles divide up to ~35 tiles from the view — beyond the windows
         cfg = bt.TerrainViewConfig(geometry_tile_count=cfg_tiles, subdivision_tolerance=tolerance)

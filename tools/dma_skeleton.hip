@@ -181,7 +181,13 @@ template <int ARITH, bool LOADER_WAVE> __global__ __launch_bounds__(LOADER_WAVE 
 #pragma unroll
         for (uint32_t r = 0; r < 8; r++) out[r] = shade<ARITH>(tex(r + 1, o00, s00), tex(r + 1, o01, s01), tex(r + 1, o10, s10), tex(r + 1, o11, s11), carry, 0.125f * float(r));
         const uint32_t ko = (k + rot) & 63u;
-        if (stores & 1) {
+        if ((stores & 1) && (stores & 256)) {
+            // (256: a thread = 4 texture columns x 4 rows — row-ALIGNED 8-byte stores, two waves per 1 KB row, half the store instructions)
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            u32x2* row = reinterpret_cast<u32x2*>(tiles + uint64_t(tx * 32 + ty) * 524288) + (tid & 127u);
+#pragma unroll
+            for (uint32_t r = 0; r < 4; r++) row[(ko * 8 + (tid >> 7) * 4 + r) * 128] = u32x2{out[2 * r], out[2 * r + 1]};
+        } else if (stores & 1) {
 #pragma unroll
             for (uint32_t r = 0; r < 8; r++) d5[(ko * 8 + r) * 256] = out[r];
         }
@@ -230,6 +236,11 @@ int main() {
     }
     for (int f : {4 + 1, 4 + 1 + 32, 4 + 1 + 8, 4 + 3, 1, 1 + 32, 1 + 8, 1 + 16, 1 + 8 + 16, 3 + 8 + 16, 3 + 8 + 16 + 32})
         printf("V0 flags %2d (1 finest, 2 parents, 4 no loads, 8 nt stores, 16 nt loads, 32 aligned rows): %6.1f us\n", f, timeit([&] { v0<0><<<1024, 256>>>(src, tiles, parents, f); }));
+    for (int a : {0, 24}) {
+        printf("arith %2d, loads + finest + parents: dword per lane (4-byte shifted) V1 %6.1f, 8 bytes per lane row-aligned V1 %6.1f us\n", a,
+               a ? timeit([&] { v12<24, false><<<1024, 256>>>(src, tiles, parents, 3); }) : timeit([&] { v12<0, false><<<1024, 256>>>(src, tiles, parents, 3); }),
+               a ? timeit([&] { v12<24, false><<<1024, 256>>>(src, tiles, parents, 3 + 256); }) : timeit([&] { v12<0, false><<<1024, 256>>>(src, tiles, parents, 3 + 256); }));
+    }
     for (int f : {3, 3 + 64, 3 + 128, 1, 1 + 64, 1 + 128})
         printf("V1 / V2 stores %3d (64: output rows rotated by tile row, 128: by tile row and column): %6.1f  %6.1f us\n", f,
                timeit([&] { v12<0, false><<<1024, 256>>>(src, tiles, parents, f); }), timeit([&] { v12<0, true><<<1024, 320>>>(src, tiles, parents, f); }));

@@ -15,7 +15,21 @@ import numpy as np
 import bevy_terrain_amd as bt
 
 
-def measure(device):
+def time_frames(device, prepass, views, **form):
+    """device time per frame: the best of three repeats of each frame (single samples carry the odd 10-20 us of launch jitter)"""
+    ms = []
+    for v in views:
+        best = None
+        for _ in range(3):
+            device.timer_begin()
+            prepass.run(v, **form)
+            t = device.timer_end()
+            best = t if best is None or t < best else best
+        ms.append(best)
+    return ms
+
+
+def measure(device, sweep=False):
     out = {}
     for name, model, positions in (
         ("planar_side1000", bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 250.0),
@@ -31,24 +45,36 @@ def measure(device):
         for v in views[:4]:
             prepass.run(v)
         device.synchronize()
-        counts, ms = [], []
+        ms = time_frames(device, prepass, views)
+        counts = []
         for v in views:
-            device.timer_begin()
             prepass.run(v)
-            ms.append(device.timer_end())
-            tiles, _ = prepass.read()
-            counts.append(len(tiles))
+            counts.append(len(prepass.read()[0]))
         # the plain single-launch form (every divide test inside its pass): the checker, and what rounds 1-2 shipped
         for v in views[:4]:
             prepass.run(v, plain=True)
         device.synchronize()
-        ms_p, same = [], True
+        ms_p, same = time_frames(device, prepass, views, plain=True), True
         for v, n in zip(views, counts):
-            device.timer_begin()
             prepass.run(v, plain=True)
-            ms_p.append(device.timer_end())
-            tiles, _ = prepass.read()
-            same = same and len(tiles) == n
+            same = same and len(prepass.read()[0]) == n
+        # the unordered form (the reference's contract is the set): two chip-wide launches, no chain of passes
+        for v in views[:4]:
+            prepass.run(v, unordered=True)
+        device.synchronize()
+        ms_u, same_u = time_frames(device, prepass, views, unordered=True), True
+        for v, n in zip(views, counts):
+            prepass.run(v, unordered=True)
+            same_u = same_u and len(prepass.read()[0]) == n
+        radius_sweep = {}
+        for radius in ((8, 12, 16, 20, 24, 28) if sweep else ()):
+            prepass.set_window(radius)
+            for v in views[:4]:
+                prepass.run(v, unordered=True)
+            device.synchronize()
+            t_r = time_frames(device, prepass, views, unordered=True)
+            radius_sweep[radius] = [round(1e3 * float(np.mean(t_r)), 1), round(1e3 * float(np.max(t_r)), 1)]
+        prepass.set_window(0)
         # the CPU side of the same frame in the reference (TileTree::update over sides x lods x tree_size^2 nodes, f64):
         # here one launch + the read-back of the request / release lists (host wall time per update, synchronous)
         lods = 12
@@ -70,6 +96,9 @@ def measure(device):
         out[name] = {"frames": len(views), "us_per_frame_avg": 1e3 * float(np.mean(ms)), "us_per_frame_max": 1e3 * float(np.max(ms)),
                      "final_tiles_avg": float(np.mean(counts)), "final_tiles_max": int(np.max(counts)),
                      "launches_per_frame": 2, "reference_dispatches_per_frame": 2 * cfg.refinement_count + 3,
+                     "unordered": {"us_per_frame_avg": 1e3 * float(np.mean(ms_u)), "us_per_frame_max": 1e3 * float(np.max(ms_u)), "launches_per_frame": 2,
+                                   "same_tile_counts": bool(same_u), "window_radius_sweep_avg_max_us": radius_sweep,
+                                   "note": "bt_tiling_prepass_run_unordered: the same set in arrival order (as the reference's atomics), every tile decided from its ancestors' divide bits"},
                      "plain_single_launch": {"us_per_frame_avg": 1e3 * float(np.mean(ms_p)), "us_per_frame_max": 1e3 * float(np.max(ms_p)), "launches_per_frame": 1,
                                              "same_tile_counts": bool(same),
                                              "note": "bt_tiling_prepass_run_plain: every divide test evaluated inside the pass that needs it"}}
@@ -77,7 +106,7 @@ def measure(device):
 
 
 def main():
-    print(json.dumps({"tiling_prepass": measure(bt.Device(0))}))
+    print(json.dumps({"tiling_prepass": measure(bt.Device(0), sweep="--sweep" in sys.argv)}))
 
 
 if __name__ == "__main__":
