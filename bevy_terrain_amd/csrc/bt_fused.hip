@@ -2133,6 +2133,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         // cube: aprons that cross a face edge come from the generic stitch kernel (after everything else)
         if (spherical) {
             const uint32_t first = uint32_t(tasks.size());
+            uint64_t seam_pixels = 0;
             for (const Task* t : stitches) {
                 const uint32_t n = 1u << t->coord.lod;
                 if (t->coord.x != 0 && t->coord.y != 0 && t->coord.x != n - 1 && t->coord.y != n - 1) continue;
@@ -2147,18 +2148,22 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                     d.rel_index[i] = t->rel[i].atlas_index;
                     d.rel_side[i] = t->rel[i].coordinate.side;
                 }
-                // only the apron regions whose neighbour lives on another face: the fused kernels already wrote the rest
+                // only the apron regions whose neighbour lives on another face (the fused kernels already wrote the rest), one
+                // task — one workgroup of stitch_region_kernel — per region
                 for (int i = 0; i < 8; i++)
-                    if (d.rel_index[i] != BT_INVALID_ATLAS_INDEX && d.rel_side[i] != d.side) d.regions |= 1u << i;
-                if (!d.regions) continue;
-                tasks.push_back(d);
+                    if (d.rel_index[i] != BT_INVALID_ATLAS_INDEX && d.rel_side[i] != d.side) {
+                        d.regions = 1u << i;
+                        tasks.push_back(d);
+                        seam_pixels += uint64_t(m.border_size) * (i < 4 ? cc : m.border_size);
+                    }
             }
             Launch ls{};
             ls.kind = kLaunchStitch;
+            ls.aux0 = 2u;  // one region per task
             ls.attachment = ai;
             ls.first_task = first;
             ls.task_count = uint32_t(tasks.size()) - first;
-            ls.algorithmic_bytes = uint64_t(ls.task_count) * 2 * (2 * m.border_size * (Tt + cc)) * bpp;
+            ls.algorithmic_bytes = 2 * seam_pixels * bpp;
             ls.phase = shard ? 2u : 0u;
             if (ls.task_count) plan.push_back(ls);
         }

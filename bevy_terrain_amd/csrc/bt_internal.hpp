@@ -182,7 +182,7 @@ bt_status launch_split(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const 
 bt_status launch_downsample(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const TaskDev* tasks, uint32_t n);
 // rows_only: just the top / bottom apron rows (full width, corners included) — the fused path writes the left / right
 // apron columns of those tiles itself
-bt_status launch_stitch(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const TaskDev* tasks, uint32_t n, bool rows_only = false);
+bt_status launch_stitch(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const TaskDev* tasks, uint32_t n, bool rows_only = false, bool one_region = false);
 bt_status launch_sample(bt_ctx* ctx, const AttachmentMeta& m, const void* atlas, const bt_tile_lookup* lookups, uint32_t count, float* out);
 bt_status launch_mip_level(bt_ctx* ctx, uint32_t format, const void* parent, void* child, uint32_t parent_size,
                            uint32_t layers);

@@ -403,6 +403,33 @@ __global__ __launch_bounds__(256) void stitch_kernel(AttachmentMeta m, void* __r
     base[uint64_t(task.atlas_index) * Tsz * Tsz + uint64_t(py) * Tsz + px] = v;
 }
 
+// A workgroup = ONE apron region of one tile (task.regions has exactly one bit): the cube's cross-face seams after the fused
+// plans, where a face-edge tile needs one edge + two corners of its eight regions — no thread is launched for the other five.
+// kPack = 2 (R16, b even): a thread moves two horizontally adjacent pixels and stores them as one dword.
+template <typename T, uint32_t kPack>
+__global__ __launch_bounds__(256) void stitch_region_kernel(AttachmentMeta m, void* __restrict__ atlas_, const TaskDev* __restrict__ tasks) {
+    const TaskDev task = tasks[blockIdx.x];
+    const uint32_t Tsz = m.texture_size, b = m.border_size, c = m.center_size, o = b + c;
+    const uint32_t region = uint32_t(__ffs(int(task.regions))) - 1u;  // 0 top, 1 right, 2 bottom, 3 left, 4 TL, 5 TR, 6 BR, 7 BL
+    const uint32_t x0 = (region == 0u || region == 2u) ? b : ((region == 1u || region == 5u || region == 6u) ? o : 0u);
+    const uint32_t y0 = (region == 1u || region == 3u) ? b : ((region == 2u || region == 6u || region == 7u) ? o : 0u);
+    const uint32_t w = (region == 0u || region == 2u) ? c : b, h = (region == 1u || region == 3u) ? c : b;
+    T* atlas = (T*)atlas_;
+    for (uint32_t i = threadIdx.x; i < (w / kPack) * h; i += 256u) {
+        const uint32_t px = x0 + kPack * (i % (w / kPack)), py = y0 + i / (w / kPack);
+        uint32_t v[kPack];
+#pragma unroll
+        for (uint32_t e = 0; e < kPack; e++) {
+            uint32_t layer, sx, sy;
+            stitch_source(task, px + e, py, Tsz, b, c, layer, sx, sy);
+            v[e] = (layer < m.atlas_size && sx < Tsz && sy < Tsz) ? uint32_t(atlas[uint64_t(layer) * Tsz * Tsz + uint64_t(sy) * Tsz + sx]) : 0u;
+        }
+        T* dst = atlas + uint64_t(task.atlas_index) * Tsz * Tsz + uint64_t(py) * Tsz + px;
+        if constexpr (kPack == 2) *reinterpret_cast<uint32_t*>(dst) = v[0] | (v[1] << 16);
+        else *dst = T(v[0]);
+    }
+}
+
 // R16 with an even border: one thread per apron pixel PAIR (a pair never straddles two regions) — half the
 // stores, each 4 bytes; the left / right columns are isolated 4-byte accesses either way
 __global__ __launch_bounds__(256) void stitch_pairs_kernel(AttachmentMeta m, uint16_t* __restrict__ atlas,
@@ -606,8 +633,14 @@ bt_status launch_downsample(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, c
     return check_launch("downsample_kernel");
 }
 
-bt_status launch_stitch(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const TaskDev* tasks, uint32_t n, bool rows_only) {
+bt_status launch_stitch(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const TaskDev* tasks, uint32_t n, bool rows_only, bool one_region) {
     if (!n || m.border_size == 0) return BT_OK;
+    if (one_region) {
+        if (m.format == BT_FORMAT_R16 && m.border_size % 2u == 0 && m.texture_size % 2u == 0) stitch_region_kernel<uint16_t, 2><<<n, 256, 0, ctx->stream>>>(m, atlas, tasks);
+        else if (m.format == BT_FORMAT_R16) stitch_region_kernel<uint16_t, 1><<<n, 256, 0, ctx->stream>>>(m, atlas, tasks);
+        else stitch_region_kernel<uint32_t, 1><<<n, 256, 0, ctx->stream>>>(m, atlas, tasks);
+        return check_launch("stitch_region_kernel");
+    }
     const uint32_t apron = 2u * m.border_size * (m.texture_size + m.center_size);
     const uint32_t blocks = (apron + 255u) / 256u;
     if (m.format == BT_FORMAT_R16 && m.border_size % 2u == 0 && m.texture_size % 2u == 0) {

@@ -164,7 +164,7 @@ bt_status run_plan_entry(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
         case kLaunchDownsample:
             return launch_downsample(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count);
         case kLaunchStitch:
-            return launch_stitch(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count, l.aux0 == 1u);
+            return launch_stitch(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count, l.aux0 == 1u, l.aux0 == 2u);
         default:
             return fused_launch(p, a, l);
     }
