@@ -2056,7 +2056,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         }
         Launch lm{};
         lm.kind = kLaunchFusedMain;
-        lm.kernels = 2;  // fused_main + fused_todo (or fused_corner + fused_main)
+        lm.kernels = main_job.args.lds_rows ? 1u : 2u;  // (without the LDS window: fused_corner + fused_main in one entry)
         lm.attachment = ai;
         lm.task_count = uint32_t(items.size());
         lm.aux0 = uint32_t(jobs.size());
@@ -2064,6 +2064,12 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         for (uint32_t k = 0; k < main_levels; k++) lm.algorithmic_bytes += tiles_at(lod_hi - k) * Tt * Tt * bpp;
         jobs.push_back(main_job);
         plan.push_back(lm);
+        if (main_job.args.lds_rows) {  // fused_todo: the chunks the fast variant re-queued + the apron corners; an entry of its own, so that
+            Launch lq = lm;            // a profiled run times fused_main alone
+            lq.kind = kLaunchFusedTodo;
+            lq.algorithmic_bytes = uint64_t(items.size()) * 4 * m.border_size * m.border_size * bpp;  // (the corners; re-queued chunks are data dependent)
+            plan.push_back(lq);
+        }
         }
 
         const bool tail_follows = lod_hi - (main_levels - 1) > lod_lo;
@@ -2223,9 +2229,12 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
     }
     std::vector<FusedJobDev>& jobs = p->fused->jobs;
     FusedJobDev job = jobs[l.aux0];
+    // the two todo lists alternate per main launch (fused_todo zeroes the one the NEXT main launch appends to); the todo entry
+    // that follows a main launch sees the same pair
     if (l.kind == kLaunchFusedMain && (jobs[l.aux0].main_runs++ & 1u)) std::swap(job.args.todo, job.args.todo_next);
+    if (l.kind == kLaunchFusedTodo && ((jobs[l.aux0].main_runs - 1u) & 1u)) std::swap(job.args.todo, job.args.todo_next);
     job.args.rasters = p->rasters_dev;
-    if (l.kind == kLaunchFusedMain && item_begin < job.args.item_count) {  // a band of the item list (streamed runs); default: all
+    if ((l.kind == kLaunchFusedMain || l.kind == kLaunchFusedTodo) && item_begin < job.args.item_count) {  // a band of the item list (streamed runs); default: all
         job.args.items += item_begin;
         job.args.item_count = std::min(item_count, job.args.item_count - item_begin);
     }
@@ -2244,11 +2253,15 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
                 fused_main_kernel<true, false, 512, 528><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
             else
                 fused_main_kernel<true, false, 0, 0><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
-            fused_todo_kernel<<<std::min(blocks, 1024u), 256, lds, p->ctx->stream>>>(job.args);
         } else {
             fused_corner_kernel<<<job.args.item_count, 64, 0, p->ctx->stream>>>(job.args);
             fused_main_kernel<false, true, 0, 0><<<blocks, 256, sizeof(MainShared), p->ctx->stream>>>(job.args);
         }
+    } else if (l.kind == kLaunchFusedTodo) {
+        const uint32_t blocks = job.args.item_count * job.args.groups;
+        size_t lds = sizeof(MainShared) + 2 * size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
+        lds = std::min<size_t>(65536, lds + job.lds_pad);
+        fused_todo_kernel<<<std::min(blocks, 1024u), 256, lds, p->ctx->stream>>>(job.args);
     } else {
         const uint32_t size = (1u << job.args.lod) * job.args.m.center_size;
         dim3 grid((size + 63) / 64, (size + 63) / 64, job.args.sides);

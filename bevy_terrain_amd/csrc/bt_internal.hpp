@@ -165,7 +165,7 @@ struct bt_atlas {
 namespace bt {
 
 // One launch of the compiled plan.
-enum LaunchKind : uint32_t { kLaunchSplit, kLaunchDownsample, kLaunchStitch, kLaunchFusedMain, kLaunchFusedTail, kLaunchFusedDirect };
+enum LaunchKind : uint32_t { kLaunchSplit, kLaunchDownsample, kLaunchStitch, kLaunchFusedMain, kLaunchFusedTail, kLaunchFusedDirect, kLaunchFusedTodo };
 struct Launch {
     LaunchKind kind;
     uint32_t attachment;

@@ -198,7 +198,7 @@ class Preprocessor:
         _ffi.check(_ffi.lib().bt_preprocessor_last_run_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in s._fields_}
 
-    KINDS = ("split", "downsample", "stitch", "fused_main", "fused_tail", "fused_direct")
+    KINDS = ("split", "downsample", "stitch", "fused_main", "fused_tail", "fused_direct", "fused_todo")
 
     def profile(self) -> List[dict]:
         """Average device time per launch of the runs made with profile=True (hipEvents on the stream)."""

@@ -345,7 +345,7 @@ bt_status bt_preprocessor_run_sharded(bt_preprocessor* p, bt_atlas* atlas, bt_co
 
 /* Per-launch device time of the runs made with BT_RUN_PROFILE since the last call (hipEvents on the
  * context's stream, averaged over those runs).  `kind`: 0 split, 1 downsample, 2 stitch, 3 fused main,
- * 4 fused tail, 5 fused direct (Rgba8).  `algorithmic_bytes`: that launch's inputs read once + outputs written once.
+ * 4 fused tail, 5 fused direct (Rgba8), 6 fused todo (re-queued no-data chunks + apron corners, follows 3).  `algorithmic_bytes`: that launch's inputs read once + outputs written once.
  * Synchronises the stream.  Returns the number of launches per run through *count. */
 typedef struct bt_launch_profile {
     uint32_t kind;
