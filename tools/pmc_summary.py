@@ -71,7 +71,10 @@ def main():
     stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
         shutil.copy(stats[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
-    for name in ("bench_n1_verified.json", "bench_under_rocprofv3.json"):
+    cfg = glob.glob(os.path.join(src, "config_stats", "**", "*kernel_stats.csv"), recursive=True)
+    if cfg:
+        shutil.copy(cfg[0], os.path.join(dst, f"{tag}_config_bench_kernel_stats.csv"))
+    for name in ("bench_n1_verified.json", "bench_under_rocprofv3.json", "config_bench.json", "refine_bench.json"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
     for k in sorted(summary):

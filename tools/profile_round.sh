@@ -19,4 +19,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o bench -- $B --steps 3 --warmup 1 --spinup-ms 0 > /dev/null 2> $O/pmc_write.log
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS \
     --kernel-trace --output-format csv -d $O/pmc_sq -o bench -- $B --steps 3 --warmup 1 --spinup-ms 0 > /dev/null 2> $O/pmc_sq.log
+# the non-headline BASELINE configs (parity cases) and the tiling prepass, for the record
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/config_stats -o cfg -- python $R/tools/config_bench.py > $O/config_bench.json 2> $O/config_bench.log
+python $R/tools/refine_bench.py --sweep > $O/refine_bench.json 2> $O/refine_bench.log
 find $O -name '*.csv' | sort
