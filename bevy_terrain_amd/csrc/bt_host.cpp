@@ -645,16 +645,18 @@ class TileSaver {
         writers_.reset(new FileWriters(threads, kBuffers));
         return BT_OK;
     }
-    // max_chunk: tiles per pinned buffer for this call (smaller chunks at the very end shorten the writers' tail)
-    bt_status add(std::vector<std::pair<uint32_t, bt_tile_coordinate>> tiles, uint32_t max_chunk = 0xFFFFFFFFu) {
+    // taper: the call's last tiles travel in shrinking chunks (half of what is left, down to 8 tiles) — full-size chunks keep the
+    // copy engine at its rate, the small ones at the very end shorten the writers' tail behind the last copy
+    bt_status add(std::vector<std::pair<uint32_t, bt_tile_coordinate>> tiles, bool taper = false) {
         const Attachment& at = a_->attachments[ai_];
         void** pinned = a_->ctx->staging;
         std::sort(tiles.begin(), tiles.end(), [](const auto& l, const auto& r) { return l.first < r.first; });
         tiles.erase(std::unique(tiles.begin(), tiles.end(), [](const auto& l, const auto& r) { return l.first == r.first && operator_eq(l.second, r.second); }),
                     tiles.end());
         const size_t n = tiles.size();
-        const size_t step = std::max<size_t>(1, std::min<size_t>(chunk_, max_chunk));
-        for (size_t lo = 0; lo < n; lo += step) {
+        for (size_t lo = 0, step = 0; lo < n; lo += step) {
+            step = chunk_;
+            if (taper && n - lo <= 2 * size_t(chunk_)) step = std::max<size_t>(std::min<size_t>(8, chunk_), (n - lo) / 2);
             const size_t hi = std::min(n, lo + step);
             const uint32_t k = uint32_t(chunks_++ % kBuffers);
             writers_->wait_buffer(k);
@@ -1509,7 +1511,7 @@ bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* a, const ch
             }
             if (hipStreamWaitEvent(p->ctx->save_stream, computed[k], 0) != hipSuccess) s = BT_ERR_DEVICE;
             stamp("saver: band enqueued by the launcher", k);
-            if (s == BT_OK && !band_tiles[k].empty()) s = ts.add(std::move(band_tiles[k]), k == nb ? 24u : 0xFFFFFFFFu);
+            if (s == BT_OK && !band_tiles[k].empty()) s = ts.add(std::move(band_tiles[k]), k == nb);
             stamp("saver: band's copies issued, previous chunks handed to the writers", k);
         }
         if (s == BT_OK) s = ts.finish();
