@@ -273,6 +273,31 @@ def test_refine_small_buffers_and_refinement_counts():
         assert np.array_equal(a[0], np.array(b[0], dtype=np.uint32).reshape(-1, 4)) and a[1:] == b[1:]
 
 
+@pytest.mark.parametrize("name", list(MODELS))
+def test_final_set_is_a_per_tile_predicate_of_the_executed_divide_test(name):
+    """What bt_tiling_prepass_run_unordered relies on (bt_refine.hip), stated against the reference's own WGSL: the
+    final list of the executed refine_tiles / prepare_prepass schedule is, as a set, exactly the tiles that (a) are reached
+    — every ancestor satisfies the executed should_be_divided — (b) do not divide themselves and (c) have lod <=
+    refinement_count; the children of tiles that still divide in the last pass appear nowhere.  Depth-first from the roots,
+    one executed divide test per visited tile; also with a refinement_count that cuts the tree short."""
+    model = O.make_model(**MODELS[name])
+    pos = camera_positions(name, 3, 77)[-1]
+    for rc in (30, 3):
+        v = O.view_state_from_config(model, O.make_view_config(geometry_tile_count=300000, refinement_count=rc), pos, 120.0)
+        schedule, _, passes = W.refine(v)
+        final, visited = [], 0
+        stack = [(s, 0, 0, 0) for s in range(6 if v.spherical else 1)]
+        while stack:
+            side, lod, x, y = stack.pop()
+            visited += 1
+            if not W.should_be_divided(v, (side, lod, x, y))[0]:
+                final.append((side, lod, x, y))
+            elif lod < rc:
+                stack.extend((side, lod + 1, 2 * x + (i & 1), 2 * y + (i >> 1)) for i in range(4))
+        assert visited == sum(passes)
+        assert len(final) == len(schedule) == len(set(schedule)) and sorted(final) == sorted(schedule), (name, rc)
+
+
 @pytest.mark.skipif(not os.path.isdir(W.REFERENCE), reason="needs /root/reference to re-translate")
 def test_abstract_constant_rule_is_observable_only_below_one_ulp(tmp_path):
     """FINDING: `const C_SQR = 0.87 * 0.87;` (functions.wgsl:12).  naga 0.20 (bevy 0.14.0's shader compiler,
