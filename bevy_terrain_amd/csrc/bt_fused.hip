@@ -191,6 +191,61 @@ __device__ __forceinline__ void push_pixel(const FusedArgs& A, uint32_t side, ui
     }
 }
 
+// push_pixel in two halves for fused_tail, which is a latency chain: push_targets does the neighbour LOOKUPS of a centre pixel —
+// coordinates only, no data — so that they are in flight together with the thread's other loads; push_store does the stores.
+// (One memory counter covers loads and stores on this ISA: a lookup issued after a store waits for that store, so four
+// push_pixel calls in a row cost an edge thread four round trips.)  A 2 x 2 pixel block with even coordinates shares its
+// targets when b is even.
+struct PushNb {
+    int ex, ey;
+    uint32_t nx, ny, nxy;
+};
+__device__ __forceinline__ PushNb push_targets(const FusedArgs& A, uint32_t side, uint32_t lod, uint32_t tx, uint32_t ty, uint32_t cx, uint32_t cy, bool active) {
+    const uint32_t b = A.m.border_size, c = A.m.center_size;
+    PushNb t{0, 0, kInvalid, kInvalid, kInvalid};
+    if (!active) return t;
+    t.ex = cx < b ? -1 : (cx >= c - b ? 1 : 0);
+    t.ey = cy < b ? -1 : (cy >= c - b ? 1 : 0);
+    if (t.ex != 0) t.nx = grid_lookup(A, side, lod, int(tx) + t.ex, int(ty));
+    if (t.ey != 0) t.ny = grid_lookup(A, side, lod, int(tx), int(ty) + t.ey);
+    if (t.ex != 0 && t.ey != 0) t.nxy = grid_lookup(A, side, lod, int(tx) + t.ex, int(ty) + t.ey);
+    return t;
+}
+template <typename TT = uint16_t>
+__device__ __forceinline__ void push_store(const FusedArgs& A, const PushNb& t, uint32_t self_index, uint32_t cx, uint32_t cy, TT v) {
+    if (t.ex == 0 && t.ey == 0) return;
+    const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
+    const uint64_t tile_texels = uint64_t(T) * T;
+    TT* atlas = reinterpret_cast<TT*>(A.atlas);
+    TT* self = atlas + uint64_t(self_index) * tile_texels;
+    const uint32_t ax = uint32_t(int(b + cx) - t.ex * int(c)), ay = uint32_t(int(b + cy) - t.ey * int(c));
+    if (t.ex != 0) {
+        if (t.nx != kInvalid) {
+            atlas[uint64_t(t.nx) * tile_texels + uint64_t(b + cy) * T + ax] = v;
+        } else if (cx == 0 || cx == c - 1) {
+            const uint32_t x0 = t.ex < 0 ? 0u : o;
+            for (uint32_t j = 0; j < b; j++) self[uint64_t(b + cy) * T + x0 + j] = v;
+        }
+    }
+    if (t.ey != 0) {
+        if (t.ny != kInvalid) {
+            atlas[uint64_t(t.ny) * tile_texels + uint64_t(ay) * T + b + cx] = v;
+        } else if (cy == 0 || cy == c - 1) {
+            const uint32_t y0 = t.ey < 0 ? 0u : o;
+            for (uint32_t j = 0; j < b; j++) self[uint64_t(y0 + j) * T + b + cx] = v;
+        }
+    }
+    if (t.ex != 0 && t.ey != 0) {
+        if (t.nxy != kInvalid) {
+            atlas[uint64_t(t.nxy) * tile_texels + uint64_t(ay) * T + ax] = v;
+        } else if ((cx == 0 || cx == c - 1) && (cy == 0 || cy == c - 1)) {
+            const uint32_t x0 = t.ex < 0 ? 0u : o, y0 = t.ey < 0 ? 0u : o;
+            for (uint32_t j = 0; j < b; j++)
+                for (uint32_t i = 0; i < b; i++) self[uint64_t(y0 + j) * T + x0 + i] = v;
+        }
+    }
+}
+
 // downsample.wgsl:25-39 on four texels in OFFSETS order (0,0),(0,1),(1,0),(1,1) of (dx, dy)
 __device__ __forceinline__ uint32_t downsample4(uint32_t t00, uint32_t t01, uint32_t t10, uint32_t t11) {
     if (t00 != 0 && t01 != 0 && t10 != 0 && t11 != 0) {
@@ -1161,6 +1216,7 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
     {
         const uint32_t extent = (1u << A.lod) * A.m.center_size, ny = (extent + 63u) / 64u;
         if (blockIdx.y >= ny) {  // workgroups past the mosaic: apron rows (Rgba8: and columns)
+            if (BT_ABLATE(A, 268435456u)) return;  // (268435456: no apron workgroups — timing experiment)
             if constexpr (kR16) tail_apron_rows(A, blockIdx.z, (blockIdx.y - ny) * gridDim.x + blockIdx.x);
             else tail_aprons_rgba8(A, blockIdx.z, (blockIdx.y - ny) * gridDim.x + blockIdx.x);
             return;
@@ -1196,6 +1252,10 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
         if (A.levels >= 2) self2 = grid_lookup(A, side, A.lod - 2, int(tile_x >> 2), int(tile_y >> 2));
         if (A.levels >= 3) self3 = grid_lookup(A, side, A.lod - 3, int(tile_x >> 3), int(tile_y >> 3));
     }
+    // ... and the neighbour tiles the four lod-1 pixels will be pushed into (edge pixels only), while nothing has been stored yet.
+    // b even: the 2 x 2 block (even coordinates) lies in one edge region and shares its targets; b odd: per pixel, push_pixel
+    const bool pre = (b & 1u) == 0;
+    const PushNb nb1 = push_targets(A, side, A.lod - 1, tile_x >> 1, tile_y >> 1, rx1, ry1, active && pre);
     if (active) {
         if (idx != kInvalid) {  // an absent tile reads as no data
             const TT* p = atlas + uint64_t(idx) * tile_texels + (b + rem_y) * T + b + rem_x;
@@ -1230,7 +1290,7 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
         for (int k = 0; k < 2; k++) q[r][k] = down(t[2 * r][2 * k], t[2 * r + 1][2 * k], t[2 * r][2 * k + 1], t[2 * r + 1][2 * k + 1]);
     if (active) {
         const uint32_t self = self1;
-        if (self != kInvalid) {
+        if (self != kInvalid && !BT_ABLATE(A, 1073741824u)) {  // (1073741824: no lod-1 stores — timing experiment)
             // R16: the two pixels of a row are one aligned dword of the tile (x1, b, c even); aprons per pixel, edge pixels only
             TT* centre = atlas + uint64_t(self) * tile_texels + (b + ry1) * T + b + rx1;
 #pragma unroll
@@ -1242,7 +1302,11 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
                     centre[r * T + 1] = q[r][1];
                 }
 #pragma unroll
-                for (int k = 0; k < 2; k++) push_pixel<false, TT>(A, side, A.lod - 1, tile_x >> 1, tile_y >> 1, self, rx1 + k, ry1 + r, TT(q[r][k]));
+                for (int k = 0; k < 2; k++) {
+                    if (BT_ABLATE(A, 536870912u)) continue;  // (536870912: no apron pushes of lod-1 — timing experiment)
+                    if (pre) push_store<TT>(A, nb1, self, rx1 + k, ry1 + r, TT(q[r][k]));
+                    else push_pixel<false, TT>(A, side, A.lod - 1, tile_x >> 1, tile_y >> 1, self, rx1 + k, ry1 + r, TT(q[r][k]));
+                }
             }
         }
     }
