@@ -1257,7 +1257,7 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
     const bool pre = (b & 1u) == 0;
     const PushNb nb1 = push_targets(A, side, A.lod - 1, tile_x >> 1, tile_y >> 1, rx1, ry1, active && pre);
     if (active) {
-        if (idx != kInvalid) {  // an absent tile reads as no data
+        if (idx != kInvalid && !BT_ABLATE(A, 33554432u)) {  // an absent tile reads as no data  (33554432: no texel loads — timing experiment)
             const TT* p = atlas + uint64_t(idx) * tile_texels + (b + rem_y) * T + b + rem_x;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -1310,7 +1310,7 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
             }
         }
     }
-    if (A.levels < 2) return;
+    if (A.levels < 2 || BT_ABLATE(A, 67108864u)) return;  // (67108864: lod-1 only — timing experiment)
     const uint32_t v2 = down(q[0][0], q[1][0], q[0][1], q[1][1]);
     if (active) {
         const uint32_t self = self2;
