@@ -12,4 +12,8 @@ from bevy_terrain_amd import _ffi
 _ffi.LIB_PATH = os.environ.get("BT_LIB") or os.path.join(ROOT, "tools", "libbevy_terrain_amd_dbg.so")  # BT_LIB: another build (A/B runs)
 import bench
 
+if os.environ.get("BT_PAD_MB"):  # placement experiment: device memory taken before the bench allocates anything
+    import torch
+
+    _pad = [torch.empty(int(mb) << 20, dtype=torch.uint8, device="cuda") for mb in os.environ["BT_PAD_MB"].split(",")]
 bench.main()
