@@ -270,6 +270,7 @@ def main():
                     help="N = 1: independent jobs in flight in the HEADLINE pass — P contexts (HIP streams) with an atlas each over "
                          "the same resident source, steps issued round-robin (default 1: one job on one stream, the definition "
                          "that also holds at N > 1, which always uses 1)")
+    ap.add_argument("--extras-timeout", type=int, default=180, help="N > 1: seconds the extra passes may take before the line is printed without them")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra passes (N = 1: two jobs in flight; N > 1: kernels only, collective only, the other result mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -454,37 +455,8 @@ def main():
             t = float(tt.item())
         return t / args.steps
 
-    # N > 1 extras: the same K steps without the collectives (kernels only), the collectives without the kernels, and the
-    # other result mode (SURVEY §8e asks for compute and compute + collective separately)
     compute_only_ms = exchange_only_ms = None
     other_result = None
-    if job is not None and extras:
-        compute_only_ms = timed_pass(lambda i: job.step(False, gather=False))
-        job.step(False)  # a complete atlas again
-        exchange_only_ms = timed_pass(lambda i: job.exchange())
-        job.step(False)  # leave a complete atlas behind (--verify)
-        fence()
-        if not cube:
-            # the other result mode on a second atlas / queue / communicator of this rank; every rank must agree that it came up
-            other = "distributed" if result == "replicated" else "replicated"
-            ok, job2 = 1, None
-            try:
-                atlas2 = bt.TileAtlas.new(cfg, device)
-                pre2 = bt.Preprocessor.new().clear_attachment(0, atlas2)
-                job2 = ShardedPreprocess(pre2, atlas2, server, paths, range(0, lod_count), rank, world, generic=args.generic, collective=collective, result=other)
-            except Exception as e:
-                print(f"[rank {rank}] extra pass ({other}) unavailable: {e!r}", file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok], device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                for _ in range(3):
-                    job2.step(False)
-                t_other = timed_pass(lambda i: job2.step(False))
-                other_result = {"result": other, "ms_per_step": t_other, "tiles_per_s": job2.stats()["tiles"] / (t_other / 1e3),
-                                "all_gather_bytes_per_rank": job2.gather_bytes}
-            if job2 is not None:
-                job2.close()
 
     # N = 1 extra: two independent jobs in flight (two contexts / streams, an atlas each): the tail, the todo launch and the
     # drain of one job's main kernel run beside the main kernel of the next
@@ -560,6 +532,56 @@ def main():
                               "LODs are exchanged, every rank holds every lower LOD"),
                    "launches": launches},
     }
+    # N > 1 extras: the same K steps without the collectives (kernels only), the collectives without the kernels, and the
+    # other result mode (SURVEY §8e asks for compute and compute + collective separately).  They come AFTER the headline is
+    # complete, under a watchdog: these passes end in collectives, and a rank that fails inside one leaves the others waiting —
+    # the headline line must not be lost to that (rank 0 prints what it has, every rank leaves).
+    if job is not None and extras:
+        import threading
+
+        def bail():
+            if rank == 0:
+                line["config"]["extras_error"] = f"the extra passes did not finish within {args.extras_timeout} s"
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.extras_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            compute_only_ms = timed_pass(lambda i: job.step(False, gather=False))
+            job.step(False)  # a complete atlas again
+            exchange_only_ms = timed_pass(lambda i: job.exchange())
+            job.step(False)  # leave a complete atlas behind (--verify)
+            fence()
+            if not cube:
+                # the other result mode on a second atlas / queue / communicator of this rank; every rank must agree that it came up
+                other = "distributed" if result == "replicated" else "replicated"
+                ok, job2 = 1, None
+                try:
+                    atlas2 = bt.TileAtlas.new(cfg, device)
+                    pre2 = bt.Preprocessor.new().clear_attachment(0, atlas2)
+                    job2 = ShardedPreprocess(pre2, atlas2, server, paths, range(0, lod_count), rank, world, generic=args.generic, collective=collective, result=other)
+                except Exception as e:
+                    print(f"[rank {rank}] extra pass ({other}) unavailable: {e!r}", file=sys.stderr)
+                    ok = 0
+                flag = torch.tensor([ok], device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 1:
+                    for _ in range(3):
+                        job2.step(False)
+                    t_other = timed_pass(lambda i: job2.step(False))
+                    other_result = {"result": other, "ms_per_step": t_other, "tiles_per_s": job2.stats()["tiles"] / (t_other / 1e3),
+                                    "all_gather_bytes_per_rank": job2.gather_bytes}
+                if job2 is not None:
+                    job2.close()
+        except Exception as e:  # (an exception every rank raises at the same point, e.g. an unsupported flag)
+            line["config"]["extras_error"] = repr(e)
+        finally:
+            watchdog.cancel()
+        line["config"]["kernels_only_ms_per_step"] = compute_only_ms
+        line["config"]["collective_only_ms_per_step"] = exchange_only_ms
+        line["config"]["other_result_mode"] = other_result
     if dominant:
         achieved = dominant["algorithmic_bytes"] / (dominant["avg_ms"] / 1e3) / 1e9
         # HBM bytes per launch from the PMC passes of the same command (rocprofv3 cannot run inside this
