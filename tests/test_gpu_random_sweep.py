@@ -1,6 +1,8 @@
 """Seeded random sweep over the job parameters the launch planner branches on (tile shape, border, LOD count, format,
 raster shape, holes, dataset rectangle, lod_range offset, planar / cube): whatever plan the product picks — fused,
 direct, hybrid or generic — every tile must equal the oracle's, byte for byte, at the same atlas index."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,7 @@ import _oracle as O
 import bevy_terrain_amd as bt
 
 pytestmark = pytest.mark.gpu
+FUZZ = int(os.environ.get("BT_FUZZ_OFFSET", "0"))  # other seeds of the same sweep: BT_FUZZ_OFFSET=1000 pytest -m gpu -k ...
 
 
 @pytest.fixture(scope="module")
@@ -38,7 +41,7 @@ def draw_case(seed):
     return dict(T=T, b=b, lods=lods, fmt=fmt, W=W, H=H, holes=holes, ds=ds, cube=cube, lod_begin=lod_begin, overlay=overlay)
 
 
-@pytest.mark.parametrize("seed", range(160))
+@pytest.mark.parametrize("seed", range(FUZZ, FUZZ + 160))
 def test_random_job_matches_oracle(device, seed):
     p = draw_case(seed)
     T, b, lods, fmt = p["T"], p["b"], p["lods"], p["fmt"]

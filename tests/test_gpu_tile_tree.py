@@ -12,6 +12,7 @@ import bevy_terrain_amd as bt
 from test_tile_tree_host import MODELS, positions
 
 pytestmark = pytest.mark.gpu
+FUZZ = int(os.environ.get("BT_FUZZ_OFFSET", "0"))  # other seeds of the same sweep: BT_FUZZ_OFFSET=1000 pytest -m gpu -k ...
 
 
 @pytest.fixture(scope="module")
@@ -263,7 +264,7 @@ def draw_tree_case(seed):
     return model, omodel, lods, cfg, pts
 
 
-@pytest.mark.parametrize("seed", range(45))
+@pytest.mark.parametrize("seed", range(FUZZ, FUZZ + 45))
 def test_update_random_models_configs_and_teleports(device, seed):
     model, omodel, lods, cfg, pts = draw_tree_case(seed)
     vc = bt.TerrainViewConfig(**cfg)
