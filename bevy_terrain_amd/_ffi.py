@@ -237,7 +237,7 @@ def lib():
         fn = getattr(L, name)  # AttributeError = ABI mismatch, also loud
         fn.restype = restype
         fn.argtypes = argtypes
-    if L.bt_abi_version() != 2:
+    if L.bt_abi_version() != 3:
         raise ImportError("libbevy_terrain_amd.so ABI version mismatch")
     _lib = L
     return L

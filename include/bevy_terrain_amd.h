@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define BT_ABI_VERSION 2u
+/* 3 (round 3): + bt_preprocessor_run_streamed, BT_RASTER_HOST_DEFERRED, BT_RUN_SHARD_EXCHANGE, bt_tiling_prepass_run_plain /
+ * _run_unordered / _set_window, launch kind 6 (fused todo) in bt_launch_profile — additions only, every version-2 call keeps its
+ * meaning. */
+#define BT_ABI_VERSION 3u
 
 typedef int32_t bt_status;
 enum {

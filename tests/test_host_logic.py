@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     exported = set(re.findall(r" T (bt_[a-z0-9_]+)", out))
     assert declared <= exported, sorted(declared - exported)
     assert declared == set(_ffi.PROTOTYPES), sorted(declared ^ set(_ffi.PROTOTYPES))
-    assert _ffi.lib().bt_abi_version() == 2
+    assert _ffi.lib().bt_abi_version() == 3
 
 
 def test_struct_layouts_match_reference_gpu_layouts():
@@ -102,7 +102,7 @@ def test_c99_consumer_of_the_header_and_ctypes_mirror_layouts(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "abi_consumer.c"), "-ldl", "-o", exe])
     out = json.loads(subprocess.check_output([exe, _ffi.LIB_PATH], text=True))
-    assert out["abi_version"] == 2 and out["done"]
+    assert out["abi_version"] == 3 and out["done"]
     assert out["ctx_create"] in (0, -1, -3)  # 0 on a GPU box; a clean error status (with a message) without one
     assert out["view_state"] == [0, 614, 307, 2 * 16 * 18, 8]
     mirror = {"bt_tile_coordinate": _ffi.TileCoordinateC, "bt_atlas_tile": _ffi.AtlasTileC, "bt_attachment_config": _ffi.AttachmentConfigC,
