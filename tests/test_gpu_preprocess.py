@@ -266,6 +266,15 @@ def test_tile_load_path_round_trip(device, tmp_path, fmt):
     with pytest.raises(bt._ffi.BtError) as e:
         again.load_tiles(0, root, [bt.TileCoordinate(0, 2, 3, 1)])
     assert e.value.status == -5 or "not found" in str(e.value)
+    # a file of the wrong length (cut short, or longer than a tile) is an error too, not a partly loaded tile
+    for name, change in (("0_2_0_0.bin", lambda d: d[:-7]), ("0_2_1_1.bin", lambda d: d + b"\0")):
+        path = os.path.join(root, "terrains/test/data/att", name)
+        data = open(path, "rb").read()
+        open(path, "wb").write(change(data))
+        side, lod, x, y = (int(v) for v in name[:-4].split("_"))
+        with pytest.raises(bt._ffi.BtError) as e:
+            bt.TileAtlas.new(cfg, device).load_tiles(0, root, [bt.TileCoordinate(side, lod, x, y)])
+        assert "does not hold" in str(e.value), str(e.value)
 
 
 @pytest.mark.parametrize("T,b,W", [(512, 4, 2100), (512, 8, 1900), (256, 2, 1100), (384, 6, 1500)])
