@@ -23,7 +23,7 @@ struct bt_tiling_prepass {
     bt_tile_coordinate* temporary_tiles = nullptr;
     bt_tile_coordinate* final_tiles = nullptr;
     bt_indirect* indirect = nullptr;
-    uint32_t* counters = nullptr;  // [0] final count, [1] overflow flag, [2] tiles visited, [3] passes; unordered form: [4] ticket, [8..40) tiles visited per LOD, [40..72) dividing tiles per LOD
+    uint32_t* counters = nullptr;  // [0] final count, [1] overflow flag, [2] tiles visited, [3] passes; unordered form: [8..40) tiles visited per LOD, [40..72) dividing tiles per LOD
     unsigned long long* bits = nullptr;  // divide bits of every (side, lod) window (allocated on first use)
     int window = 0;                      // window radius of the unordered form (0 = the default, kWinK)
     bool unordered = false;              // the last run was the unordered form: read() derives counters [1..3] from the per-LOD counts
@@ -153,7 +153,7 @@ __device__ __forceinline__ void window_origin(const bt_view_state& v, uint32_t s
 
 // lods: LODs 0 .. lods - 1 get their bits (the host's estimate of how deep this view can refine; anything deeper is
 // evaluated in place by the ordered kernel — an estimate can only cost time, never change the result)
-constexpr uint32_t kCntTicket = 4, kCntVisited = 8, kCntDivide = 40, kCounterWords = 72;  // (bt_tiling_prepass::counters)
+constexpr uint32_t kCntVisited = 8, kCntDivide = 40, kCounterWords = 72;  // (bt_tiling_prepass::counters)
 
 // radius <= kWinK: the window actually used (storage is laid out for kWinK); counters != nullptr: also resets the counters and
 // the indirect arguments the unordered collector (next launch) accumulates into
