@@ -11,6 +11,25 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbevy_terrain_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bevy_terrain_amd.h")
+
+
+def header_abi_version() -> int:
+    """BT_ABI_VERSION as include/bevy_terrain_amd.h declares it: the one place the number is written."""
+    import re
+    with open(HEADER_PATH) as f:
+        m = re.search(r"^#define\s+BT_ABI_VERSION\s+(\d+)u?\s*$", f.read(), flags=re.M)
+    if not m:
+        raise ImportError(f"{HEADER_PATH}: BT_ABI_VERSION not found")
+    return int(m.group(1))
+
+
+def header_symbols() -> set:
+    """Every bt_* function include/bevy_terrain_amd.h declares."""
+    import re
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return set(re.findall(r"\b(bt_[a-z0-9_]+)\s*\(", text))
 
 INVALID_ATLAS_INDEX = 0xFFFFFFFF
 MAX_ATTACHMENTS = 8
@@ -237,8 +256,9 @@ def lib():
         fn = getattr(L, name)  # AttributeError = ABI mismatch, also loud
         fn.restype = restype
         fn.argtypes = argtypes
-    if L.bt_abi_version() != 3:
-        raise ImportError("libbevy_terrain_amd.so ABI version mismatch")
+    if L.bt_abi_version() != header_abi_version():
+        raise ImportError(f"libbevy_terrain_amd.so is ABI {L.bt_abi_version()}, include/bevy_terrain_amd.h is "
+                          f"{header_abi_version()}: rebuild (make -C bevy_terrain_amd/csrc)")
     _lib = L
     return L
 

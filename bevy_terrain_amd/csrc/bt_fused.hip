@@ -347,6 +347,20 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
+// LDS-DMA by hand (global_load_lds_dwordx4: 64 lanes x 16 bytes, per-lane global addresses, LDS destination = M0 + lane * 16).
+// The builtin makes the compiler guard every later LDS read with s_waitcnt vmcnt(0) (it cannot prove that the read does not
+// alias the DMA's destination), i.e. a wave would wait for the rows it has just requested for the NEXT chunk before it shades
+// the current one; from inline assembly the instruction is invisible to that pass and every wait is written out here.
+typedef const uint8_t __attribute__((address_space(1))) * dma_global;
+template <bool kNt = false>
+__device__ __forceinline__ void dma16(dma_global g, uint32_t lds_addr /* wave-uniform */) {
+    if constexpr (kNt) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(lds_addr), "v"(g) : "memory");
+    else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(g) : "memory");
+}
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the wave's global stores (vmcnt(0)), which
+// nothing in this workgroup reads back
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct RowParam {  // one centre row of the workgroup: LDS slots of its two source rows + the y weight
     int y0, y1;
     float fy;
@@ -393,7 +407,11 @@ __device__ __forceinline__ Texel4 convert4(uint32_t ta0, uint32_t ta1, uint32_t 
 // the texels each thread actually reads, per thread: a thread (pair) that saw a no-data texel stores nothing for that
 // quad of rows and flags the chunk for fused_todo, whose generic pass rewrites the whole chunk (identical values where the
 // fast pass did store, keep-previous / valid-average where it did not).
-template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP, bool kDma = false>
+// kMode (kDma only): 0 = every wave moves its share of the rows through the builtin; 1 = the same through dma16 (no compiler
+// waits); 2 = LOADER WAVE: the workgroup has a fifth wave that does nothing but move source rows (one chunk ahead) and is the only
+// one that ever waits on the vector-memory counter — the four shading waves issue their stores and go on (their barrier orders
+// LDS only), so neither the latency of the rows nor the drain of the stores sits in a shading wave's time line.
+template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP, bool kDma = false, uint32_t kMode = 0>
 __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t item_index, uint32_t k_begin, uint32_t k_end, uint8_t* smem) {
     MainShared& S = *reinterpret_cast<MainShared*>(smem);
     uint16_t* s_buf = reinterpret_cast<uint16_t*>(smem + sizeof(MainShared));
@@ -571,8 +589,29 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     auto dma_issue = [&](uint16_t* s_dst, int ymin, uint32_t slots) {
         static_assert(!kDma || kP == 528, "the DMA variant assumes 1056-byte LDS rows");
         const lds_bytes dst = (lds_bytes)reinterpret_cast<uint8_t*>(s_dst);
+        if constexpr (kMode == 2) {
+            // the loader wave fills the window as ONE linear run of LDS bytes (rows of 1056 bytes follow each other): 1 KB per
+            // instruction, every lane fetches the 16 source bytes that belong at its LDS address (a piece may straddle two rows)
+            const uint32_t base = uint32_t(reinterpret_cast<uintptr_t>(dst)), bytes = slots * (kP * 2u);
+            for (uint32_t off = 0; off < bytes; off += 1024u) {  // wave-uniform
+                const uint32_t l = off + dma_lane * 16u, slot = l / (kP * 2u), within = l - slot * (kP * 2u);
+                if (l < bytes) {
+                    const uint32_t goff = min(uint32_t(xa) * 2u + within, uint32_t(raster.pitch) - 16u);
+                    const dma_global g = (dma_global)(data + uint64_t(uint32_t(ymin) + slot) * raster.pitch + goff);
+                    if (BT_ABLATE(A, 32768u)) dma16<true>(g, __builtin_amdgcn_readfirstlane(base + off));
+                    else dma16<false>(g, __builtin_amdgcn_readfirstlane(base + off));
+                }
+            }
+            return;
+        }
         for (uint32_t slot = tid >> 6; slot < slots; slot += 4u) {  // wave-uniform
             const global_bytes row = data + uint64_t(uint32_t(ymin) + slot) * raster.pitch;
+            if constexpr (kMode == 1) {
+                const uint32_t base = uint32_t(reinterpret_cast<uintptr_t>(dst)) + slot * (kP * 2u);
+                dma16<false>((dma_global)(row + dma_off_main), __builtin_amdgcn_readfirstlane(base));
+                if (dma_lane < 2u) dma16<false>((dma_global)(row + dma_off_tail), __builtin_amdgcn_readfirstlane(base + 1024u));
+                continue;
+            }
             if (BT_ABLATE(A, 32768u))  // (32768: the non-temporal policy on the source stream — timing experiment)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + dma_off_main),
                                                  (__attribute__((address_space(3))) void*)(dst + slot * (kP * 2u)), 16, 0, 2);
@@ -634,7 +673,26 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     bool nodata = !kStaged;
     u32x4 pre[kBatch];
     window(k_begin, ymin, slots);
-    if constexpr (kDma) {
+    if constexpr (kDma && kMode == 2) {
+        if (tid == 0) S.nodata[0][0] = S.nodata[1][0] = 0;
+        if (tid >= 256u) {
+            // ---- the loader wave: chunk k + 1 travels while chunk k is shaded; one barrier per chunk, matched by the shading waves
+            __builtin_amdgcn_s_setprio(3);
+            dma_issue(s_buf + (k_begin & 1u) * buf_texels, ymin, slots);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();  // chunk k_begin is in LDS
+            for (uint32_t k = k_begin; k + 1 < k_end; k++) {
+                // the buffer of chunk k + 1 was read last for chunk k - 1: every shading wave has passed that chunk's barrier
+                window(k + 1, ymin, slots);
+                dma_issue(s_buf + ((k + 1) & 1u) * buf_texels, ymin, slots);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_barrier();  // end of chunk k
+            }
+            lds_barrier();  // the shading waves' last flag exchange
+            return;
+        }
+        nodata = false;
+    } else if constexpr (kDma) {
         if (tid == 0) S.nodata[0][0] = S.nodata[1][0] = 0;
         dma_issue(s_buf + (k_begin & 1u) * buf_texels, ymin, slots);
         nodata = false;
@@ -649,6 +707,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     // block-wide OR of the threads' bits around ONE barrier: a wave writes its ballot into the slot of the chunk's
     // parity, everybody reads the four slots after the barrier (the slot is rewritten two barriers later)
     auto any_nodata = [&](bool mine, uint32_t parity) -> bool {
+        if constexpr (kDma && kMode == 2) {  // the loader wave has seen the rows land; the stores of this wave stay in flight
+            lds_barrier();
+            return false;
+        }
         if constexpr (kDma) {  // a plain barrier behind the landing of this wave's DMA rows (and, one counter, its stores)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -678,7 +740,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         const bool more = k + 1 < k_end;
         if (more) {
             window(k + 1, next_ymin, next_slots);
-            if constexpr (kDma) {
+            if constexpr (kDma && kMode != 2) {
                 if (BT_ABLATE(A, 2048u)) __builtin_amdgcn_s_setprio(3);  // (2048: the DMA issue at top priority — timing experiment)
                 dma_issue(s_buf + ((k + 1) & 1u) * buf_texels, next_ymin, next_slots);
             }
@@ -1067,7 +1129,8 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         has_nodata = any_nodata(nodata, (k + 1) & 1u);
     }
     if constexpr (kDma) {  // the last chunk's flag
-        __syncthreads();
+        if constexpr (kMode == 2) lds_barrier();
+        else __syncthreads();
         if (tid == 0 && k_end > k_begin && S.nodata[(k_end - 1u) & 1u][0]) A.todo[2 + atomicAdd(&A.todo[0], 1u)] = item_index * chunks_per_tile + (k_end - 1u);
     }
 #ifdef BT_DEBUG_HOOKS
@@ -1077,8 +1140,8 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
 }
 
 // fast / non-staged variants: workgroup = (tile, part of its chunks), XCD-contiguous order
-template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP, bool kDma = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_main_kernel(FusedArgs A) {
+template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP, bool kDma = false, uint32_t kMode = 0>
+__global__ __launch_bounds__(kMode == 2 ? 320 : 256) __attribute__((amdgpu_waves_per_eu(kMode == 2 ? 5 : 4, kMode == 2 ? 5 : 4))) void fused_main_kernel(FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t work = BT_ABLATE(A, 1024u) ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);  // (1024: dispatch order, no XCD remap)
     const uint32_t chunks_per_tile = (A.m.center_size + kMainRows - 1) / kMainRows;
@@ -1090,7 +1153,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #include "bt_fused_debug.inc"  // (static wave priority by dispatch rank: timing experiment)
 #undef BT_FUSED_DEBUG_ENTRY_PRIORITY
 #endif
-    fused_main_chunks<kStaged, kGeneric, kT, kP, kDma>(A, work / A.groups, k_begin, k_end, smem);
+    fused_main_chunks<kStaged, kGeneric, kT, kP, kDma, kMode>(A, work / A.groups, k_begin, k_end, smem);
 }
 
 // the b x b apron corners of the finest tiles: governed by the diagonal neighbour alone (stitch.wgsl:57-66,
@@ -1717,6 +1780,7 @@ struct FusedJobDev {  // one fused launch of a compiled queue
     uint32_t main_runs = 0;  // parity selects the todo list
     uint32_t lds_pad = 0;    // profiling build only (BT_FUSED_LDS_PAD at plan time): extra dynamic LDS per workgroup
     bool dma = false;        // fused_main stages through LDS-DMA (every raster of the job 16-byte aligned in base and pitch)
+    uint32_t mode = 2;       // kMode of the LDS-DMA variant (profiling build: BT_FUSED_MODE)
     std::vector<MainItem> host_items;  // fused_main's items as uploaded (tile-row order): streamed runs cut them into bands
     float tly = 0.0f, bry = 1.0f;
 };
@@ -2116,6 +2180,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             }
 #ifdef BT_DEBUG_HOOKS
             if (const char* e = getenv("BT_FUSED_DMA")) main_job.dma = main_job.dma && atoi(e) != 0;
+            if (const char* e = getenv("BT_FUSED_MODE")) main_job.mode = uint32_t(atoi(e));
 #endif
         }
         Launch lm{};
@@ -2311,7 +2376,11 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
         if (job.args.lds_rows) {
             size_t lds = sizeof(MainShared) + 2 * size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
             lds = std::min<size_t>(65536, lds + job.lds_pad);  // (occupancy experiments)
-            if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528 && job.dma)
+            if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528 && job.dma && job.mode == 2)
+                fused_main_kernel<true, false, 512, 528, true, 2><<<blocks, 320, lds, p->ctx->stream>>>(job.args);
+            else if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528 && job.dma && job.mode == 1)
+                fused_main_kernel<true, false, 512, 528, true, 1><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
+            else if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528 && job.dma)
                 fused_main_kernel<true, false, 512, 528, true><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
             else if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528)
                 fused_main_kernel<true, false, 512, 528><<<blocks, 256, lds, p->ctx->stream>>>(job.args);

@@ -1091,6 +1091,13 @@ bt_status bt_preprocessor_create(bt_ctx* ctx, bt_preprocessor** out) {
 }
 
 static void release_rasters(bt_preprocessor* p) {
+    // kernels of an asynchronous run may still read these buffers; the hipFree this parking replaces synchronised implicitly
+    bool synced = false;
+    for (Raster& r : p->rasters)
+        if (r.owned && r.dev.data && !synced) {
+            hipStreamSynchronize(p->ctx->stream);
+            synced = true;
+        }
     for (Raster& r : p->rasters)
         if (r.owned && r.dev.data) {
             // keep the largest released buffer for the next queue's raster (bt_ctx::spare_raster)
@@ -1472,7 +1479,13 @@ bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* a, const ch
     // which tiles to write after which band: the finest tiles of its tile rows; everything else after the last launch
     const std::string terrain = std::string(assets_root) + "/" + a->config.path;
     const std::string dir = terrain + "/data/" + a->attachments[ai].cfg.name;
-    const uint32_t finest = [&] { uint32_t l = 0; for (const AtlasTileAttachment& t : a->to_save) l = std::max(l, t.coordinate.lod); return l; }();
+    // (entries of other attachments may wait in a->to_save from an earlier, unsaved run: they neither count here nor get lost below)
+    const uint32_t finest = [&] {
+        uint32_t l = 0;
+        for (const AtlasTileAttachment& t : a->to_save)
+            if (t.attachment_index == ai) l = std::max(l, t.coordinate.lod);
+        return l;
+    }();
     std::vector<std::vector<std::pair<uint32_t, bt_tile_coordinate>>> band_tiles(nb + 1);
     for (const AtlasTileAttachment& t : a->to_save) {
         if (t.attachment_index != ai || t.atlas_index == BT_INVALID_ATLAS_INDEX) continue;
@@ -1545,7 +1558,8 @@ bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* a, const ch
         if (rc == BT_OK && hipEventRecord(computed[k], p->ctx->stream) != hipSuccess) rc = BT_ERR_DEVICE;
         if (rc == BT_OK) publish(k + 1);
     }
-    r.pending = false;
+    // the raster counts as uploaded only when every band went out; after a failure a later run of the kept queue uploads it whole
+    if (rc == BT_OK) r.pending = false;
     for (size_t i = has_todo ? 2 : 1; i < p->plan.size() && rc == BT_OK; i++) rc = run_plan_entry(p, a, p->plan[i]);
     if (rc == BT_OK && hipEventRecord(computed[nb], p->ctx->stream) != hipSuccess) rc = BT_ERR_DEVICE;
     if (rc == BT_OK) publish(nb + 1);
@@ -1557,6 +1571,10 @@ bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* a, const ch
     saver.join();
     stamp("saver done", nb);
     hipStreamSynchronize(p->ctx->stream);
+    if (rc != BT_OK || save_rc != BT_OK) {  // nothing of this call may still read the caller's raster or write the pinned buffers
+        hipStreamSynchronize(p->ctx->copy_stream);
+        hipStreamSynchronize(p->ctx->save_stream);
+    }
     for (hipEvent_t e : uploaded) if (e) hipEventDestroy(e);
     for (hipEvent_t e : computed) if (e) hipEventDestroy(e);
     if (rc == BT_ERR_DEVICE) set_error("bt_preprocessor_run_streamed: HIP call failed (%s)", hipGetErrorString(hipGetLastError()));
@@ -1565,11 +1583,11 @@ bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* a, const ch
         set_error("%s", save_error);
         return save_rc;
     }
-    // tiles of other attachments (none in a streamable plan) and config.tc, as bt_preprocessor_save does
-    a->to_save.clear();
-    p->saves_recorded = false;
-    if (bt_status s = make_dirs(terrain)) return s;
-    if (bt_status s = bt_atlas_save_tile_config(a, (terrain + "/config.tc").c_str())) return s;
+    // the saver wrote exactly the entries of attachment `ai`; whatever else waits in the atlas's list (Save tasks of another
+    // attachment from an earlier run that was not saved yet) goes through bt_preprocessor_save, which also writes config.tc
+    a->to_save.erase(std::remove_if(a->to_save.begin(), a->to_save.end(), [&](const AtlasTileAttachment& t) { return t.attachment_index == ai; }),
+                     a->to_save.end());
+    if (bt_status s = bt_preprocessor_save(p, a, assets_root)) return s;
     st.streamed = 1;
     st.bands = uint32_t(nb);
     if (out) *out = st;

@@ -143,7 +143,11 @@ constexpr uint32_t kFrontierCap = 2048;                      // tiles of a pass 
 
 // first tile (x, y) of the window of (side, lod): centred on the view's tile of that LOD, clamped into the face
 __device__ __forceinline__ void window_origin(const bt_view_state& v, uint32_t side, uint32_t lod, int& ox, int& oy, int radius = kWinK) {
-    Coordinate vc{side, v.origin_lod, uint32_t(v.sides[side].view_xy[0]), uint32_t(v.sides[side].view_xy[1]), v.sides[side].view_uv[0], v.sides[side].view_uv[1]};
+    // view_xy is signed: on a neighbouring cube face the view's tile lies outside [0, 2^origin_lod); the window belongs at the
+    // face's NEAR edge then (cast to u32 first, a negative coordinate would end up clamped to the far one)
+    const int olast = int((1u << min(v.origin_lod, 30u)) - 1u);
+    const int vx = min(max(v.sides[side].view_xy[0], 0), olast), vy = min(max(v.sides[side].view_xy[1], 0), olast);
+    Coordinate vc{side, v.origin_lod, uint32_t(vx), uint32_t(vy), v.sides[side].view_uv[0], v.sides[side].view_uv[1]};
     coordinate_change_lod(vc, lod);
     const int last = int((1u << lod) - 1u);  // lod <= 31
     const int cx = min(max(int(vc.x), 0), last), cy = min(max(int(vc.y), 0), last);
