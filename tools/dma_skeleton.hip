@@ -109,9 +109,10 @@ template <int ARITH> __global__ __launch_bounds__(256) void v0(const uint8_t* sr
 
 // ------------------------------------------------------------------------------------------------ V1 / V2
 // DMA of source row y (relative to the tile's first row) into ring slot y % 32: one 1 KB instruction
+template <bool NT = false>
 __device__ __forceinline__ void dma_row(gbytes tile_base, lbytes ring, uint32_t y, uint32_t lane) {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(tile_base + uint64_t(y) * kPitch + lane * 16),
-                                     (void __attribute__((address_space(3)))*)(ring + (y & (kRing - 1)) * kRowMain), 16, 0, 0);
+                                     (void __attribute__((address_space(3)))*)(ring + (y & (kRing - 1)) * kRowMain), 16, 0, NT ? 2 : 0);
 }
 // the 32-byte tails of 8 consecutive rows y0 .. y0+7 (y0 a multiple of 8): lanes 0..15, two lanes per row
 __device__ __forceinline__ void dma_tails(gbytes tile_base, lbytes ring, uint32_t y0, uint32_t lane) {
@@ -120,7 +121,7 @@ __device__ __forceinline__ void dma_tails(gbytes tile_base, lbytes ring, uint32_
                                          (void __attribute__((address_space(3)))*)(ring + kTailBase + (y0 & (kRing - 1)) * kRowTail), 16, 0, 0);
 }
 
-template <int ARITH, bool LOADER_WAVE> __global__ __launch_bounds__(LOADER_WAVE ? 320 : 256) void v12(const uint8_t* src, uint8_t* tiles, uint8_t* parents, int stores) {
+template <int ARITH, bool LOADER_WAVE, bool NTL = false, bool NTS = false> __global__ __launch_bounds__(LOADER_WAVE ? 320 : 256) void v12(const uint8_t* src, uint8_t* tiles, uint8_t* parents, int stores) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kRing * (kRowMain + kRowTail)];
     uint32_t tx, ty;
     tile_of(tx, ty);
@@ -130,7 +131,7 @@ template <int ARITH, bool LOADER_WAVE> __global__ __launch_bounds__(LOADER_WAVE 
     // prologue: rows 0 .. 17 (chunks 0 and 1; the tails in groups of 8, rows 16..23 complete with the first in-loop group)
     if (LOADER_WAVE ? wave == 4 : true) {
         const uint32_t nw = LOADER_WAVE ? 1 : 4, w = LOADER_WAVE ? 0 : wave;
-        for (uint32_t y = w; y < 18; y += nw) dma_row(base, ring, y, lane);
+        for (uint32_t y = w; y < 18; y += nw) dma_row<NTL>(base, ring, y, lane);
         if (w == 0) {
             dma_tails(base, ring, 0, lane);
             dma_tails(base, ring, 8, lane);
@@ -145,7 +146,7 @@ template <int ARITH, bool LOADER_WAVE> __global__ __launch_bounds__(LOADER_WAVE 
             const uint32_t y0 = 8 * k + 18;
             if (k + 2 < 64 + 1) {
 #pragma unroll
-                for (uint32_t i = 0; i < 8; i++) dma_row(base, ring, y0 + i, lane);
+                for (uint32_t i = 0; i < 8; i++) dma_row<NTL>(base, ring, y0 + i, lane);
                 dma_tails(base, ring, 8 * k + 24, lane);
                 asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  // everything but this group
             }
@@ -168,8 +169,8 @@ template <int ARITH, bool LOADER_WAVE> __global__ __launch_bounds__(LOADER_WAVE 
     for (uint32_t k = 0; k < 64; k++) {
         if (!LOADER_WAVE) {  // every wave streams two rows of the group two chunks ahead (wave 0 also the tails)
             const uint32_t y0 = 8 * k + 18 + 2 * wave;
-            dma_row(base, ring, y0, lane);
-            dma_row(base, ring, y0 + 1, lane);
+            dma_row<NTL>(base, ring, y0, lane);
+            dma_row<NTL>(base, ring, y0 + 1, lane);
             if (wave == 0) dma_tails(base, ring, 8 * k + 24, lane);
         }
         const uint32_t slot0 = (8 * k) & (kRing - 1);
@@ -189,11 +190,17 @@ template <int ARITH, bool LOADER_WAVE> __global__ __launch_bounds__(LOADER_WAVE 
             for (uint32_t r = 0; r < 4; r++) row[(ko * 8 + (tid >> 7) * 4 + r) * 128] = u32x2{out[2 * r], out[2 * r + 1]};
         } else if (stores & 1) {
 #pragma unroll
-            for (uint32_t r = 0; r < 8; r++) d5[(ko * 8 + r) * 256] = out[r];
+            for (uint32_t r = 0; r < 8; r++) {
+                if (NTS) __builtin_nontemporal_store(out[r], &d5[(ko * 8 + r) * 256]);
+                else d5[(ko * 8 + r) * 256] = out[r];
+            }
         }
         if ((stores & 2) && (tid & 1u) == 0) {
 #pragma unroll
-            for (uint32_t r = 0; r < 4; r++) d4[(ko * 4 + r) * 256] = out[2 * r] + out[2 * r + 1];
+            for (uint32_t r = 0; r < 4; r++) {
+                if (NTS) __builtin_nontemporal_store(out[2 * r] + out[2 * r + 1], &d4[(ko * 4 + r) * 256]);
+                else d4[(ko * 4 + r) * 256] = out[2 * r] + out[2 * r + 1];
+            }
         }
         if (!LOADER_WAVE) {
             // the rows of chunk k + 1 were issued one iteration ago, BEFORE the stores of chunk k - 1: everything issued since
@@ -220,7 +227,7 @@ template <typename F> static float timeit(F f) {
     return ms * 10;
 }
 
-int main() {
+int main(int argc, char** argv) {
     uint8_t *src, *tiles, *parents;
     hipMalloc(&src, 16384ull * kPitch + (1 << 20));  // the last tiles' windows run 32 bytes and 18 rows past the raster
     hipMalloc(&tiles, 1024ull * 524288 + 4096);
@@ -228,6 +235,23 @@ int main() {
     hipMemset(src, 3, 16384ull * kPitch + (1 << 20));
     for (int i = 0; i < 200; i++) v0<0><<<1024, 256>>>(src, tiles, parents, 3);
     hipDeviceSynchronize();
+    if (argc > 1 && !strcmp(argv[1], "nt")) {  // round 4: every source row read once (V1's ring) — does the non-temporal policy pay in the tile-stream pattern?
+        for (int rep = 0; rep < 2; rep++) {
+            printf("V1 arith  0: plain %6.1f   nt loads %6.1f   nt stores %6.1f   both %6.1f us\n", timeit([&] { v12<0, false, false, false><<<1024, 256>>>(src, tiles, parents, 3); }),
+                   timeit([&] { v12<0, false, true, false><<<1024, 256>>>(src, tiles, parents, 3); }), timeit([&] { v12<0, false, false, true><<<1024, 256>>>(src, tiles, parents, 3); }),
+                   timeit([&] { v12<0, false, true, true><<<1024, 256>>>(src, tiles, parents, 3); }));
+            printf("V1 arith 24: plain %6.1f   nt loads %6.1f   nt stores %6.1f   both %6.1f us\n", timeit([&] { v12<24, false, false, false><<<1024, 256>>>(src, tiles, parents, 3); }),
+                   timeit([&] { v12<24, false, true, false><<<1024, 256>>>(src, tiles, parents, 3); }), timeit([&] { v12<24, false, false, true><<<1024, 256>>>(src, tiles, parents, 3); }),
+                   timeit([&] { v12<24, false, true, true><<<1024, 256>>>(src, tiles, parents, 3); }));
+            printf("V1 arith 48: plain %6.1f   nt loads %6.1f   nt stores %6.1f   both %6.1f us\n", timeit([&] { v12<48, false, false, false><<<1024, 256>>>(src, tiles, parents, 3); }),
+                   timeit([&] { v12<48, false, true, false><<<1024, 256>>>(src, tiles, parents, 3); }), timeit([&] { v12<48, false, false, true><<<1024, 256>>>(src, tiles, parents, 3); }),
+                   timeit([&] { v12<48, false, true, true><<<1024, 256>>>(src, tiles, parents, 3); }));
+            printf("V2 arith 24: plain %6.1f   nt loads %6.1f   both %6.1f us\n", timeit([&] { v12<24, true, false, false><<<1024, 320>>>(src, tiles, parents, 3); }),
+                   timeit([&] { v12<24, true, true, false><<<1024, 320>>>(src, tiles, parents, 3); }), timeit([&] { v12<24, true, true, true><<<1024, 320>>>(src, tiles, parents, 3); }));
+            fflush(stdout);
+        }
+        return 0;
+    }
     const char* names[4] = {"loads only", "loads + finest stores", "loads + parent stores", "loads + finest + parent stores"};
     for (int stores = 0; stores < 4; stores++) {
         printf("%-32s arith 0 : V0 %6.1f  V1 %6.1f  V2 %6.1f us\n", names[stores], timeit([&] { v0<0><<<1024, 256>>>(src, tiles, parents, stores); }),
