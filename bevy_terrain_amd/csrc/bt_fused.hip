@@ -48,7 +48,6 @@ constexpr uint32_t kMaxBorder = 8;
 
 struct MainItem {  // one finest-LOD tile
     uint32_t side, x, y, atlas_index, raster;
-    uint32_t ring_row;  // row of FusedArgs::ring that holds the staging schedule of this tile's chunks (same for every tile of a tile row)
 };
 
 struct FusedArgs {
@@ -66,13 +65,9 @@ struct FusedArgs {
     uint32_t sides;       // fused_tail: 1 or 6
     uint32_t lds_pitch;   // fused_main: texels per staged source row (multiple of 8)
     uint32_t lds_rows;    // fused_main: staged source rows that fit
-    const uint32_t* ring; // fused_main, loader-wave variant: [ring_row * chunks_per_tile + k] = first row of chunk k's window in the LDS arena | (chunk at whose start the loader may request it) << 16
-    uint32_t* todo;       // fused_main: [0] count, [2..] chunks (item * chunks_per_tile + k) left to the generic variant
-    uint32_t* todo_next;  // the list of the NEXT run (the two alternate): fused_todo zeroes its count, so no reset protocol
     uint32_t apron_lods;  // fused_tail: LODs lod, lod+1, ... (this many) get their top / bottom apron rows from extra workgroups
     uint32_t rotate_priority;  // fused_main: wave priority rotates with the chunk index (see fused_main_chunks)
     uint32_t apron_cols;  // fused_tail (Rgba8 after fused_direct, which writes centres only): ... and their left / right apron columns
-    uint32_t extra_valu;  // debug only (env BT_FUSED_EXTRA_VALU): packed fma instructions added to every chunk — how sensitive is the kernel to its VALU count?
     uint32_t ablate;      // debug only (env BT_FUSED_ABLATE): 1 no pyramid, 2 no finest stores, 4 no parent stores, 64 no grand-parent stores (static path), 8 no staging loads, 16 prologue only, 256 / 512 finest / parent stores without arithmetic (use with 16); skeleton shapes: 65536 parent rows in bursts of four chunks, 262144 parent rows as 16-byte stores, 1048576 finest rows as 16-byte stores
 };
 
@@ -350,34 +345,6 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
-// LDS-DMA by hand (global_load_lds_dwordx4: 64 lanes x 16 bytes, per-lane global addresses, LDS destination = M0 + lane * 16).
-// The builtin makes the compiler guard every later LDS read with s_waitcnt vmcnt(0) (it cannot prove that the read does not
-// alias the DMA's destination), i.e. a wave would wait for the rows it has just requested for the NEXT chunk before it shades
-// the current one; from inline assembly the instruction is invisible to that pass and every wait is written out here.
-typedef const uint8_t __attribute__((address_space(1))) * dma_global;
-template <bool kNt = false>
-__device__ __forceinline__ void dma16(dma_global g, uint32_t lds_addr /* wave-uniform */) {
-    if constexpr (kNt) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(lds_addr), "v"(g) : "memory");
-    else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(g) : "memory");
-}
-// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the wave's global stores (vmcnt(0)), which
-// nothing in this workgroup reads back
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// s_waitcnt vmcnt(n) for a wave-uniform n: all but the n youngest vector-memory operations of this wave have completed
-// (a smaller immediate than the true count only waits longer)
-__device__ __forceinline__ void wait_vmcnt_le(uint32_t n) {
-#define BT_VMCNT_CASE(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
-    switch (min(n, 31u)) {
-        BT_VMCNT_CASE(0) BT_VMCNT_CASE(1) BT_VMCNT_CASE(2) BT_VMCNT_CASE(3) BT_VMCNT_CASE(4) BT_VMCNT_CASE(5) BT_VMCNT_CASE(6) BT_VMCNT_CASE(7)
-        BT_VMCNT_CASE(8) BT_VMCNT_CASE(9) BT_VMCNT_CASE(10) BT_VMCNT_CASE(11) BT_VMCNT_CASE(12) BT_VMCNT_CASE(13) BT_VMCNT_CASE(14) BT_VMCNT_CASE(15)
-        BT_VMCNT_CASE(16) BT_VMCNT_CASE(17) BT_VMCNT_CASE(18) BT_VMCNT_CASE(19) BT_VMCNT_CASE(20) BT_VMCNT_CASE(21) BT_VMCNT_CASE(22) BT_VMCNT_CASE(23)
-        BT_VMCNT_CASE(24) BT_VMCNT_CASE(25) BT_VMCNT_CASE(26) BT_VMCNT_CASE(27) BT_VMCNT_CASE(28) BT_VMCNT_CASE(29) BT_VMCNT_CASE(30)
-        default: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
-    }
-#undef BT_VMCNT_CASE
-}
-
 struct RowParam {  // one centre row of the workgroup: LDS slots of its two source rows + the y weight
     int y0, y1;
     float fy;
@@ -388,14 +355,13 @@ constexpr uint32_t kMaxChunks = 64;  // chunks one workgroup may run through (T 
 struct MainShared {  // fixed part of the dynamic LDS block (size is a multiple of 16 bytes)
     // row tables of ALL chunks of the workgroup's run, written once in the prologue; index = (k - k_begin) * kMainRows + row
     int row_y0[kMaxChunks * kMainRows];    // first source row; bit 31: the second source row is the same one (clamped)
-    float row_fy[kMaxChunks * kMainRows];  // y weights: read by every lane at one address (a broadcast), used as they arrive
+    float2 row_fy[kMaxChunks * kMainRows];  // y weights (fy, 1 - fy): read by every lane at one address (a broadcast), used as they arrive
     int win_ymin[kMaxChunks];              // source window of a chunk: first row ...
     uint32_t win_slots[kMaxChunks];        // ... and row count; bit 31: the chunk's rows use source rows y, y+1, ..., y+kMainRows
-    uint32_t win_pos[kMaxChunks];          // loader-wave variant: the chunk's entry of FusedArgs::ring
     uint32_t nodata[2][4];                 // [chunk parity][wave]: the staged window holds a no-data texel; kDma: [parity][0] = some thread of the chunk read one
     RowParam apron[2 * kMaxBorder];  // [0, b): top apron rows, [b, 2b): bottom apron rows (pad = mosaic row ry)
     int xmin, xmax;
-    uint32_t pad[2];
+    uint32_t redo[2];  // fast variants: bit (k - k_begin) = chunk k saw a no-data texel and is redone by the generic rows after the run
 };
 static_assert(sizeof(MainShared) % 16 == 0, "LDS carve must stay 16-byte aligned");
 
@@ -415,21 +381,40 @@ __device__ __forceinline__ Texel4 convert4(uint32_t ta0, uint32_t ta1, uint32_t 
     return r;
 }
 
+// the b x b apron corners of the finest tiles: governed by the diagonal neighbour alone (stitch.wgsl:57-66,
+// 105-118) — its centre corner if it exists, else the own centre corner — evaluated with the general formula
+__device__ __forceinline__ void corner_pixels(const FusedArgs& A, uint32_t item_index, uint32_t tid, uint32_t threads) {
+    const MainItem it = A.items[item_index];
+    const RasterDev raster = A.rasters[it.raster];
+    const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
+    const uint32_t self = grid_lookup(A, it.side, A.lod, int(it.x), int(it.y));
+    for (uint32_t t = tid; t < 4 * b * b; t += threads) {
+        const uint32_t corner = t / (b * b), i = (t % (b * b)) % b, j = (t % (b * b)) / b;
+        const bool left = corner == 0 || corner == 3, top = corner < 2;  // 0 NW, 1 NE, 2 SE, 3 SW
+        const uint32_t px = left ? i : o + i, py = top ? j : o + j;
+        const uint32_t n = grid_lookup(A, it.side, A.lod, int(it.x) + (left ? -1 : 1), int(it.y) + (top ? -1 : 1));
+        uint32_t v;
+        if (n != kInvalid)
+            v = split_value_slow(A, raster, left ? it.x - 1 : it.x + 1, left ? c - b + i : i, top ? it.y - 1 : it.y + 1, top ? c - b + j : j, n);
+        else
+            v = split_value_slow(A, raster, it.x, left ? 0u : c - 1, it.y, top ? 0u : c - 1, self);
+        A.atlas[uint64_t(self) * T * T + py * T + px] = uint16_t(v);
+    }
+}
+
 // kGeneric == false: the fast variant (packed f32, no validity bookkeeping).  A chunk whose source window holds a
-// no-data texel is not processed but appended to A.todo; the kGeneric == true variant then runs exactly those
-// chunks with per-pixel validity, the keep-previous rule and the valid-average.  (Keeping both loops in one kernel
-// costs ~90 spilled VGPRs at the 4-waves-per-SIMD budget.)  kStaged == false reads the source directly (window too
-// large for LDS) and always takes the generic loop.
+// no-data texel is flagged in S.redo; when the run is through, the workgroup stages the flagged chunks once more and redoes
+// them with the generic rows (per-pixel validity, the keep-previous rule, the valid-average) — the same code the kGeneric
+// variant runs inside its loop, here behind the loop, where its registers do not add to the fast loop's (inside the loop
+// the two cost ~90 spilled VGPRs at the 4-waves-per-SIMD budget; rounds 1-3 therefore ran the generic rows as a launch of
+// their own, fused_todo, which was an empty 4096-wave launch + a kernel boundary on every clean input).  kStaged == false
+// reads the source directly (window too large for LDS) and always takes the generic loop.
 // kDma (fast staged variant only, rasters 16-byte aligned): the source rows of the next chunk travel global -> LDS by
 // LDS-DMA (global_load_lds_dwordx4: no staging registers, no commit pass); the no-data test moves from the staging pass to
 // the texels each thread actually reads, per thread: a thread (pair) that saw a no-data texel stores nothing for that
-// quad of rows and flags the chunk for fused_todo, whose generic pass rewrites the whole chunk (identical values where the
-// fast pass did store, keep-previous / valid-average where it did not).
-// kMode (kDma only): 0 = every wave moves its share of the rows through the builtin; 1 = the same through dma16 (no compiler
-// waits); 2 = LOADER WAVE: the workgroup has a fifth wave that does nothing but move source rows (one chunk ahead) and is the only
-// one that ever waits on the vector-memory counter — the four shading waves issue their stores and go on (their barrier orders
-// LDS only), so neither the latency of the rows nor the drain of the stores sits in a shading wave's time line.
-template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP, bool kDma = false, uint32_t kMode = 0>
+// quad of rows and flags the chunk; the redo behind the loop rewrites the whole chunk (identical values where the fast pass
+// did store, keep-previous / valid-average where it did not).
+template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP, bool kDma = false>
 __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t item_index, uint32_t k_begin, uint32_t k_end, uint8_t* smem) {
     MainShared& S = *reinterpret_cast<MainShared*>(smem);
     uint16_t* s_buf = reinterpret_cast<uint16_t*>(smem + sizeof(MainShared));
@@ -458,7 +443,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         if (cr < c) {
             const Axis ay = split_axis(cr, c, it.y, scale, A.tly, A.bry, raster.height);
             S.row_y0[i] = ay.i0 | (ay.i1 == ay.i0 ? int(0x80000000u) : 0);
-            S.row_fy[i] = ay.fr;
+            S.row_fy[i] = float2{ay.fr, 1.0f - ay.fr};
         }
     }
     if (tid >= 32 && tid < 32 + 2 * b) {
@@ -503,6 +488,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     // atlas tile holding each column's pixels (keep-previous rule reads it when the source has no data)
     const uint32_t home_col = is_right && t5.e != kInvalid ? t5.e : (is_left && t5.w != kInvalid ? t5.w : t5.self);
 
+    if (tid == 0) S.redo[0] = S.redo[1] = 0;
     // the first left-apron pair reads the leftmost source column, the last right-apron pair the rightmost
     if (tid == half_c + half_b) S.xmin = min(axa.i0, axb.i0);
     if (tid == half_c + half_b - 1) S.xmax = max(axa.i1, axb.i1);
@@ -519,7 +505,6 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         if (k == chunks_per_tile - 1) hi = max(hi, S.apron[2 * b - 1].y1);
         S.win_ymin[tid] = lo;
         S.win_slots[tid] = uint32_t(hi - lo + 1) | (consecutive ? 0x80000000u : 0u);
-        if constexpr (kDma && (kMode == 2 || kMode == 3)) S.win_pos[tid] = A.ring[it.ring_row * chunks_per_tile + k];
     }
     __syncthreads();
 
@@ -540,11 +525,6 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     constexpr uint32_t kBatch = 4;  // 16-byte loads per thread and chunk (host guarantees slots * pitch / 8 <= 256 * kBatch)
 
     auto chunk_rows = [&](uint32_t k) -> uint32_t { return min(kMainRows, c - k * kMainRows); };
-    // where chunk k's source rows are staged: the two halves alternate; loader-wave variant: at the arena row the host's schedule names
-    auto chunk_buf = [&](uint32_t k) -> uint16_t* {
-        if constexpr (kDma && (kMode == 2 || kMode == 3)) return s_buf + (uint32_t(__builtin_amdgcn_readfirstlane(int(S.win_pos[k - k_begin]))) & 0xFFFFu) * (kP ? kP : A.lds_pitch);
-        else return s_buf + (k & 1u) * buf_texels;
-    };
     auto window = [&](uint32_t k, int& ymin, uint32_t& slots) {  // workgroup-uniform
         ymin = __builtin_amdgcn_readfirstlane(S.win_ymin[k - k_begin]);
         slots = uint32_t(__builtin_amdgcn_readfirstlane(S.win_slots[k - k_begin])) & 0x7fffffffu;
@@ -610,32 +590,11 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     const uint32_t dma_lane = tid & 63u;
     const uint32_t dma_off_main = min(uint32_t(xa) * 2u + dma_lane * 16u, uint32_t(raster.pitch) - 16u);
     const uint32_t dma_off_tail = min(uint32_t(xa) * 2u + 1024u + (dma_lane & 1u) * 16u, uint32_t(raster.pitch) - 16u);
-    auto dma_issue = [&](uint16_t* s_dst, int ymin, uint32_t slots) -> uint32_t {  // returns the number of instructions issued (loader-wave variant)
+    auto dma_issue = [&](uint16_t* s_dst, int ymin, uint32_t slots) {
         static_assert(!kDma || kP == 528, "the DMA variant assumes 1056-byte LDS rows");
         const lds_bytes dst = (lds_bytes)reinterpret_cast<uint8_t*>(s_dst);
-        if constexpr (kMode == 2 || kMode == 3) {
-            // the loader wave fills the window as ONE linear run of LDS bytes (rows of 1056 bytes follow each other): 1 KB per
-            // instruction, every lane fetches the 16 source bytes that belong at its LDS address (a piece may straddle two rows)
-            const uint32_t base = uint32_t(reinterpret_cast<uintptr_t>(dst)), bytes = slots * (kP * 2u);
-            for (uint32_t off = 0; off < bytes; off += 1024u) {  // wave-uniform
-                const uint32_t l = off + dma_lane * 16u, slot = l / (kP * 2u), within = l - slot * (kP * 2u);
-                if (l < bytes) {
-                    const uint32_t goff = min(uint32_t(xa) * 2u + within, uint32_t(raster.pitch) - 16u);
-                    const dma_global g = (dma_global)(data + uint64_t(uint32_t(ymin) + slot) * raster.pitch + goff);
-                    if (BT_ABLATE(A, 32768u)) dma16<true>(g, __builtin_amdgcn_readfirstlane(base + off));
-                    else dma16<false>(g, __builtin_amdgcn_readfirstlane(base + off));
-                }
-            }
-            return (bytes + 1023u) / 1024u;
-        }
         for (uint32_t slot = tid >> 6; slot < slots; slot += 4u) {  // wave-uniform
             const global_bytes row = data + uint64_t(uint32_t(ymin) + slot) * raster.pitch;
-            if constexpr (kMode == 1 || kMode == 4) {
-                const uint32_t base = uint32_t(reinterpret_cast<uintptr_t>(dst)) + slot * (kP * 2u);
-                dma16<false>((dma_global)(row + dma_off_main), __builtin_amdgcn_readfirstlane(base));
-                if (dma_lane < 2u) dma16<false>((dma_global)(row + dma_off_tail), __builtin_amdgcn_readfirstlane(base + 1024u));
-                continue;
-            }
             if (BT_ABLATE(A, 32768u))  // (32768: the non-temporal policy on the source stream — timing experiment)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + dma_off_main),
                                                  (__attribute__((address_space(3))) void*)(dst + slot * (kP * 2u)), 16, 0, 2);
@@ -646,7 +605,6 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + dma_off_tail),
                                                  (__attribute__((address_space(3))) void*)(dst + slot * (kP * 2u) + 1024u), 16, 0, 0);
         }
-        return 0u;
     };
     // exchange inside the lane pair (2m, 2m+1): quad_perm [1, 0, 3, 2]
     auto pair_min = [](uint32_t v) -> uint32_t { return min(v, uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0xB1, 0xf, 0xf, true))); };
@@ -658,10 +616,37 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     const uint32_t cx4 = (it.x & 1u) * half_c + tid, cy4_base = (it.y & 1u) * half_c;
     const uint32_t cx3 = (it.x & 3u) * (c / 4) + (tid >> 1), cy3_base = (it.y & 3u) * (c / 4);
     const bool do4 = A.levels >= 2 && !BT_ABLATE(A, 1u), do3 = A.levels >= 3 && !BT_ABLATE(A, 1u);
-    // (The left / right apron columns of the parent and grand-parent tiles are not written here: like their top / bottom rows they
-    // come from the launch that follows — fused_tail's apron workgroups or the stitch launch — which reads the finished centres.
-    // Rounds 1-3 pushed them from registers: 2-byte scattered stores, ~20 VALU instructions and 8 long-lived registers per thread
-    // for the sake of ~0.4 % of the bytes.)
+    // Left / right apron columns of the parent (shift 1) and grand-parent (shift 2) tile: a centre column within b of
+    // the tile's x edge is also the x neighbour's apron column (stitch.wgsl:79-88); with that neighbour absent the
+    // own apron repeats the edge column (stitch.wgsl:105-118) and the edge column's thread writes all b of them.
+    // Per thread and level: element offset of the first extra texel in the row of centre row 0, and how many.
+    auto make_xpush = [&](uint32_t shift, uint32_t self, uint32_t cx, uint32_t& off, uint32_t& count) {
+        off = 0;
+        count = 0;
+        if (!is_centre || self == kInvalid) return;
+        // cx is the column in the PARENT tile (it already carries this finest tile's share of it): with narrow tiles
+        // (c / 2^shift < b) the strip of width b spans more than one finest tile's share
+        const bool left = cx < b, right = cx >= c - b;
+        if (!left && !right) return;
+        const uint32_t n = grid_lookup(A, it.side, A.lod - shift, int(it.x >> shift) + (left ? -1 : 1), int(it.y >> shift));
+        const uint32_t j = left ? cx : cx - (c - b);
+        if (n != kInvalid) {
+            off = n * tile_texels + b * T + (left ? o + j : j);
+            count = 1;
+        } else if (left ? cx == 0 : cx == c - 1) {
+            off = self * tile_texels + b * T + (left ? 0u : o);
+            count = b;
+        }
+    };
+    uint32_t x4_off, x4_count, x3_off, x3_count;
+    make_xpush(1, A.levels >= 2 ? self4 : kInvalid, cx4, x4_off, x4_count);
+    make_xpush(2, A.levels >= 3 ? self3 : kInvalid, cx3, x3_off, x3_count);
+    auto xpush4 = [&](uint32_t cy, uint16_t v) {  // cy: centre row in the parent tile
+        for (uint32_t e = 0; e < x4_count; e++) A.atlas[x4_off + cy * T + e] = v;
+    };
+    auto xpush3 = [&](uint32_t cy, uint16_t v) {
+        for (uint32_t e = 0; e < x3_count; e++) A.atlas[x3_off + cy * T + e] = v;
+    };
     // LDS offsets of this thread's four source columns (idle lanes read column 0 and store nothing)
     const uint32_t la0 = uint32_t(axa.i0 - xa), la1 = uint32_t(axa.i1 - xa), lb0 = uint32_t(axb.i0 - xa), lb1 = uint32_t(axb.i1 - xa);
 
@@ -671,59 +656,25 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     bool nodata = !kStaged;
     u32x4 pre[kBatch];
     window(k_begin, ymin, slots);
-    if constexpr (kDma && (kMode == 2 || kMode == 3)) {
+    if constexpr (kDma) {
         if (tid == 0) S.nodata[0][0] = S.nodata[1][0] = 0;
-        if (tid >= 256u) {
-            // ---- the loader wave.  The host's schedule (FusedArgs::ring) places every chunk's window in the LDS arena and names
-            // the chunk at whose start it may be requested (its rows then overwrite a window no shading wave reads any more):
-            // up to two chunks ahead of the one being shaded.  One barrier per chunk, matched by the shading waves; this wave
-            // issues nothing but the DMA, so "all but the n youngest operations" is exact.
-            __builtin_amdgcn_s_setprio(3);
-            uint32_t q = k_begin, n_last = 0, n_prev = 0;  // next chunk to request; instruction counts of the last two requests
-            auto pump = [&](uint32_t now) {
-                while (q < k_end) {
-                    const uint32_t e = uint32_t(__builtin_amdgcn_readfirstlane(int(S.win_pos[q - k_begin])));
-                    if ((e >> 16) > now) break;
-                    window(q, ymin, slots);
-                    n_prev = n_last;
-                    n_last = dma_issue(s_buf + (e & 0xFFFFu) * P, ymin, slots);
-                    q++;
-                }
-            };
-            auto landed = [&](uint32_t x) {  // chunk x (requested: the schedule guarantees it) is in LDS
-                wait_vmcnt_le((q > x + 1u ? n_last : 0u) + (q > x + 2u ? n_prev : 0u));
-            };
-            pump(k_begin);
-            landed(k_begin);
-            lds_barrier();  // chunk k_begin may be shaded
-            for (uint32_t k = k_begin; k + 1 < k_end; k++) {
-                if (k > k_begin) pump(k);
-                landed(k + 1);
-                lds_barrier();  // end of chunk k
-            }
-            lds_barrier();  // the shading waves' last flag exchange
-            return;
-        }
-        nodata = false;
-    } else if constexpr (kDma) {
-        if (tid == 0) S.nodata[0][0] = S.nodata[1][0] = 0;
-        dma_issue(chunk_buf(k_begin), ymin, slots);
+        dma_issue(s_buf + (k_begin & 1u) * buf_texels, ymin, slots);
         nodata = false;
     } else if (kStaged && !BT_ABLATE(A, 8u)) {
         if (wide) {
             stage_issue(ymin, slots, pre);
-            nodata = stage_commit(chunk_buf(k_begin), slots, pre);
+            nodata = stage_commit(s_buf + (k_begin & 1u) * buf_texels, slots, pre);
         } else {
-            nodata = stage_narrow(chunk_buf(k_begin), ymin, slots);
+            nodata = stage_narrow(s_buf + (k_begin & 1u) * buf_texels, ymin, slots);
         }
+    }
+    // the tile's b x b apron corners (4 b^2 pixels by the general formula): evaluated while the first rows are on their way
+    if constexpr (kStaged) {
+        if (k_begin == 0) corner_pixels(A, item_index, tid, 256u);
     }
     // block-wide OR of the threads' bits around ONE barrier: a wave writes its ballot into the slot of the chunk's
     // parity, everybody reads the four slots after the barrier (the slot is rewritten two barriers later)
     auto any_nodata = [&](bool mine, uint32_t parity) -> bool {
-        if constexpr (kDma && (kMode == 2 || kMode == 3)) {  // the loader wave has seen the rows land; the stores of this wave stay in flight
-            lds_barrier();
-            return false;
-        }
         if constexpr (kDma) {  // a plain barrier behind the landing of this wave's DMA rows (and, one counter, its stores)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -739,44 +690,144 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         const uint32_t* f = S.nodata[parity];
         return __builtin_amdgcn_readfirstlane(int(f[0] | f[1] | f[2] | f[3])) != 0;
     };
+    // ---- per-chunk pieces shared by the loop and by the redo of flagged chunks behind it
+    uint16_t* s_src = s_buf;  // staged rows of the chunk being shaded ...
+    int cur_ymin = 0;         // ... and the source row of its first slot
+    uint32_t dirty = 0;       // kDma: this thread skipped stores in the current chunk
+    auto fetch_row = [&](int y) -> Texel4 {
+        if constexpr (kStaged) {
+            const uint16_t* row = s_src + uint32_t(y - cur_ymin) * P;
+            return convert4(row[la0], row[la1], row[lb0], row[lb1]);
+        } else {
+            const global_u16 row = (global_u16)(data + uint64_t(y) * raster.pitch);
+            return convert4(row[axa.i0], row[axa.i1], row[axb.i0], row[axb.i1]);
+        }
+    };
+    auto flag_chunk = [&](uint32_t kk) { S.redo[(kk - k_begin) >> 5] |= 1u << ((kk - k_begin) & 31u); };  // thread 0 only
+    // apron rows (first / last chunk of a tile only): the centre columns are rows like any other (the north / south
+    // neighbour's centre rows, or clamped into the own centre); the b x b corners follow the diagonal neighbour alone
+    // (stitch.wgsl:57-66, 105-118) and are written by corner_pixels.  gtag: with the keep-previous rule (generic rows) or without
+    auto apron_rows = [&](uint32_t k, auto gtag) {
+        constexpr bool kKeep = decltype(gtag)::value;
+        if (!((k == 0 || k == chunks_per_tile - 1) && is_centre)) return;
+        for (uint32_t r = 0; r < 2 * b; r++) {
+            const bool top = r < b;
+            if (top ? k != 0 : k != chunks_per_tile - 1) continue;
+            const uint32_t kk = r % b, py = top ? kk : o + kk;
+            const int y0 = __builtin_amdgcn_readfirstlane(S.apron[r].y0), y1 = __builtin_amdgcn_readfirstlane(S.apron[r].y1);
+            const float fy = S.apron[r].fy, gy = 1.0f - fy;
+            const Texel4 t0 = fetch_row(y0), t1 = fetch_row(y1);
+            uint32_t va = float_to_unorm16((t0.a0 * gxa + t0.a1 * fxa) * gy + (t1.a0 * gxa + t1.a1 * fxa) * fy);
+            uint32_t vb = float_to_unorm16((t0.b0 * gxb + t0.b1 * fxb) * gy + (t1.b0 * gxb + t1.b1 * fxb) * fy);
+            if (kKeep && min(min(t0.za, t1.za), min(t0.zb, t1.zb)) == 0) {
+                const uint32_t nrow = top ? t5.n : t5.s;
+                const uint16_t* h = A.atlas + uint64_t(nrow == kInvalid ? t5.self : nrow) * tile_texels + (b + S.apron[r].pad) * T + b;
+                if (min(t0.za, t1.za) == 0) va = h[rxa];
+                if (min(t0.zb, t1.zb) == 0) vb = h[rxb];
+            }
+            if (!kKeep && kDma && min(min(t0.za, t1.za), min(t0.zb, t1.zb)) == 0) {
+                dirty = 1;
+                continue;
+            }
+            tile5_u32[(py * T + px0) >> 1] = va | (vb << 16);
+        }
+    };
+    // the generic rows of chunk k: per-pixel validity (no-data texels), keep-previous rule, valid-average
+    auto generic_rows = [&](uint32_t k) {
+        const int* row_y0 = S.row_y0 + (k - k_begin) * kMainRows;
+        const float2* row_fy = S.row_fy + (k - k_begin) * kMainRows;
+        const uint32_t cr0 = k * kMainRows, nrows = chunk_rows(k);
+        // ---- generic loop: tracks per-pixel validity (no-data texels), keep-previous rule, valid-average
+        Texel4 cur{};
+        int cur_y = -1;
+        for (uint32_t q = 0; q < nrows; q += 4) {
+            uint32_t va[4], vb[4];
+            uint32_t zany = 1;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) {
+                const int yy = __builtin_amdgcn_readfirstlane(row_y0[q + i]);
+                const int y0 = yy & 0x7fffffff, y1 = y0 + (yy < 0 ? 0 : 1);
+                const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row_fy[q + i].x)));
+                const Texel4 top = (y0 == cur_y) ? cur : fetch_row(y0);
+                const Texel4 bot = (y1 == y0) ? top : fetch_row(y1);
+                cur = bot;
+                cur_y = y1;
+                const float gy = 1.0f - fy;
+                va[i] = float_to_unorm16((top.a0 * gxa + top.a1 * fxa) * gy + (bot.a0 * gxa + bot.a1 * fxa) * fy);
+                vb[i] = float_to_unorm16((top.b0 * gxb + top.b1 * fxb) * gy + (bot.b0 * gxb + bot.b1 * fxb) * fy);
+                const uint32_t za = min(top.za, bot.za), zb = min(top.zb, bot.zb);
+                zany = min(zany, min(za, zb));
+                // remember the validity in bit 16 (cleared below): 0x10000 = no data in the footprint
+                va[i] |= za == 0 ? 0x10000u : 0u;
+                vb[i] |= zb == 0 ? 0x10000u : 0u;
+            }
+            if (zany == 0) {  // some footprint had no data: those pixels keep their previous atlas value (split.wgsl:37-42)
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) {
+                    const uint16_t* h = A.atlas + uint64_t(home_col) * tile_texels + (b + cr0 + q + i) * T + b;
+                    if (va[i] & 0x10000u) va[i] = h[rxa];
+                    if (vb[i] & 0x10000u) vb[i] = h[rxb];
+                }
+            }
+            const uint32_t py = b + cr0 + q;
+            if (!is_idle) {
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) tile5_u32[((py + i) * T + px0) >> 1] = (va[i] & 0xFFFFu) | (vb[i] << 16);
+            }
+            if (do4) {
+                const uint32_t cy = cr0 + q;  // multiple of 4
+                const uint32_t q0 = downsample4(va[0] & 0xFFFFu, va[1] & 0xFFFFu, vb[0] & 0xFFFFu, vb[1] & 0xFFFFu);  // OFFSETS order
+                const uint32_t q1 = downsample4(va[2] & 0xFFFFu, va[3] & 0xFFFFu, vb[2] & 0xFFFFu, vb[3] & 0xFFFFu);
+                const uint32_t cy4 = cy4_base + (cy >> 1);
+                if (is_centre) {
+                    uint16_t* dst = tile4 + (b + cy4) * T + b + cx4;
+                    dst[0] = uint16_t(q0);
+                    dst[T] = uint16_t(q1);
+                }
+                if (x4_count) {
+                    xpush4(cy4, uint16_t(q0));
+                    xpush4(cy4 + 1, uint16_t(q1));
+                }
+                if (do3) {
+                    const uint32_t other0 = __shfl_xor(q0, 1), other1 = __shfl_xor(q1, 1);
+                    if (is_centre && (tid & 1u) == 0) {
+                        const uint32_t w = downsample4(q0, q1, other0, other1);
+                        tile3[(b + cy3_base + (cy >> 2)) * T + b + cx3] = uint16_t(w);
+                        if (x3_count) xpush3(cy3_base + (cy >> 2), uint16_t(w));
+                    }
+                }
+            }
+        }
+    };
+
     bool has_nodata = any_nodata(nodata, k_begin & 1u);
 
     for (uint32_t k = k_begin; k < k_end; k++) {
         const int* row_y0 = S.row_y0 + (k - k_begin) * kMainRows;
-        const float* row_fy = S.row_fy + (k - k_begin) * kMainRows;
+        const float2* row_fy = S.row_fy + (k - k_begin) * kMainRows;
         const uint32_t cr0 = k * kMainRows, nrows = chunk_rows(k);
-        uint16_t* s_src = chunk_buf(k);  // this chunk's staged rows
-        const int cur_ymin = ymin;
+        s_src = s_buf + (k & 1u) * buf_texels;  // this chunk's staged rows; the other half receives chunk k + 1
+        cur_ymin = ymin;
         // prefetch the next chunk's source rows while this one is shaded
         int next_ymin = 0;
         uint32_t next_slots = 0;
         const bool more = k + 1 < k_end;
         if (more) {
             window(k + 1, next_ymin, next_slots);
-            if constexpr (kDma && (kMode < 2 || kMode == 4)) {
+            if constexpr (kDma) {
                 if (BT_ABLATE(A, 2048u)) __builtin_amdgcn_s_setprio(3);  // (2048: the DMA issue at top priority — timing experiment)
-                dma_issue(chunk_buf(k + 1), next_ymin, next_slots);
+                dma_issue(s_buf + ((k + 1) & 1u) * buf_texels, next_ymin, next_slots);
             }
             else if (kStaged && wide && !BT_ABLATE(A, 8u)) stage_issue(next_ymin, next_slots, pre);
         }
-        // kDma: the chunk before this one was flagged by some thread: append it to the todo list (once), clear the flag
+        // kDma: the chunk before this one was flagged by some thread: note it for the redo (once), clear the flag
         if constexpr (kDma) {
             if (tid == 0 && k > k_begin && S.nodata[(k - 1u) & 1u][0]) {
                 S.nodata[(k - 1u) & 1u][0] = 0;
-                A.todo[2 + atomicAdd(&A.todo[0], 1u)] = item_index * chunks_per_tile + (k - 1u);
+                flag_chunk(k - 1u);
             }
         }
-        uint32_t dirty = 0;  // kDma: this thread skipped stores in this chunk
-
-        auto fetch_row = [&](int y) -> Texel4 {
-            if constexpr (kStaged) {
-                const uint16_t* row = s_src + uint32_t(y - cur_ymin) * P;
-                return convert4(row[la0], row[la1], row[lb0], row[lb1]);
-            } else {
-                const global_u16 row = (global_u16)(data + uint64_t(y) * raster.pitch);
-                return convert4(row[axa.i0], row[axa.i1], row[axb.i0], row[axb.i1]);
-            }
-        };
+        dirty = 0;
 
         // Wave priority rotating with the chunk index, offset by the workgroup's dispatch rank on its CU.  The CU's arbiters serve
         // the highest-priority wave first and, among equals, the OLDEST — strictly: without this the four resident workgroups
@@ -797,36 +848,11 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
 #include "bt_fused_debug.inc"  // (per-chunk time stamps, rotating wave priorities: timing experiments)
 #undef BT_FUSED_DEBUG_CHUNK_PROBES
 #endif
-        // a chunk with no-data goes to the generic variant as a whole
+        // a chunk with no-data goes to the generic rows as a whole
         const bool skip_chunk = !kGeneric && has_nodata;
-        if (skip_chunk && tid == 0) A.todo[2 + atomicAdd(&A.todo[0], 1u)] = item_index * chunks_per_tile + k;
+        if (skip_chunk && tid == 0) flag_chunk(k);
 
-        // ---- apron rows (first / last chunk of a tile only): the centre columns are rows like any other (the
-        // north / south neighbour's centre rows, or clamped into the own centre); the b x b corners follow the
-        // diagonal neighbour alone (stitch.wgsl:57-66, 105-118) and are written by corner_pixels (fused_todo / fused_corner).
-        if ((k == 0 || k == chunks_per_tile - 1) && is_centre && !skip_chunk) {
-            for (uint32_t r = 0; r < 2 * b; r++) {
-                const bool top = r < b;
-                if (top ? k != 0 : k != chunks_per_tile - 1) continue;
-                const uint32_t kk = r % b, py = top ? kk : o + kk;
-                const int y0 = __builtin_amdgcn_readfirstlane(S.apron[r].y0), y1 = __builtin_amdgcn_readfirstlane(S.apron[r].y1);
-                const float fy = S.apron[r].fy, gy = 1.0f - fy;
-                const Texel4 t0 = fetch_row(y0), t1 = fetch_row(y1);
-                uint32_t va = float_to_unorm16((t0.a0 * gxa + t0.a1 * fxa) * gy + (t1.a0 * gxa + t1.a1 * fxa) * fy);
-                uint32_t vb = float_to_unorm16((t0.b0 * gxb + t0.b1 * fxb) * gy + (t1.b0 * gxb + t1.b1 * fxb) * fy);
-                if (kGeneric && min(min(t0.za, t1.za), min(t0.zb, t1.zb)) == 0) {
-                    const uint32_t nrow = top ? t5.n : t5.s;
-                    const uint16_t* h = A.atlas + uint64_t(nrow == kInvalid ? t5.self : nrow) * tile_texels + (b + S.apron[r].pad) * T + b;
-                    if (min(t0.za, t1.za) == 0) va = h[rxa];
-                    if (min(t0.zb, t1.zb) == 0) vb = h[rxb];
-                }
-                if (kDma && min(min(t0.za, t1.za), min(t0.zb, t1.zb)) == 0) {
-                    dirty = 1;
-                    continue;
-                }
-                tile5_u32[(py * T + px0) >> 1] = va | (vb << 16);
-            }
-        }
+        if (!skip_chunk) apron_rows(k, std::integral_constant<bool, kGeneric>{});
 
 #ifdef BT_DEBUG_HOOKS
 #define BT_FUSED_DEBUG_SKELETON_STORES
@@ -867,7 +893,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                     // LDS latency hides behind the packed arithmetic.
                     const uint16_t* base = s_src + uint32_t(__builtin_amdgcn_readfirstlane(row_y0[0]) - cur_ymin) * P;  // consecutive: bit 31 clear
                     const uint16_t *pa0 = base + la0, *pa1 = base + la1, *pb0 = base + lb0, *pb1 = base + lb1;
-                    const float* fyt = row_fy;
+                    const float2* fyt = row_fy;
                     // the texels of a source row as two 16-bit PAIRS (columns a | b at i0, at i1): the pairs convert with SDWA selects
                     // and the no-data test is two packed 16-bit minima per row
                     u16x2 ta = {pa0[0], pb0[0]}, tb = {pa1[0], pb1[0]};
@@ -897,10 +923,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                 if (quad == 0 && i == 3) zmin[1] = zrow;  // source row 4 feeds both quads
                             }
                             const f2 hnew = conv2p(ta) * gx + conv2p(tb) * fx;
-                            // fy of output row r: one LDS read at a workgroup-uniform address, the value stays in a vector register
-                            // (no v_readfirstlane)
-                            const float wy = fyt[r], wg = 1.0f - wy;
-                            const f2 fy2 = {wy, wy}, gy2 = {wg, wg};
+                            // (fy, 1 - fy) of output row r: one 8-byte LDS read at a workgroup-uniform address, the values stay in
+                            // vector registers (no v_readfirstlane, no subtraction: 16 VALU instructions less per chunk)
+                            const float2 wy = fyt[r];
+                            const f2 fy2 = {wy.x, wy.x}, gy2 = {wy.y, wy.y};
                             const f2 w = quantise(hprev * gy2 + hnew * fy2);
                             hprev = hnew;
                             ua[i] = uint32_t(w.x);
@@ -945,6 +971,17 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                 }
                             }
                         }
+                        if (x4_count && !BT_ABLATE(A, 4u)) {  // a few lanes of a tile; one texel each unless the x neighbour is absent
+                            uint16_t* t = A.atlas + x4_off + cy4_first * T;
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; j++)
+                                if (!kDma || zq[j >> 1] != 0) t[j * T] = uint16_t(q[j]);
+                            if (x4_count > 1)
+                                for (uint32_t e = 1; e < x4_count; e++)
+#pragma unroll
+                                    for (uint32_t j = 0; j < 4; j++)
+                                        if (!kDma || zq[j >> 1] != 0) t[j * T + e] = uint16_t(q[j]);
+                        }
                         if (do3) {
                             // the lane pair (2m, 2m+1) owns two level-2 pixels (quads 0 and 1): the even lane finishes
                             // quad 0, the odd lane quad 1.  Sum order ((x0y0 + x0y1) + x1y0) + x1y1: the even lane holds the
@@ -963,6 +1000,12 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             const uint32_t row3 = (b + cy3_first + (even ? 0u : 1u)) * T;
                             const bool clean3 = !kDma || (even ? zp[0] : zp[1]) != 0;
                             if (is_centre && clean3 && !BT_ABLATE(A, 64u)) tile3[row3 + b + cx3] = uint16_t(w3);
+                            if (x3_count && clean3 && !BT_ABLATE(A, 64u)) {
+                                uint16_t* t = A.atlas + x3_off + (cy3_first + (even ? 0u : 1u)) * T;
+                                t[0] = uint16_t(w3);
+                                if (x3_count > 1)
+                                    for (uint32_t e = 1; e < x3_count; e++) t[e] = uint16_t(w3);
+                            }
                         }
                     }
                 } else {
@@ -984,7 +1027,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                     for (uint32_t i = 0; i < 4; i++) {
                         const int yy = __builtin_amdgcn_readfirstlane(row_y0[q + i]);
                         const int y0 = yy & 0x7fffffff, y1 = y0 + (yy < 0 ? 0 : 1);
-                        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row_fy[q + i])));
+                        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row_fy[q + i].x)));
                         f2 top = hcur;
                         uint32_t ztop = zcur;
                         if (y0 != hy) {
@@ -1026,6 +1069,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             dst[0] = uint16_t(q0);
                             dst[T] = uint16_t(q1);
                         }
+                        if (x4_count && (!kDma || zq != 0)) {
+                            xpush4(cy4, uint16_t(q0));
+                            xpush4(cy4 + 1, uint16_t(q1));
+                        }
                         if (do3) {
                             const uint32_t other0 = __shfl_xor(q0, 1), other1 = __shfl_xor(q1, 1);
                             if (is_centre && (tid & 1u) == 0 && (!kDma || zp != 0)) {
@@ -1034,68 +1081,14 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                 const uint32_t w3 = uint32_t(0.5f + (0.25f * (65535.0f / 65536.0f)) * s3);  // scaled domain (conv2)
                                 const uint32_t cy3 = cy3_base + (cy >> 2);
                                 tile3[(b + cy3) * T + b + cx3] = uint16_t(w3);
+                                if (x3_count) xpush3(cy3, uint16_t(w3));
                             }
                         }
                     }
                 }
                 }
             } else {
-                // ---- generic loop: tracks per-pixel validity (no-data texels), keep-previous rule, valid-average
-                Texel4 cur{};
-                int cur_y = -1;
-                for (uint32_t q = 0; q < nrows; q += 4) {
-                    uint32_t va[4], vb[4];
-                    uint32_t zany = 1;
-#pragma unroll
-                    for (uint32_t i = 0; i < 4; i++) {
-                        const int yy = __builtin_amdgcn_readfirstlane(row_y0[q + i]);
-                        const int y0 = yy & 0x7fffffff, y1 = y0 + (yy < 0 ? 0 : 1);
-                        const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row_fy[q + i])));
-                        const Texel4 top = (y0 == cur_y) ? cur : fetch_row(y0);
-                        const Texel4 bot = (y1 == y0) ? top : fetch_row(y1);
-                        cur = bot;
-                        cur_y = y1;
-                        const float gy = 1.0f - fy;
-                        va[i] = float_to_unorm16((top.a0 * gxa + top.a1 * fxa) * gy + (bot.a0 * gxa + bot.a1 * fxa) * fy);
-                        vb[i] = float_to_unorm16((top.b0 * gxb + top.b1 * fxb) * gy + (bot.b0 * gxb + bot.b1 * fxb) * fy);
-                        const uint32_t za = min(top.za, bot.za), zb = min(top.zb, bot.zb);
-                        zany = min(zany, min(za, zb));
-                        // remember the validity in bit 16 (cleared below): 0x10000 = no data in the footprint
-                        va[i] |= za == 0 ? 0x10000u : 0u;
-                        vb[i] |= zb == 0 ? 0x10000u : 0u;
-                    }
-                    if (zany == 0) {  // some footprint had no data: those pixels keep their previous atlas value (split.wgsl:37-42)
-#pragma unroll
-                        for (uint32_t i = 0; i < 4; i++) {
-                            const uint16_t* h = A.atlas + uint64_t(home_col) * tile_texels + (b + cr0 + q + i) * T + b;
-                            if (va[i] & 0x10000u) va[i] = h[rxa];
-                            if (vb[i] & 0x10000u) vb[i] = h[rxb];
-                        }
-                    }
-                    const uint32_t py = b + cr0 + q;
-                    if (!is_idle) {
-#pragma unroll
-                        for (uint32_t i = 0; i < 4; i++) tile5_u32[((py + i) * T + px0) >> 1] = (va[i] & 0xFFFFu) | (vb[i] << 16);
-                    }
-                    if (do4) {
-                        const uint32_t cy = cr0 + q;  // multiple of 4
-                        const uint32_t q0 = downsample4(va[0] & 0xFFFFu, va[1] & 0xFFFFu, vb[0] & 0xFFFFu, vb[1] & 0xFFFFu);  // OFFSETS order
-                        const uint32_t q1 = downsample4(va[2] & 0xFFFFu, va[3] & 0xFFFFu, vb[2] & 0xFFFFu, vb[3] & 0xFFFFu);
-                        const uint32_t cy4 = cy4_base + (cy >> 1);
-                        if (is_centre) {
-                            uint16_t* dst = tile4 + (b + cy4) * T + b + cx4;
-                            dst[0] = uint16_t(q0);
-                            dst[T] = uint16_t(q1);
-                        }
-                        if (do3) {
-                            const uint32_t other0 = __shfl_xor(q0, 1), other1 = __shfl_xor(q1, 1);
-                            if (is_centre && (tid & 1u) == 0) {
-                                const uint32_t w = downsample4(q0, q1, other0, other1);
-                                tile3[(b + cy3_base + (cy >> 2)) * T + b + cx3] = uint16_t(w);
-                            }
-                        }
-                    }
-                }
+                generic_rows(k);
             }
         }
 
@@ -1107,7 +1100,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         // previous barrier), the row table of chunk k + 3 replaces the one of chunk k after the barrier
         nodata = !kStaged;
         if (kStaged && !kDma && !BT_ABLATE(A, 8u)) {
-            uint16_t* s_next = chunk_buf(k + 1);
+            uint16_t* s_next = s_buf + ((k + 1) & 1u) * buf_texels;
             nodata = wide ? stage_commit(s_next, next_slots, pre) : stage_narrow(s_next, next_ymin, next_slots);
         }
         ymin = next_ymin;
@@ -1115,9 +1108,36 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         has_nodata = any_nodata(nodata, (k + 1) & 1u);
     }
     if constexpr (kDma) {  // the last chunk's flag
-        if constexpr (kMode == 2 || kMode == 3) lds_barrier();
-        else __syncthreads();
-        if (tid == 0 && k_end > k_begin && S.nodata[(k_end - 1u) & 1u][0]) A.todo[2 + atomicAdd(&A.todo[0], 1u)] = item_index * chunks_per_tile + (k_end - 1u);
+        __syncthreads();
+        if (tid == 0 && k_end > k_begin && S.nodata[(k_end - 1u) & 1u][0]) flag_chunk(k_end - 1u);
+    }
+    if constexpr (kStaged && !kGeneric) {
+        // ---- redo of the flagged chunks with the generic rows: stage the window once more (nobody reads LDS any more), run the
+        // apron rows and the rows with validity.  Clean inputs pay one barrier and one LDS read per tile.
+        __syncthreads();
+        const uint32_t redo0 = uint32_t(__builtin_amdgcn_readfirstlane(int(S.redo[0]))), redo1 = uint32_t(__builtin_amdgcn_readfirstlane(int(S.redo[1])));
+        if (redo0 | redo1) {
+#pragma unroll 1
+            for (uint32_t k = k_begin; k < k_end; k++) {
+                if (!(((k - k_begin) < 32u ? redo0 >> (k - k_begin) : redo1 >> (k - k_begin - 32u)) & 1u)) continue;
+                window(k, ymin, slots);
+                if constexpr (kDma) {
+                    dma_issue(s_buf, ymin, slots);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else if (wide) {
+                    stage_issue(ymin, slots, pre);
+                    stage_commit(s_buf, slots, pre);
+                } else {
+                    stage_narrow(s_buf, ymin, slots);
+                }
+                __syncthreads();
+                s_src = s_buf;
+                cur_ymin = ymin;
+                apron_rows(k, std::true_type{});
+                generic_rows(k);
+                __syncthreads();  // the next flagged chunk overwrites the staged rows
+            }
+        }
     }
 #ifdef BT_DEBUG_HOOKS
     if (BT_ABLATE(A, 134217728u) && tid == 0)
@@ -1126,8 +1146,8 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
 }
 
 // fast / non-staged variants: workgroup = (tile, part of its chunks), XCD-contiguous order
-template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP, bool kDma = false, uint32_t kMode = 0>
-__global__ __launch_bounds__(kMode == 2 || kMode == 3 ? 320 : 256) __attribute__((amdgpu_waves_per_eu(kMode == 3 ? 6 : (kMode == 2 ? 5 : (kMode == 4 ? 3 : 4)), kMode == 3 ? 6 : (kMode == 2 ? 5 : (kMode == 4 ? 3 : 4))))) void fused_main_kernel(FusedArgs A) {
+template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP, bool kDma = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_main_kernel(FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t work = BT_ABLATE(A, 1024u) ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);  // (1024: dispatch order, no XCD remap)
     const uint32_t chunks_per_tile = (A.m.center_size + kMainRows - 1) / kMainRows;
@@ -1139,46 +1159,10 @@ __global__ __launch_bounds__(kMode == 2 || kMode == 3 ? 320 : 256) __attribute__
 #include "bt_fused_debug.inc"  // (static wave priority by dispatch rank: timing experiment)
 #undef BT_FUSED_DEBUG_ENTRY_PRIORITY
 #endif
-    fused_main_chunks<kStaged, kGeneric, kT, kP, kDma, kMode>(A, work / A.groups, k_begin, k_end, smem);
-}
-
-// the b x b apron corners of the finest tiles: governed by the diagonal neighbour alone (stitch.wgsl:57-66,
-// 105-118) — its centre corner if it exists, else the own centre corner — evaluated with the general formula
-__device__ __forceinline__ void corner_pixels(const FusedArgs& A, uint32_t item_index, uint32_t tid, uint32_t threads) {
-    const MainItem it = A.items[item_index];
-    const RasterDev raster = A.rasters[it.raster];
-    const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
-    const uint32_t self = grid_lookup(A, it.side, A.lod, int(it.x), int(it.y));
-    for (uint32_t t = tid; t < 4 * b * b; t += threads) {
-        const uint32_t corner = t / (b * b), i = (t % (b * b)) % b, j = (t % (b * b)) / b;
-        const bool left = corner == 0 || corner == 3, top = corner < 2;  // 0 NW, 1 NE, 2 SE, 3 SW
-        const uint32_t px = left ? i : o + i, py = top ? j : o + j;
-        const uint32_t n = grid_lookup(A, it.side, A.lod, int(it.x) + (left ? -1 : 1), int(it.y) + (top ? -1 : 1));
-        uint32_t v;
-        if (n != kInvalid)
-            v = split_value_slow(A, raster, left ? it.x - 1 : it.x + 1, left ? c - b + i : i, top ? it.y - 1 : it.y + 1, top ? c - b + j : j, n);
-        else
-            v = split_value_slow(A, raster, it.x, left ? 0u : c - 1, it.y, top ? 0u : c - 1, self);
-        A.atlas[uint64_t(self) * T * T + py * T + px] = uint16_t(v);
-    }
+    fused_main_chunks<kStaged, kGeneric, kT, kP, kDma>(A, work / A.groups, k_begin, k_end, smem);
 }
 
 __global__ __launch_bounds__(64) void fused_corner_kernel(FusedArgs A) { corner_pixels(A, blockIdx.x, threadIdx.x, blockDim.x); }
-
-// generic variant over the chunks the fast variant left in A.todo; also clears the list the next run appends to
-__global__ __launch_bounds__(256, 2) void fused_todo_kernel(FusedArgs A) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t chunks_per_tile = (A.m.center_size + kMainRows - 1) / kMainRows;
-    const uint32_t count = A.todo[0];
-    if (threadIdx.x < 64)  // the apron corners ride along: same stream position, no launch of their own
-        for (uint32_t i = blockIdx.x; i < A.item_count; i += gridDim.x) corner_pixels(A, i, threadIdx.x, 64);
-    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
-        const uint32_t entry = A.todo[2 + e];
-        fused_main_chunks<true, true, 0, 0>(A, entry / chunks_per_tile, entry % chunks_per_tile, entry % chunks_per_tile + 1, smem);
-        __syncthreads();  // LDS is reused by the next entry
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) A.todo_next[0] = 0;
-}
 
 // ---- fused_tail: up to three LODs below `A.lod`, read from the atlas ---------------------------------
 // Workgroup = 64 x 64 pixels of the LOD-`lod` mosaic, 16 x 16 threads, 4 x 4 input pixels per thread: a thread
@@ -1188,12 +1172,9 @@ __global__ __launch_bounds__(256, 2) void fused_todo_kernel(FusedArgs A) {
 // Top / bottom apron rows (whole rows, corners included) of the tiles of the LODs fused_main produced below the
 // finest one: stitch.wgsl:53-118 for same-side neighbours — neighbour's centre rows, or the own centre clamped
 // when it is absent.  (Cube face edges are re-stitched afterwards by the generic kernel.)  One thread per pixel pair.
-__device__ __forceinline__ uint32_t tail_apron_pairs_per_tile(const FusedArgs& A) {  // R16: texel pairs (b is even)
-    return A.m.border_size * A.m.texture_size + (A.apron_cols ? A.m.border_size * A.m.center_size : 0u);
-}
 __device__ __forceinline__ void tail_apron_rows(const FusedArgs& A, uint32_t side, uint32_t e) {
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
-    const uint32_t row_pairs = b * T, pairs = tail_apron_pairs_per_tile(A), blocks_per_tile = (pairs + 255u) / 256u;
+    const uint32_t pairs = b * T, blocks_per_tile = (pairs + 255u) / 256u;
     for (uint32_t k = 0; k < A.apron_lods; k++) {
         const uint32_t lod = A.lod + k, n = 1u << lod, blocks = n * n * blocks_per_tile;
         if (e >= blocks) {
@@ -1205,17 +1186,8 @@ __device__ __forceinline__ void tail_apron_rows(const FusedArgs& A, uint32_t sid
         const uint32_t tx = tile / n, ty = tile % n;
         const uint32_t self = grid_lookup(A, side, lod, int(tx), int(ty));
         if (self == kInvalid) return;
-        uint32_t px, py;
-        if (i < row_pairs) {  // whole apron rows (with the corners)
-            const uint32_t r = i / (T / 2u);
-            px = 2u * (i % (T / 2u));
-            py = r < b ? r : c + r;
-        } else {  // (A.apron_cols) the left / right apron columns of the centre rows: b / 2 pairs per side and row
-            const uint32_t j = i - row_pairs, kk = j % b;
-            px = kk < b / 2u ? 2u * kk : o + 2u * (kk - b / 2u);
-            py = b + j / b;
-        }
-        const int rx = px < b ? -1 : (px >= o ? 1 : 0), ry = py < b ? -1 : (py >= o ? 1 : 0);
+        const uint32_t r = i / (T / 2u), px = 2u * (i % (T / 2u)), py = r < b ? r : c + r;
+        const int rx = px < b ? -1 : (px >= o ? 1 : 0), ry = r < b ? -1 : 1;
         const uint32_t nb = grid_lookup(A, side, lod, int(tx) + rx, int(ty) + ry);
         uint32_t v[2];
 #pragma unroll
@@ -1775,11 +1747,8 @@ __global__ void selftest_kernel(uint32_t* failures) {
 struct FusedJobDev {  // one fused launch of a compiled queue
     FusedArgs args;
     uint32_t attachment;
-    uint32_t main_runs = 0;  // parity selects the todo list
     uint32_t lds_pad = 0;    // profiling build only (BT_FUSED_LDS_PAD at plan time): extra dynamic LDS per workgroup
     bool dma = false;        // fused_main stages through LDS-DMA (every raster of the job 16-byte aligned in base and pitch)
-    uint32_t mode = 2;       // kMode of the LDS-DMA variant (profiling build: BT_FUSED_MODE)
-    uint32_t arena_rows = 0; // fused_main: staged source rows the workgroup's LDS holds (loader-wave variant: see the planning)
     std::vector<MainItem> host_items;  // fused_main's items as uploaded (tile-row order): streamed runs cut them into bands
     float tly = 0.0f, bry = 1.0f;
 };
@@ -1787,7 +1756,7 @@ struct FusedJobDev {  // one fused launch of a compiled queue
 // the fused path's per-queue state, owned by the bt_preprocessor that compiled it (bt_preprocessor::fused)
 struct FusedState {
     std::vector<FusedJobDev> jobs;
-    std::vector<void*> allocs;  // device buffers of the jobs (grids, item lists, todo lists)
+    std::vector<void*> allocs;  // device buffers of the jobs (grids, item lists)
 };
 
 }  // namespace bt
@@ -1995,7 +1964,6 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         args.m = m;
 #ifdef BT_DEBUG_HOOKS
         if (const char* e = getenv("BT_FUSED_ABLATE")) args.ablate = uint32_t(atoi(e));
-        if (const char* e = getenv("BT_FUSED_EXTRA_VALU")) args.extra_valu = uint32_t(atoi(e));
 #endif
         args.atlas = (uint16_t*)at.level0;
         args.rasters = p->rasters_dev;  // (re)allocated by bt_preprocessor_run before the first launch
@@ -2004,19 +1972,11 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         args.brx = splits[0]->br[0];
         args.bry = splits[0]->br[1];
         args.sides = sides;
-        {
-            const uint32_t chunks = (m.center_size + kMainRows - 1) / kMainRows;
-            const size_t list = 2 + splits.size() * size_t(chunks);  // two lists, used by alternate runs
-            std::vector<uint32_t> todo(2 * list, 0u);
-            const uint32_t* dev = nullptr;
-            if (upload_vector(p, todo, &dev)) return false;
-            args.todo = const_cast<uint32_t*>(dev);
-            args.todo_next = args.todo + list;
-        }
         args.grid_lod_lo = lod_lo;
         args.grid_lod_hi = lod_hi;
         args.grid_sides = sides;
-        if (upload_vector(p, grids, &args.grids)) return false;  // (the items follow below: their ring_row comes out of the LDS planning)
+        if (upload_vector(p, items, &args.items) || upload_vector(p, grids, &args.grids))
+            return false;
 
         const uint64_t bpp = m.pixel_size, Tt = m.texture_size, cc = m.center_size;
         uint64_t source_bytes = 0;
@@ -2081,7 +2041,6 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             job.args.lod = lod_hi;
             job.args.levels = main_levels;
             job.args.item_count = uint32_t(items.size());
-            if (upload_vector(p, items, &job.args.items)) return false;
             {   // row blocks per workgroup: as many as keep at least one resident generation (1024 workgroups) busy
                 const uint64_t blocks = uint64_t(items.size()) * ((m.center_size + kDirectRows - 1) / kDirectRows);
                 job.args.groups = uint32_t(std::min<uint64_t>(kDirectMaxBlocks, std::max<uint64_t>(1, blocks / 1024)));
@@ -2139,17 +2098,15 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             const uint32_t rows = std::min(kMainRows, m.center_size) + 2 * m.border_size;
             const uint64_t cols_needed = uint64_t(double(m.texture_size - 1) * ratio_x) + 4 + 7;
             uint64_t rows_needed = uint64_t(double(rows - 1) * ratio_y) + 4;  // contiguous source-row range (safe bound)
-            std::vector<std::pair<uint32_t, int>> seen;       // (tile row, raster): the tiles of one share their chunks' source windows
-            std::vector<std::vector<uint32_t>> window_rows;  // per entry of `seen`: source rows of every chunk's window
             {   // exact: replay the kernel's own window computation for every tile row and chunk (same f32 operations)
                 const uint32_t c = m.center_size, b = m.border_size, chunks = (c + kMainRows - 1) / kMainRows;
                 const float scale = float(1u << lod_hi);
                 uint64_t exact = 1;
+                std::vector<std::pair<uint32_t, int>> seen;  // (tile row, raster)
                 for (const Task* t : splits) {
                     const std::pair<uint32_t, int> key(t->coord.y, t->raster);
                     if (std::find(seen.begin(), seen.end(), key) != seen.end()) continue;
                     seen.push_back(key);
-                    window_rows.emplace_back(chunks, 0u);
                     const uint32_t H = p->rasters[t->raster].dev.height, n = 1u << lod_hi, ty = t->coord.y;
                     auto axis = [&](uint32_t tile, uint32_t r) { return split_axis(r, c, tile, scale, args.tly, args.bry, H); };
                     for (uint32_t k = 0; k < chunks; k++) {
@@ -2158,7 +2115,6 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                         if (k == 0) lo = std::min(lo, ty > 0 ? axis(ty - 1, c - b).i0 : axis(ty, 0).i0);
                         if (k == chunks - 1) hi = std::max(hi, ty + 1 < n ? axis(ty + 1, b - 1).i1 : axis(ty, c - 1).i1);
                         exact = std::max<uint64_t>(exact, uint64_t(hi - lo + 1));
-                        window_rows.back()[k] = uint32_t(hi - lo + 1);  // (an upper bound of the kernel's window: a missing north / south tile only shrinks it)
                     }
                 }
                 rows_needed = std::min(rows_needed, exact);
@@ -2183,65 +2139,8 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             }
 #ifdef BT_DEBUG_HOOKS
             if (const char* e = getenv("BT_FUSED_DMA")) main_job.dma = main_job.dma && atoi(e) != 0;
-            if (const char* e = getenv("BT_FUSED_MODE")) main_job.mode = uint32_t(atoi(e));
 #endif
-            // Loader-wave variant: the LDS arena and the staging schedule.  The arena is as many rows as let four workgroups share
-            // a CU's 160 KiB (never fewer than two maximal windows); a chunk's window goes behind the previous one, or to row 0
-            // when it does not fit there, and is requested as early as that leaves the windows of the chunk being shaded and of
-            // the chunks requested before it intact — at most two chunks ahead.  Simulated here per tile row and part, so that the
-            // kernel only reads the result; a row whose windows cannot be scheduled falls back to the alternating halves.
-            main_job.arena_rows = 2 * main_job.args.lds_rows;
-            if (main_job.dma && (main_job.mode == 2 || main_job.mode == 3) && main_job.args.lds_rows) {
-                const uint32_t chunks = (m.center_size + kMainRows - 1) / kMainRows, groups = main_job.args.groups;
-                const uint32_t per_cu_rows = uint32_t((40960 - sizeof(MainShared)) / (pitch * 2));
-                uint32_t depth = 3;
-#ifdef BT_DEBUG_HOOKS
-                if (const char* e = getenv("BT_FUSED_RING_DEPTH")) depth = uint32_t(std::max(2, atoi(e)));
-#endif
-                const uint32_t R = std::max<uint32_t>(depth > 2 ? per_cu_rows : 0u, 2 * main_job.args.lds_rows), M = main_job.args.lds_rows;
-                main_job.arena_rows = R;
-                std::vector<uint32_t> ring(seen.size() * size_t(chunks), 0u);
-                for (size_t row = 0; row < seen.size(); row++) {
-                    const std::vector<uint32_t>& rows_of = window_rows[row];
-                    uint32_t* out = ring.data() + row * chunks;
-                    for (uint32_t part = 0; part < groups; part++) {
-                        const uint32_t k0 = part * chunks / groups, k1 = (part + 1) * chunks / groups;
-                        bool ok = depth > 2;
-                        std::vector<uint32_t> pos(chunks, 0u);
-                        uint32_t q = k0;
-                        for (uint32_t t = k0; t < k1 && ok; t++) {  // start of chunk t: the windows of the chunks before it are free
-                            while (q < k1 && q <= t + (depth - 1)) {
-                                const uint32_t sz = rows_of[q];
-                                const uint32_t behind = q > k0 ? pos[q - 1] + rows_of[q - 1] : 0u;
-                                bool placed = false;
-                                for (uint32_t cand : {behind, 0u}) {
-                                    if (cand + sz > R) continue;
-                                    bool clash = false;
-                                    for (uint32_t j = t; j < q; j++) clash = clash || (cand < pos[j] + rows_of[j] && pos[j] < cand + sz);
-                                    if (clash) continue;
-                                    pos[q] = cand;
-                                    placed = true;
-                                    break;
-                                }
-                                if (!placed) break;
-                                out[q] = pos[q] | (t << 16);
-                                q++;
-                            }
-                            ok = q > t + 1 || q == k1;  // chunk t + 1 must be on its way when chunk t starts
-                        }
-                        if (!ok)  // alternating halves, one chunk ahead (what the four-wave variants do)
-                            for (uint32_t k = k0; k < k1; k++) out[k] = ((k - k0) & 1u) * M | (std::max(k0 + 1, k) - 1) << 16;
-                    }
-                }
-                if (upload_vector(p, ring, &main_job.args.ring)) return false;
-                for (MainItem& it : items) {
-                    const auto f = std::find(seen.begin(), seen.end(), std::pair<uint32_t, int>(it.y, int(it.raster)));
-                    it.ring_row = uint32_t(f - seen.begin());
-                }
-            }
         }
-        if (upload_vector(p, items, &main_job.args.items)) return false;
-        main_job.host_items = items;
         Launch lm{};
         lm.kind = kLaunchFusedMain;
         lm.kernels = main_job.args.lds_rows ? 1u : 2u;  // (without the LDS window: fused_corner + fused_main in one entry)
@@ -2252,20 +2151,15 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         for (uint32_t k = 0; k < main_levels; k++) lm.algorithmic_bytes += tiles_at(lod_hi - k) * Tt * Tt * bpp;
         jobs.push_back(main_job);
         plan.push_back(lm);
-        if (main_job.args.lds_rows) {  // fused_todo: the chunks the fast variant re-queued + the apron corners; an entry of its own, so that
-            Launch lq = lm;            // a profiled run times fused_main alone
-            lq.kind = kLaunchFusedTodo;
-            lq.algorithmic_bytes = uint64_t(items.size()) * 4 * m.border_size * m.border_size * bpp;  // (the corners; re-queued chunks are data dependent)
-            plan.push_back(lq);
-        }
         }
 
         const bool tail_follows = lod_hi - (main_levels - 1) > lod_lo;
         // (after fused_direct, which writes centres only, the tail's extra workgroups do all four sides: no stitch launch)
         const bool rows_in_tail = !shard && tail_follows && main_levels > 1 && (direct || m.border_size % 2u == 0);
         if (main_levels > 1 && !rows_in_tail) {
-            // fused_main writes the centres of the parent / grand-parent tiles; all four apron sides come from the batched
-            // stitch kernel (sharded: after the all-gather, from the then complete centres)
+            // fused_main writes the centres and the left / right apron columns of the parent / grand-parent tiles; their
+            // top / bottom apron rows (whole 1 KB rows) come from the batched stitch kernel — sharded: everything, after
+            // the all-gather, from the then complete centres
             const uint32_t first = uint32_t(tasks.size());
             for (const Task* t : stitches) {
                 if (t->coord.lod == lod_hi || t->coord.lod + main_levels <= lod_hi) continue;
@@ -2288,7 +2182,10 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             ls.task_count = uint32_t(tasks.size()) - first;
             ls.algorithmic_bytes = uint64_t(ls.task_count) * 2 * (2 * m.border_size * (Tt + cc)) * bpp;
             ls.phase = shard ? 2u : 0u;
-            ls.aux0 = 0u;  // all four sides (fused_main and fused_direct write centres only)
+            // fused_main also writes the left / right apron columns of these tiles (from registers); sharded runs lose
+            // the ones that crossed a strip boundary in the all-gather and re-stitch everything
+            ls.aux0 = (shard || direct) ? 0u : 1u;  // (fused_direct writes centres only: all four sides)
+            if (!shard && !direct) ls.algorithmic_bytes = uint64_t(ls.task_count) * 2 * (2 * m.border_size * Tt) * bpp;
             if (ls.task_count) plan.push_back(ls);
         }
 
@@ -2302,9 +2199,9 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             tail.args.levels = levels;
             // the first tail launch also fills the top / bottom apron rows of the LODs fused_main produced (see above)
             tail.args.apron_lods = (rows_in_tail && in_lod == lod_hi - (main_levels - 1)) ? main_levels - 1 : 0u;
-            tail.args.apron_cols = 1u;  // (neither fused_main nor fused_direct writes the apron columns of its parent LODs)
+            tail.args.apron_cols = direct ? 1u : 0u;
             if (tail.args.apron_lods)
-                for (uint32_t k = 0; k < tail.args.apron_lods; k++) lt_extra += tiles_at(in_lod + k) * 2 * (2 * m.border_size * (Tt + cc)) * bpp;
+                for (uint32_t k = 0; k < tail.args.apron_lods; k++) lt_extra += tiles_at(in_lod + k) * 2 * (2 * m.border_size * (Tt + (direct ? cc : 0))) * bpp;
             Launch lt{};
             lt.kind = kLaunchFusedTail;
             lt.attachment = ai;
@@ -2413,12 +2310,8 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
     }
     std::vector<FusedJobDev>& jobs = p->fused->jobs;
     FusedJobDev job = jobs[l.aux0];
-    // the two todo lists alternate per main launch (fused_todo zeroes the one the NEXT main launch appends to); the todo entry
-    // that follows a main launch sees the same pair
-    if (l.kind == kLaunchFusedMain && (jobs[l.aux0].main_runs++ & 1u)) std::swap(job.args.todo, job.args.todo_next);
-    if (l.kind == kLaunchFusedTodo && ((jobs[l.aux0].main_runs - 1u) & 1u)) std::swap(job.args.todo, job.args.todo_next);
     job.args.rasters = p->rasters_dev;
-    if ((l.kind == kLaunchFusedMain || l.kind == kLaunchFusedTodo) && item_begin < job.args.item_count) {  // a band of the item list (streamed runs); default: all
+    if (l.kind == kLaunchFusedMain && item_begin < job.args.item_count) {  // a band of the item list (streamed runs); default: all
         job.args.items += item_begin;
         job.args.item_count = std::min(item_count, job.args.item_count - item_begin);
     }
@@ -2429,17 +2322,9 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
     } else if (l.kind == kLaunchFusedMain) {
         const uint32_t blocks = job.args.item_count * job.args.groups;
         if (job.args.lds_rows) {
-            size_t lds = sizeof(MainShared) + size_t(job.arena_rows) * job.args.lds_pitch * 2;
+            size_t lds = sizeof(MainShared) + 2 * size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
             lds = std::min<size_t>(65536, lds + job.lds_pad);  // (occupancy experiments)
-            if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528 && job.dma && job.mode == 3)
-                fused_main_kernel<true, false, 512, 528, true, 3><<<blocks, 320, lds, p->ctx->stream>>>(job.args);
-            else if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528 && job.dma && job.mode == 2)
-                fused_main_kernel<true, false, 512, 528, true, 2><<<blocks, 320, lds, p->ctx->stream>>>(job.args);
-            else if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528 && job.dma && job.mode == 4)
-                fused_main_kernel<true, false, 512, 528, true, 4><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
-            else if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528 && job.dma && job.mode == 1)
-                fused_main_kernel<true, false, 512, 528, true, 1><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
-            else if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528 && job.dma)
+            if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528 && job.dma)
                 fused_main_kernel<true, false, 512, 528, true><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
             else if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528)
                 fused_main_kernel<true, false, 512, 528><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
@@ -2449,17 +2334,12 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
             fused_corner_kernel<<<job.args.item_count, 64, 0, p->ctx->stream>>>(job.args);
             fused_main_kernel<false, true, 0, 0><<<blocks, 256, sizeof(MainShared), p->ctx->stream>>>(job.args);
         }
-    } else if (l.kind == kLaunchFusedTodo) {
-        const uint32_t blocks = job.args.item_count * job.args.groups;
-        size_t lds = sizeof(MainShared) + 2 * size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
-        lds = std::min<size_t>(65536, lds + job.lds_pad);
-        fused_todo_kernel<<<std::min(blocks, 1024u), 256, lds, p->ctx->stream>>>(job.args);
     } else {
         const uint32_t size = (1u << job.args.lod) * job.args.m.center_size;
         dim3 grid((size + 63) / 64, (size + 63) / 64, job.args.sides);
         if (job.args.apron_lods) {
             const uint32_t blocks_per_tile = job.args.m.format == BT_FORMAT_R16
-                ? (job.args.m.border_size * (job.args.m.texture_size + (job.args.apron_cols ? job.args.m.center_size : 0u)) + 255u) / 256u  // texel pairs of the 2b apron rows (and columns)
+                ? (job.args.m.border_size * job.args.m.texture_size + 255u) / 256u  // texel pairs of the 2b apron rows
                 : (2u * job.args.m.border_size * (job.args.m.texture_size + (job.args.apron_cols ? job.args.m.center_size : 0u)) + 255u) / 256u;
             uint64_t extra = 0;
             for (uint32_t k = 0; k < job.args.apron_lods; k++) extra += (1ull << (2 * (job.args.lod + k))) * blocks_per_tile;

@@ -1463,7 +1463,6 @@ bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* a, const ch
     }
     if (bt_status s = ctx_side_streams(p->ctx)) return s;
     const Launch main = p->plan[0];
-    const bool has_todo = p->plan.size() > 1 && p->plan[1].kind == kLaunchFusedTodo;  // every band's fused_main is followed by its fused_todo
     const uint32_t ai = main.attachment;
     Raster& r = p->rasters[size_t(raster)];
     const size_t nb = bands.size();
@@ -1554,13 +1553,12 @@ bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* a, const ch
         if (rc == BT_OK && hipEventRecord(uploaded[k], p->ctx->copy_stream) != hipSuccess) rc = BT_ERR_DEVICE;
         if (rc == BT_OK && hipStreamWaitEvent(p->ctx->stream, uploaded[k], 0) != hipSuccess) rc = BT_ERR_DEVICE;
         if (rc == BT_OK) rc = fused_launch_range(p, a, main, bands[k].item_begin, bands[k].item_count);
-        if (rc == BT_OK && has_todo) rc = fused_launch_range(p, a, p->plan[1], bands[k].item_begin, bands[k].item_count);
         if (rc == BT_OK && hipEventRecord(computed[k], p->ctx->stream) != hipSuccess) rc = BT_ERR_DEVICE;
         if (rc == BT_OK) publish(k + 1);
     }
     // the raster counts as uploaded only when every band went out; after a failure a later run of the kept queue uploads it whole
     if (rc == BT_OK) r.pending = false;
-    for (size_t i = has_todo ? 2 : 1; i < p->plan.size() && rc == BT_OK; i++) rc = run_plan_entry(p, a, p->plan[i]);
+    for (size_t i = 1; i < p->plan.size() && rc == BT_OK; i++) rc = run_plan_entry(p, a, p->plan[i]);
     if (rc == BT_OK && hipEventRecord(computed[nb], p->ctx->stream) != hipSuccess) rc = BT_ERR_DEVICE;
     if (rc == BT_OK) publish(nb + 1);
     else {

@@ -173,7 +173,7 @@ struct Launch {
     uint32_t aux0 = 0, aux1 = 0;
     uint64_t algorithmic_bytes = 0;  // inputs read once + outputs written once
     uint32_t phase = 0;              // sharded runs: 0 = BT_RUN_SHARD_LOCAL part, 2 = BT_RUN_SHARD_FINISH part
-    uint32_t kernels = 1;            // kernels this plan entry launches (fused main: itself + fused_todo / fused_corner)
+    uint32_t kernels = 1;            // kernels this plan entry launches (fused main without an LDS window: fused_corner + itself)
 };
 
 // host-side launchers implemented in bt_kernels.hip
