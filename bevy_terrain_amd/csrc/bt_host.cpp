@@ -1118,6 +1118,7 @@ void bt_preprocessor_destroy(bt_preprocessor* p) {
     release_rasters(p);
     fused_release(p);
     for (hipEvent_t e : p->events) hipEventDestroy(e);
+    for (hipEvent_t e : p->event_pool) hipEventDestroy(e);
     if (p->tasks_dev) hipFree(p->tasks_dev);
     if (p->rasters_dev) hipFree(p->rasters_dev);
     delete p;

@@ -236,6 +236,7 @@ struct bt_preprocessor {
     bt::FusedState* fused = nullptr;  // owned; freed by fused_release
     // BT_RUN_PROFILE: events[run * (plan.size() + 1) + i]; event 0 of a run precedes its first launch
     std::vector<hipEvent_t> events;
+    std::vector<hipEvent_t> event_pool;  // events read by bt_preprocessor_profile, kept for the next profiled runs (no hipEventCreate inside a timed step)
     uint32_t profiled_runs = 0;
 };
 

@@ -149,7 +149,7 @@ bt_status ensure_compiled(bt_preprocessor* p, bt_atlas* a, uint32_t mode) {
         p->stats = st;
         p->compiled = true;
         p->compiled_flags = mode;
-        for (hipEvent_t e : p->events) hipEventDestroy(e);
+        p->event_pool.insert(p->event_pool.end(), p->events.begin(), p->events.end());
         p->events.clear();
         p->profiled_runs = 0;
     }
@@ -189,7 +189,12 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
     const bool profile = (flags & BT_RUN_PROFILE) != 0;
     auto record = [&](void) -> bt_status {
         hipEvent_t e;
-        BT_HIP(hipEventCreate(&e));
+        if (!p->event_pool.empty()) {  // (profiled steps sit inside the bench's timed region: the events are created once and recycled)
+            e = p->event_pool.back();
+            p->event_pool.pop_back();
+        } else {
+            BT_HIP(hipEventCreate(&e));
+        }
         p->events.push_back(e);
         BT_HIP(hipEventRecord(e, p->ctx->stream));
         return BT_OK;
@@ -277,7 +282,7 @@ extern "C" bt_status bt_preprocessor_profile(bt_preprocessor* p, bt_launch_profi
         out[i].samples = p->profiled_runs;
         out[i].avg_ms = p->profiled_runs ? float(total / p->profiled_runs) : 0.0f;
     }
-    for (hipEvent_t e : p->events) hipEventDestroy(e);
+    p->event_pool.insert(p->event_pool.end(), p->events.begin(), p->events.end());
     p->events.clear();
     p->profiled_runs = 0;
     return BT_OK;

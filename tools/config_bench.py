@@ -28,9 +28,35 @@ def time_job(device, pre, atlas, steps=50):
     return s.elapsed_time(e) / steps, pre.profile(), pre.stats()
 
 
+def masked_16k(device):
+    """The 16k job with the 5 % no-data mask of tests/test_gpu_preprocess.py (seed 43: 37 x 53 texel cells + single texels): about
+    half of all 8-row chunks hold a no-data texel and are redone by the generic rows."""
+    size, lods = 16384, 6
+    ptr = device.synth_fbm_r16(size, size, 42)
+    src = device.download(ptr, (size, size), np.uint16)
+    rng = np.random.default_rng(43)
+    cells = rng.random((size // 37 + 1, size // 53 + 1)) < 0.05
+    mask = np.repeat(np.repeat(cells, 37, axis=0), 53, axis=1)[:size, :size]
+    single = rng.integers(0, size, size=(size, 2))
+    mask[single[:, 0], single[:, 1]] = True
+    src[mask] = 0
+    device.free(ptr)
+    ptr = device.upload(src)
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=2048, path="terrains/masked16k", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=512, border_size=2, format=bt.AttachmentFormat.R16))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer().insert("m", (ptr, size, size))
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="m", lod_range=range(0, lods)), server, atlas)
+    ms, prof, st = time_job(device, pre, atlas, steps=20)
+    return {"ms": ms, "tiles": st["tiles"], "launches": [(l["kind"], round(l["avg_ms"] * 1e3, 1)) for l in prof]}
+
+
 def main():
     device = bt.Device(0)
     out = {}
+    if "--masked16k" in sys.argv:
+        print(json.dumps({"config3_masked_16k": masked_16k(device)}))
+        return
     # config 2
     h = device.synth_fbm_r16(4096, 4096, 1234)
     rng = np.random.default_rng(1235)
