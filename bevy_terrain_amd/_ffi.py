@@ -118,6 +118,13 @@ class IndirectC(C.Structure):
                 ("base_instance", C.c_uint32)]
 
 
+class FrameInfoC(C.Structure):
+    _fields_ = [("released_count", C.c_uint32), ("requested_count", C.c_uint32), ("apply_status", C.c_int32), ("approximate_height", C.c_float)]
+
+
+FRAME_PREPASS_UNORDERED, FRAME_PREPASS_PLAIN, FRAME_KEEP_REQUESTS, FRAME_KEEP_HEIGHT = 1, 2, 4, 8
+
+
 class TileTreeEntryC(C.Structure):
     _fields_ = [("atlas_index", C.c_uint32), ("atlas_lod", C.c_uint32)]
 
@@ -223,6 +230,7 @@ PROTOTYPES = {
     "bt_tile_tree_sample_attachment": (_i32, [_vp, _vp, _u32, _P(C.c_double), _u32, _P(C.c_float), _P(C.c_float)]),
     "bt_tile_tree_approximate_height": (_i32, [_vp, _vp, _P(C.c_float)]),
     "bt_tile_tree_view_state": (_i32, [_vp, _P(ViewStateC)]),
+    "bt_frame_update": (_i32, [_vp, _vp, _vp, _P(C.c_double), C.c_uint32, _P(FrameInfoC)]),
     "bt_selftest": (_i32, [_vp, _P(_u32)]),
     "bt_synth_fbm_r16": (_i32, [_vp, _vp, _u32, _u32, _u64, _u32, _u32, _u32, _u32, _u32]),
     "bt_preprocessor_run_streamed": (_i32, [_vp, _vp, C.c_char_p, _u32, _vp]),

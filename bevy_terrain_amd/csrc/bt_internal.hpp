@@ -258,3 +258,9 @@ inline uint32_t shard_holder(const ::bt_preprocessor* p, uint32_t attachment, ui
     return atlas_index % p->shard_world;
 }
 }  // namespace bt
+
+namespace bt {
+// the three forms of the tiling prepass with the view's approximate_height optionally taken from device memory (bt_frame_update);
+// form: 0 = bt_tiling_prepass_run, 1 = _run_unordered, 2 = _run_plain
+bt_status tiling_prepass_enqueue(bt_tiling_prepass* t, const bt_view_state* view, const float* device_height, uint32_t form);
+}  // namespace bt

@@ -162,7 +162,8 @@ constexpr uint32_t kCntVisited = 8, kCntDivide = 40, kCounterWords = 72;  // (bt
 // radius <= kWinK: the window actually used (storage is laid out for kWinK); counters != nullptr: also resets the counters and
 // the indirect arguments the unordered collector (next launch) accumulates into
 __global__ __launch_bounds__(256) void tiling_divide_bits_kernel(bt_view_state view, uint32_t lods, int radius, unsigned long long* __restrict__ bits,
-                                                                 uint32_t* __restrict__ counters, bt_indirect* __restrict__ indirect) {
+                                                                 uint32_t* __restrict__ counters, bt_indirect* __restrict__ indirect, const float* __restrict__ height) {
+    if (height) view.approximate_height = *height;  // (bt_frame_update: the height sampled earlier on this stream, never seen by the host)
     const uint32_t W = 2u * uint32_t(radius) + 1u, chunks = (W * W + 255u) / 256u;
     const uint32_t chunk = blockIdx.x % chunks, lod = (blockIdx.x / chunks) % lods, side = blockIdx.x / (chunks * lods);
     if (counters && blockIdx.x == 0) {
@@ -210,8 +211,9 @@ struct WindowBits {
 
 __global__ __launch_bounds__(256) void tiling_collect_kernel(bt_view_state view, uint32_t lods, int radius, uint32_t capacity,
                                                              const unsigned long long* __restrict__ bits, bt_tile_coordinate* __restrict__ final_tiles,
-                                                             bt_indirect* __restrict__ indirect, uint32_t* __restrict__ counters) {
+                                                             bt_indirect* __restrict__ indirect, uint32_t* __restrict__ counters, const float* __restrict__ height) {
     __shared__ unsigned long long s_bits[kMaxLods * kWinWords];
+    if (height) view.approximate_height = *height;
     __shared__ int2 s_origin[kMaxLods];
     const uint32_t W = 2u * uint32_t(radius) + 1u, chunks = (W * W + 255u) / 256u;
     const uint32_t chunk = blockIdx.x % chunks, lod = (blockIdx.x / chunks) % lods, side = blockIdx.x / (chunks * lods);
@@ -320,7 +322,9 @@ __global__ __launch_bounds__(kThreads) void tiling_prepass_kernel(bt_view_state 
                                                                   bt_tile_coordinate* __restrict__ temporary_tiles,
                                                                   bt_tile_coordinate* __restrict__ final_tiles,
                                                                   bt_indirect* __restrict__ indirect,
-                                                                  uint32_t* __restrict__ counters, const unsigned long long* __restrict__ bits, uint32_t assist_lods) {
+                                                                  uint32_t* __restrict__ counters, const unsigned long long* __restrict__ bits, uint32_t assist_lods,
+                                                                  const float* __restrict__ height) {
+    if (height) view.approximate_height = *height;
     // The pass state (Parameters, types.wgsl:43-48) is uniform and kept in registers by every thread; only the
     // per-wave counts of a sweep go through LDS (double-buffered by sweep parity: ONE barrier per sweep).
     __shared__ uint32_t s_divide[2][kWaves], s_final[2][kWaves];
@@ -523,50 +527,16 @@ bt_status prepass_check(bt_tiling_prepass* t, const bt_view_state* view) {
 }
 }  // namespace
 
-bt_status bt_tiling_prepass_run(bt_tiling_prepass* t, const bt_view_state* view) {
-    if (bt_status s = prepass_check(t, view)) return s;
-    const uint32_t capacity = std::min(t->capacity, view->geometry_tile_count ? view->geometry_tile_count : t->capacity);
-    const uint32_t sides = view->spherical ? 6u : 1u;
-    const size_t lds = size_t(sides) * kMaxLods * (kWinWords * sizeof(unsigned long long) + sizeof(int2)) + 2 * size_t(kFrontierCap) * sizeof(bt_tile_coordinate);
-    // shallow views (few hundred tiles) are faster in the plain kernel, which saves them the second launch
-    const uint32_t lods = estimate_lods(view);
-    if (lods < 12u) return bt_tiling_prepass_run_plain(t, view);
-    // launch 1: every divide test that can matter (independent, chip-wide); launch 2: the ordered schedule over the bits
-    tiling_divide_bits_kernel<<<sides * lods * kWinChunks, 256, 0, t->ctx->stream>>>(*view, lods, kWinK, t->bits, nullptr, nullptr);
-    tiling_prepass_kernel<true><<<1, kThreads, lds, t->ctx->stream>>>(*view, capacity, t->temporary_tiles, t->final_tiles, t->indirect, t->counters, t->bits, lods);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "tiling_prepass_kernel");
-    t->unordered = false;
-    return BT_OK;
-}
+}  // extern "C"
 
-// The unordered form: the same SET of final tiles and the same indirect arguments, in whatever order the waves arrive (the
-// reference's own order is the arrival order of its atomics).  Two chip-wide launches, no pass chain: flat ~10 us whatever the
-// frame.  temporary_tiles is not written.
-bt_status bt_tiling_prepass_run_unordered(bt_tiling_prepass* t, const bt_view_state* view) {
-    if (bt_status s = prepass_check(t, view)) return s;
-    const uint32_t capacity = std::min(t->capacity, view->geometry_tile_count ? view->geometry_tile_count : t->capacity);
-    const uint32_t sides = view->spherical ? 6u : 1u, lods = estimate_lods(view);
-    const int radius = t->window ? t->window : kWinK;
-    const uint32_t W = 2u * uint32_t(radius) + 1u, chunks = (W * W + 255u) / 256u;
-    tiling_divide_bits_kernel<<<sides * lods * chunks, 256, 0, t->ctx->stream>>>(*view, lods, radius, t->bits, t->counters, t->indirect);
-    tiling_collect_kernel<<<sides * lods * chunks, 256, 0, t->ctx->stream>>>(*view, lods, radius, capacity, t->bits, t->final_tiles, t->indirect, t->counters);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "tiling_collect_kernel");
-    t->unordered = true;
-    t->unordered_capacity = capacity;
-    return BT_OK;
-}
-
-bt_status bt_tiling_prepass_set_window(bt_tiling_prepass* t, uint32_t radius) {
-    if (!t || radius > uint32_t(kWinK)) return BT_ERR_INVALID_ARGUMENT;
-    t->window = int(radius);
-    return BT_OK;
-}
-
-// The plain form: one launch, every divide test evaluated inside the pass that needs it.  Same list, same order; kept as the
-// checker of the two-launch form above (tests) and for hosts that want a single kernel.
-bt_status bt_tiling_prepass_run_plain(bt_tiling_prepass* t, const bt_view_state* view) {
+namespace bt {
+// form 0: two launches — every divide test that can matter (independent, chip-wide), then the ordered schedule over the bits;
+//         shallow views (few hundred tiles) take the plain kernel, which saves them the second launch
+// form 1: the unordered form — the same SET of final tiles and the same indirect arguments, in whatever order the waves arrive
+//         (the reference's own order is the arrival order of its atomics); two chip-wide launches, no pass chain, flat ~10 us
+//         whatever the frame; temporary_tiles is not written
+// form 2: the plain form — one launch, every divide test evaluated inside the pass that needs it; same list, same order as form 0
+bt_status tiling_prepass_enqueue(bt_tiling_prepass* t, const bt_view_state* view, const float* device_height, uint32_t form) {
     if (!t || !view) return BT_ERR_INVALID_ARGUMENT;
     if (view->refinement_count > 31 || view->origin_lod > 31) {
         set_error("refinement_count %u / origin_lod %u > 31 (tile x/y are u32)", view->refinement_count, view->origin_lod);
@@ -574,10 +544,48 @@ bt_status bt_tiling_prepass_run_plain(bt_tiling_prepass* t, const bt_view_state*
     }
     BT_HIP(hipSetDevice(t->ctx->device));
     const uint32_t capacity = std::min(t->capacity, view->geometry_tile_count ? view->geometry_tile_count : t->capacity);
-    tiling_prepass_kernel<false><<<1, kThreads, 0, t->ctx->stream>>>(*view, capacity, t->temporary_tiles, t->final_tiles, t->indirect, t->counters, nullptr, 0u);
+    const uint32_t sides = view->spherical ? 6u : 1u;
+    // (with the height on the device the estimate works from the host's copy, one frame old: it decides how many LODs get their
+    // bits up front and can only cost time)
+    const uint32_t lods = form == 2u ? 0u : estimate_lods(view);
+    if (form == 2u || (form == 0u && lods < 12u)) {
+        tiling_prepass_kernel<false><<<1, kThreads, 0, t->ctx->stream>>>(*view, capacity, t->temporary_tiles, t->final_tiles, t->indirect, t->counters, nullptr, 0u, device_height);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "tiling_prepass_kernel");
+        t->unordered = false;
+        return BT_OK;
+    }
+    if (bt_status s = prepass_check(t, view)) return s;
+    if (form == 0u) {
+        const size_t lds = size_t(sides) * kMaxLods * (kWinWords * sizeof(unsigned long long) + sizeof(int2)) + 2 * size_t(kFrontierCap) * sizeof(bt_tile_coordinate);
+        tiling_divide_bits_kernel<<<sides * lods * kWinChunks, 256, 0, t->ctx->stream>>>(*view, lods, kWinK, t->bits, nullptr, nullptr, device_height);
+        tiling_prepass_kernel<true><<<1, kThreads, lds, t->ctx->stream>>>(*view, capacity, t->temporary_tiles, t->final_tiles, t->indirect, t->counters, t->bits, lods, device_height);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "tiling_prepass_kernel");
+        t->unordered = false;
+        return BT_OK;
+    }
+    const int radius = t->window ? t->window : kWinK;
+    const uint32_t W = 2u * uint32_t(radius) + 1u, chunks = (W * W + 255u) / 256u;
+    tiling_divide_bits_kernel<<<sides * lods * chunks, 256, 0, t->ctx->stream>>>(*view, lods, radius, t->bits, t->counters, t->indirect, device_height);
+    tiling_collect_kernel<<<sides * lods * chunks, 256, 0, t->ctx->stream>>>(*view, lods, radius, capacity, t->bits, t->final_tiles, t->indirect, t->counters, device_height);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "tiling_prepass_kernel");
-    t->unordered = false;
+    if (e != hipSuccess) return hip_fail(e, "tiling_collect_kernel");
+    t->unordered = true;
+    t->unordered_capacity = capacity;
+    return BT_OK;
+}
+}  // namespace bt
+
+extern "C" {
+
+bt_status bt_tiling_prepass_run(bt_tiling_prepass* t, const bt_view_state* view) { return bt::tiling_prepass_enqueue(t, view, nullptr, 0u); }
+bt_status bt_tiling_prepass_run_unordered(bt_tiling_prepass* t, const bt_view_state* view) { return bt::tiling_prepass_enqueue(t, view, nullptr, 1u); }
+bt_status bt_tiling_prepass_run_plain(bt_tiling_prepass* t, const bt_view_state* view) { return bt::tiling_prepass_enqueue(t, view, nullptr, 2u); }
+
+bt_status bt_tiling_prepass_set_window(bt_tiling_prepass* t, uint32_t radius) {
+    if (!t || radius > uint32_t(kWinK)) return BT_ERR_INVALID_ARGUMENT;
+    t->window = int(radius);
     return BT_OK;
 }
 

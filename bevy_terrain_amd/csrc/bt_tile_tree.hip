@@ -62,8 +62,9 @@ __host__ __device__ __forceinline__ uint32_t hash_coordinate(bt_tile_coordinate 
 // order (iproduct!(0..ts, 0..ts): x outer); the node's table slot is [side][lod][tile.x % ts][tile.y % ts].
 __global__ __launch_bounds__(kThreads) void tile_tree_update_kernel(TreeParams P, NodeState* __restrict__ nodes, uint32_t* __restrict__ origins,
                                                                     bt_tile_coordinate* __restrict__ released, bt_tile_coordinate* __restrict__ requested,
-                                                                    uint32_t* __restrict__ counts) {
+                                                                    uint32_t* __restrict__ counts, const float* __restrict__ height) {
     __shared__ uint32_t s_rel[2][kWaves], s_req[2][kWaves];
+    if (height) P.approximate_height = *height;  // the tree's height lives on the device (bt_frame_update: the host's copy may lag a frame)
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const uint32_t ts = P.tree_size, per_layer = ts * ts, total = P.sides * P.lod_count * per_layer;
     uint32_t rel_base = 0, req_base = 0, sweep = 0;
@@ -250,9 +251,10 @@ __device__ __forceinline__ void sample_lookup(const AttachmentMeta& m, const voi
 // sample_attachment / sample_height (terrain_data/mod.rs:265-307), one world position per thread
 __global__ __launch_bounds__(128) void tile_tree_sample_kernel(TreeParams P, const bt_tile_tree_entry* __restrict__ entries, AttachmentMeta m,
                                                                const void* __restrict__ atlas, const double* __restrict__ positions, uint32_t count,
-                                                               float4* __restrict__ out, float* __restrict__ heights) {
+                                                               float4* __restrict__ out, float* __restrict__ heights, const float* __restrict__ height) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
+    if (height) P.approximate_height = *height;
     const V3 p = {positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]};
     const V3 surface = surface_position(P.model, p, double(P.approximate_height));
     // compute_blend (tile_tree.rs:223-239)
@@ -295,16 +297,22 @@ struct bt_tile_tree {
     NodeState* d_nodes = nullptr;
     bt_tile_tree_entry* d_entries = nullptr;
     uint32_t* d_origins = nullptr;
-    bt_tile_coordinate *d_released = nullptr, *d_requested = nullptr;
-    uint32_t* d_counts = nullptr;
+    float* d_height = nullptr;  // [0] approximate_height (what the kernels read), [4..8) the vec4 sample behind it
     StateSlot* d_table = nullptr;
     uint32_t table_capacity = 0;
     uint64_t table_version = 0;
     const bt_atlas* table_atlas = nullptr;
-    // host copies of the last update's lists (pinned)
+    // the last update's lists: pinned host memory the update kernel writes directly (one synchronisation, no copies)
     bt_tile_coordinate *h_released = nullptr, *h_requested = nullptr;
     uint32_t* h_counts = nullptr;
     uint32_t released_count = 0, requested_count = 0;
+    // bt_frame_update: pinned staging of the view position, of the height read back one frame late, and of the atlas's tile states
+    double* h_view_position = nullptr;
+    float* h_height = nullptr;
+    bool height_in_flight = false;  // an asynchronous copy d_height -> h_height was enqueued after the last synchronisation
+    StateSlot* h_table = nullptr;
+    uint32_t h_table_capacity = 0;
+    bool table_copy_pending = false;  // h_table -> d_table enqueued since the last synchronisation
 };
 
 namespace {
@@ -408,9 +416,9 @@ bt_status bt_tile_tree_create(bt_ctx* ctx, const bt_terrain_model* model, uint32
     hipError_t e = hipMalloc((void**)&t->d_nodes, sizeof(NodeState) * t->nodes);
     if (e == hipSuccess) e = hipMalloc((void**)&t->d_entries, sizeof(bt_tile_tree_entry) * t->nodes);
     if (e == hipSuccess) e = hipMalloc((void**)&t->d_origins, sizeof(uint32_t) * 2 * t->sides * lod_count);
-    if (e == hipSuccess) e = hipMalloc((void**)&t->d_released, sizeof(bt_tile_coordinate) * t->nodes);
-    if (e == hipSuccess) e = hipMalloc((void**)&t->d_requested, sizeof(bt_tile_coordinate) * t->nodes);
-    if (e == hipSuccess) e = hipMalloc((void**)&t->d_counts, sizeof(uint32_t) * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&t->d_height, sizeof(float) * 8);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&t->h_view_position, sizeof(double) * 3, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&t->h_height, sizeof(float), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&t->h_released, sizeof(bt_tile_coordinate) * t->nodes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&t->h_requested, sizeof(bt_tile_coordinate) * t->nodes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&t->h_counts, sizeof(uint32_t) * 2, hipHostMallocDefault);
@@ -425,6 +433,8 @@ bt_status bt_tile_tree_create(bt_ctx* ctx, const bt_terrain_model* model, uint32
     // `requested` must start as 0 (Released): the 0xFF fill set it; clear that field with one small kernel-free pass
     std::vector<NodeState> init(t->nodes, NodeState{{kInvalid, kInvalid, kInvalid, kInvalid}, 0u});
     e = hipMemcpyAsync(t->d_nodes, init.data(), sizeof(NodeState) * t->nodes, hipMemcpyHostToDevice, ctx->stream);
+    const float height0[8] = {t->approximate_height, 0, 0, 0, 0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(t->d_height, height0, sizeof height0, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         bt_tile_tree_destroy(t);
@@ -437,29 +447,46 @@ bt_status bt_tile_tree_create(bt_ctx* ctx, const bt_terrain_model* model, uint32
 void bt_tile_tree_destroy(bt_tile_tree* t) {
     if (!t) return;
     hipSetDevice(t->ctx->device);
-    for (void* p : {(void*)t->d_nodes, (void*)t->d_entries, (void*)t->d_origins, (void*)t->d_released, (void*)t->d_requested, (void*)t->d_counts, (void*)t->d_table})
+    for (void* p : {(void*)t->d_nodes, (void*)t->d_entries, (void*)t->d_origins, (void*)t->d_height, (void*)t->d_table})
         if (p) hipFree(p);
-    for (void* p : {(void*)t->h_released, (void*)t->h_requested, (void*)t->h_counts})
+    for (void* p : {(void*)t->h_released, (void*)t->h_requested, (void*)t->h_counts, (void*)t->h_view_position, (void*)t->h_height, (void*)t->h_table})
         if (p) hipHostFree(p);
     delete t;
 }
 
+namespace {
+// the host's mirror of the tree's height: refreshed whenever the stream has just been synchronised
+void adopt_height(bt_tile_tree* t) {
+    if (t->height_in_flight) {
+        t->approximate_height = *t->h_height;
+        t->height_in_flight = false;
+    }
+}
+
+// TileTree::update as one launch; the kernel writes both lists and their lengths straight into pinned host memory
+bt_status enqueue_update(bt_tile_tree* t, const double view_world_position[3]) {
+    for (int i = 0; i < 3; i++) t->view_world_position[i] = view_world_position[i];
+    const TreeParams P = make_params(t);
+    tile_tree_update_kernel<<<1, kThreads, 0, t->ctx->stream>>>(P, t->d_nodes, t->d_origins, t->h_released, t->h_requested, t->h_counts, t->d_height);
+    BT_HIP(hipGetLastError());
+    return BT_OK;
+}
+
+bt_status finish_update(bt_tile_tree* t) {
+    BT_HIP(hipStreamSynchronize(t->ctx->stream));
+    adopt_height(t);
+    t->table_copy_pending = false;
+    t->released_count = t->h_counts[0];
+    t->requested_count = t->h_counts[1];
+    return BT_OK;
+}
+}  // namespace
+
 bt_status bt_tile_tree_update(bt_tile_tree* t, const double view_world_position[3]) {
     if (!t || !view_world_position) return BT_ERR_INVALID_ARGUMENT;
     BT_HIP(hipSetDevice(t->ctx->device));
-    for (int i = 0; i < 3; i++) t->view_world_position[i] = view_world_position[i];
-    const TreeParams P = make_params(t);
-    hipStream_t s = t->ctx->stream;
-    tile_tree_update_kernel<<<1, kThreads, 0, s>>>(P, t->d_nodes, t->d_origins, t->d_released, t->d_requested, t->d_counts);
-    BT_HIP(hipGetLastError());
-    BT_HIP(hipMemcpyAsync(t->h_counts, t->d_counts, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, s));
-    BT_HIP(hipStreamSynchronize(s));
-    t->released_count = t->h_counts[0];
-    t->requested_count = t->h_counts[1];
-    if (t->released_count) BT_HIP(hipMemcpyAsync(t->h_released, t->d_released, sizeof(bt_tile_coordinate) * t->released_count, hipMemcpyDeviceToHost, s));
-    if (t->requested_count) BT_HIP(hipMemcpyAsync(t->h_requested, t->d_requested, sizeof(bt_tile_coordinate) * t->requested_count, hipMemcpyDeviceToHost, s));
-    if (t->released_count || t->requested_count) BT_HIP(hipStreamSynchronize(s));
-    return BT_OK;
+    if (bt_status s = enqueue_update(t, view_world_position)) return s;
+    return finish_update(t);
 }
 
 bt_status bt_tile_tree_requests(const bt_tile_tree* t, const bt_tile_coordinate** released, uint32_t* released_count, const bt_tile_coordinate** requested,
@@ -493,7 +520,22 @@ bt_status bt_tile_tree_adjust_to_tile_atlas(bt_tile_tree* t, const bt_atlas* a) 
     if (t->table_atlas != a || t->table_version != a->state_version || !t->d_table) {
         uint32_t capacity = 64;
         while (capacity < 2 * a->tile_states.size() + 2) capacity *= 2;
-        std::vector<StateSlot> table(capacity, StateSlot{{kInvalid, kInvalid, kInvalid, kInvalid}, BT_INVALID_ATLAS_INDEX, 0u});
+        if (capacity > t->h_table_capacity) {
+            // (the staging table is rewritten below: a copy out of the old one may still be in flight)
+            BT_HIP(hipStreamSynchronize(s));
+            adopt_height(t);
+            if (t->h_table) BT_HIP(hipHostFree(t->h_table));
+            t->h_table = nullptr;
+            t->h_table_capacity = 0;
+            BT_HIP(hipHostMalloc((void**)&t->h_table, sizeof(StateSlot) * capacity, hipHostMallocDefault));
+            t->h_table_capacity = capacity;
+        }
+        // The pinned staging table is reused by every upload.  Its previous copy was enqueued before the update kernel whose
+        // lists the host has since read (bt_tile_tree_update / bt_frame_update synchronise on them), i.e. it has completed —
+        // unless the caller adjusts twice without an update in between: then wait for it.
+        if (t->table_copy_pending) BT_HIP(hipStreamSynchronize(s));
+        StateSlot* table = t->h_table;
+        for (uint32_t i = 0; i < capacity; i++) table[i] = StateSlot{{kInvalid, kInvalid, kInvalid, kInvalid}, BT_INVALID_ATLAS_INDEX, 0u};
         for (const auto& kv : a->tile_states) {
             uint32_t i = hash_coordinate(kv.first) & (capacity - 1);
             while (table[i].coordinate.side != kInvalid) i = (i + 1u) & (capacity - 1);
@@ -505,9 +547,8 @@ bt_status bt_tile_tree_adjust_to_tile_atlas(bt_tile_tree* t, const bt_atlas* a) 
             BT_HIP(hipMalloc((void**)&t->d_table, sizeof(StateSlot) * capacity));
         }
         t->table_capacity = capacity;
-        // (pageable source: the copy is staged before the call returns)
-        BT_HIP(hipMemcpyAsync(t->d_table, table.data(), sizeof(StateSlot) * capacity, hipMemcpyHostToDevice, s));
-        BT_HIP(hipStreamSynchronize(s));
+        BT_HIP(hipMemcpyAsync(t->d_table, table, sizeof(StateSlot) * capacity, hipMemcpyHostToDevice, s));  // pinned source: asynchronous
+        t->table_copy_pending = true;
         t->table_atlas = a;
         t->table_version = a->state_version;
     }
@@ -536,6 +577,8 @@ bt_status bt_tile_tree_read(bt_tile_tree* t, bt_tile_tree_entry* entries, uint32
         BT_HIP(hipMemcpyAsync(nodes.data(), t->d_nodes, sizeof(NodeState) * t->nodes, hipMemcpyDeviceToHost, s));
     }
     BT_HIP(hipStreamSynchronize(s));
+    adopt_height(t);
+    t->table_copy_pending = false;
     for (uint32_t i = 0; i < uint32_t(nodes.size()) && i < entry_cap; i++) {
         if (node_coordinates) node_coordinates[i] = nodes[i].coordinate;
         if (node_requested) node_requested[i] = nodes[i].requested;
@@ -556,7 +599,7 @@ bt_status bt_tile_tree_sample_attachment(bt_tile_tree* t, bt_atlas* a, uint32_t 
     hipError_t e = hipMemcpyAsync(dev, positions, in_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
         tile_tree_sample_kernel<<<(count + 127u) / 128u, 128, 0, s>>>(make_params(t), t->d_entries, at.meta, at.level0, (const double*)dev, count,
-                                                                      (float4*)(dev + in_bytes), (float*)(dev + in_bytes + out_bytes));
+                                                                      (float4*)(dev + in_bytes), (float*)(dev + in_bytes + out_bytes), t->d_height);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out_vec4, dev + in_bytes, out_bytes, hipMemcpyDeviceToHost, s);
@@ -567,12 +610,64 @@ bt_status bt_tile_tree_sample_attachment(bt_tile_tree* t, bt_atlas* a, uint32_t 
     return BT_OK;
 }
 
+namespace {
+// TileTree::approximate_height (tile_tree.rs:372-386): sample_height of attachment 0 at the view position, kept on the device
+// (d_height[0]; the kernel reads the old value for its surface position, then overwrites it) and copied to pinned memory
+bt_status enqueue_height(bt_tile_tree* t, bt_atlas* a) {
+    if (a->attachments.empty()) return BT_ERR_INVALID_ARGUMENT;
+    const Attachment& at = a->attachments[0];
+    if (at.meta.format != BT_FORMAT_R16 && at.meta.format != BT_FORMAT_RGBA8) return BT_ERR_UNSUPPORTED;
+    for (int i = 0; i < 3; i++) t->h_view_position[i] = t->view_world_position[i];  // (read by the kernel: the previous kernel that read it has finished — the caller synchronised on the update since)
+    hipStream_t s = t->ctx->stream;
+    tile_tree_sample_kernel<<<1, 128, 0, s>>>(make_params(t), t->d_entries, at.meta, at.level0, t->h_view_position, 1u, (float4*)(t->d_height + 4), t->d_height, t->d_height);
+    BT_HIP(hipGetLastError());
+    BT_HIP(hipMemcpyAsync(t->h_height, t->d_height, sizeof(float), hipMemcpyDeviceToHost, s));
+    t->height_in_flight = true;
+    return BT_OK;
+}
+}  // namespace
+
 bt_status bt_tile_tree_approximate_height(bt_tile_tree* t, bt_atlas* a, float* height) {
     if (!t || !a) return BT_ERR_INVALID_ARGUMENT;
-    float value[4], h = 0.0f;
-    if (bt_status s = bt_tile_tree_sample_attachment(t, a, 0, t->view_world_position, 1, value, &h)) return s;
-    t->approximate_height = h;
-    if (height) *height = h;
+    BT_HIP(hipSetDevice(t->ctx->device));
+    if (bt_status s = enqueue_height(t, a)) return s;
+    BT_HIP(hipStreamSynchronize(t->ctx->stream));
+    adopt_height(t);
+    t->table_copy_pending = false;
+    if (height) *height = t->approximate_height;
+    return BT_OK;
+}
+
+// The reference's per-frame chain (src/plugin.rs:46-56): TileTree::compute_requests -> TileAtlas::update (the tree's releases
+// and requests) -> TileTree::adjust_to_tile_atlas -> TileTree::approximate_height -> the tiling prepass of the view, as ONE call
+// with ONE host synchronisation: the one the reference's structure forces, because the atlas's streaming state machine (LRU,
+// file loads) is host code and needs the two lists.  Everything behind it is enqueued and left running: the tile states travel
+// from pinned memory, the height stays on the device (the prepass kernels and the next frame's update read it there; the host's
+// copy arrives with the next synchronisation), the final tiles and indirect arguments are in the buffers a renderer binds.
+bt_status bt_frame_update(bt_tile_tree* t, bt_atlas* a, bt_tiling_prepass* prepass, const double view_world_position[3], uint32_t flags, bt_frame_info* out) {
+    if (!t || !a || !view_world_position) return BT_ERR_INVALID_ARGUMENT;
+    if (t->ctx != a->ctx) {
+        set_error("tile tree and atlas belong to different contexts");
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    BT_HIP(hipSetDevice(t->ctx->device));
+    if (bt_status s = enqueue_update(t, view_world_position)) return s;
+    if (bt_status s = finish_update(t)) return s;  // the synchronisation
+    bt_frame_info info{};
+    info.released_count = t->released_count;
+    info.requested_count = t->requested_count;
+    info.approximate_height = t->approximate_height;  // what this frame's update saw
+    if (!(flags & BT_FRAME_KEEP_REQUESTS)) info.apply_status = bt_tile_tree_apply_requests(t, a);
+    if (bt_status s = bt_tile_tree_adjust_to_tile_atlas(t, a)) return s;
+    if (!(flags & BT_FRAME_KEEP_HEIGHT))
+        if (bt_status s = enqueue_height(t, a)) return s;
+    if (prepass) {
+        bt_view_state view;
+        if (bt_status s = bt_tile_tree_view_state(t, &view)) return s;  // (approximate_height: the host's copy; the kernels take the device's)
+        const uint32_t form = (flags & BT_FRAME_PREPASS_UNORDERED) ? 1u : ((flags & BT_FRAME_PREPASS_PLAIN) ? 2u : 0u);
+        if (bt_status s = bt::tiling_prepass_enqueue(prepass, &view, t->d_height, form)) return s;
+    }
+    if (out) *out = info;
     return BT_OK;
 }
 

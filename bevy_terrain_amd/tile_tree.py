@@ -113,6 +113,18 @@ class TileTree:
         _ffi.check(_ffi.lib().bt_tile_tree_approximate_height(self._h, self.atlas._h, C.byref(h)))
         return h.value
 
+    def frame_update(self, view_position: Sequence[float], prepass=None, *, unordered=False, plain=False, keep_requests=False, keep_height=False):
+        """One frame of this view as ONE library call with one host synchronisation (bt_frame_update): update -> the lists
+        applied to the atlas -> adjust_to_tile_atlas -> approximate_height (left on the device) -> the tiling prepass.
+        Returns bt_frame_info (list lengths, the status of the apply step, the height this frame's update used)."""
+        pos = (C.c_double * 3)(*view_position)
+        info = _ffi.FrameInfoC()
+        flags = (_ffi.FRAME_PREPASS_UNORDERED if unordered else 0) | (_ffi.FRAME_PREPASS_PLAIN if plain else 0) | \
+            (_ffi.FRAME_KEEP_REQUESTS if keep_requests else 0) | (_ffi.FRAME_KEEP_HEIGHT if keep_height else 0)
+        # the lists are consumed by the call (apply_requests drains them): read them through KEEP_REQUESTS when wanted
+        _ffi.check(_ffi.lib().bt_frame_update(self._h, self.atlas._h, prepass._h if prepass is not None else None, pos, flags, C.byref(info)))
+        return info
+
     def view_state(self) -> _ffi.ViewStateC:
         v = _ffi.ViewStateC()
         _ffi.check(_ffi.lib().bt_tile_tree_view_state(self._h, C.byref(v)))

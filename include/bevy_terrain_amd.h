@@ -29,10 +29,12 @@
 extern "C" {
 #endif
 
-/* 3 (round 3): + bt_preprocessor_run_streamed, BT_RASTER_HOST_DEFERRED, BT_RUN_SHARD_EXCHANGE, bt_tiling_prepass_run_plain /
+/* 4 (round 4): + bt_frame_update / bt_frame_info; the fused plan no longer has a fused_todo launch (kind 6 of bt_launch_profile
+ * does not occur any more) — additions only.
+ * 3 (round 3): + bt_preprocessor_run_streamed, BT_RASTER_HOST_DEFERRED, BT_RUN_SHARD_EXCHANGE, bt_tiling_prepass_run_plain /
  * _run_unordered / _set_window, launch kind 6 (fused todo) in bt_launch_profile — additions only, every version-2 call keeps its
  * meaning. */
-#define BT_ABI_VERSION 3u
+#define BT_ABI_VERSION 4u
 
 typedef int32_t bt_status;
 enum {
@@ -487,6 +489,28 @@ bt_status bt_tile_tree_sample_attachment(bt_tile_tree* tree, bt_atlas* atlas, ui
 bt_status bt_tile_tree_approximate_height(bt_tile_tree* tree, bt_atlas* atlas, float* height);
 /* the tree's current state as a prepass input (bt_view_state_from_config with the tree's view position / height) */
 bt_status bt_tile_tree_view_state(const bt_tile_tree* tree, bt_view_state* out);
+
+/* One frame of one view (src/plugin.rs:46-56: TileTree::compute_requests -> TileAtlas::update's release / request half ->
+ * TileTree::adjust_to_tile_atlas -> TileTree::approximate_height -> TilingPrepassNode::run) as ONE call with ONE host
+ * synchronisation — the one the structure forces: the atlas's streaming state machine is host code and needs the two lists,
+ * which the update kernel writes straight into pinned memory.  Everything behind it is enqueued and left running on the
+ * context's stream: tile states from pinned staging, the sampled height stays on the device (the prepass kernels and the
+ * next frame's update read it there; bt_tile_tree_view_state / the next bt_frame_info report it one frame late), the final
+ * tile list and indirect arguments land in bt_tiling_prepass_buffers().  File loads stay with bt_atlas_update().
+ * Identical lists, entries and final tiles to the separate calls (tests/test_gpu_tile_tree.py). */
+enum {
+    BT_FRAME_PREPASS_UNORDERED = 1, /* bt_tiling_prepass_run_unordered instead of bt_tiling_prepass_run */
+    BT_FRAME_PREPASS_PLAIN = 2,     /* bt_tiling_prepass_run_plain */
+    BT_FRAME_KEEP_REQUESTS = 4,     /* do not apply the lists to the atlas: the caller does (bt_tile_tree_requests / _apply_requests) */
+    BT_FRAME_KEEP_HEIGHT = 8,       /* skip approximate_height */
+};
+typedef struct bt_frame_info {
+    uint32_t released_count, requested_count; /* this frame's lists (bt_tile_tree_requests) */
+    bt_status apply_status;                   /* of bt_tile_tree_apply_requests (BT_OK when skipped) */
+    float approximate_height;                 /* the height this frame's update used, i.e. the previous frame's sample */
+} bt_frame_info;
+bt_status bt_frame_update(bt_tile_tree* tree, bt_atlas* atlas, bt_tiling_prepass* prepass /* may be NULL */,
+                          const double view_world_position[3], uint32_t flags, bt_frame_info* out /* may be NULL */);
 
 /* ---------------------------------------------------------------- diagnostics */
 /* Exhaustive device check that the kernels' 3-operation unorm16 -> f32 conversion equals the correctly

@@ -161,6 +161,58 @@ def test_streaming_loop_entries_and_heights(device, tmp_path, kind, atlas_size):
     assert bytes(v) == bytes(bt.view_state_from_config(model, vc, path[-1], v.approximate_height))
 
 
+@pytest.mark.parametrize("kind,unordered", [("planar", False), ("sphere", False), ("sphere", True)])
+def test_frame_update_equals_the_separate_calls(device, tmp_path, kind, unordered):
+    """bt_frame_update (one call, one host synchronisation, the height left on the device) against the chain of separate calls
+    it replaces — two streaming instances of the same terrain in lock step: the same request / release lists, the same
+    tile-tree entries, the same final tile list of the prepass (ordered form: in order; unordered form: as a set) and the
+    same indirect arguments, frame by frame; the host's copy of the height arrives one frame late and is then the same."""
+    model, _ = MODELS[kind]
+    lods, T, b = 4, 32, 2
+    root, cfg, tiles = build_terrain(device, tmp_path, model, lods, T, b)
+    vc = bt.TerrainViewConfig(tree_size=4, load_distance=1.2, blend_distance=1.0, geometry_tile_count=20000)
+
+    def instance():
+        scfg = bt.TerrainConfig(lod_count=lods, atlas_size=256 if kind == "planar" else 512, path=cfg.path, model=model)
+        scfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=T, border_size=b, format=bt.AttachmentFormat.R16, mip_level_count=3))
+        atlas = bt.TileAtlas.new(scfg, device)
+        atlas.load_tile_config(root)
+        return atlas, bt.TileTree.new(atlas, vc), bt.TilingPrepass(device, vc.geometry_tile_count)
+
+    atlas_a, tree_a, prepass_a = instance()
+    atlas_b, tree_b, prepass_b = instance()
+    heights_a, moved = [], 0
+    for frame, pos in enumerate(camera_path(kind, 25, seed=5)):
+        # A: the separate calls, in the reference's order (plugin.rs:46-56)
+        released, requested = tree_a.update(pos)
+        atlas_a.update(root)
+        tree_a.apply_requests()
+        tree_a.adjust_to_tile_atlas()
+        heights_a.append(tree_a.approximate_height())
+        prepass_a.run(tree_a.view_state(), unordered=unordered)
+        # B: the loads of earlier frames, then ONE call
+        atlas_b.update(root)
+        info = tree_b.frame_update(pos, prepass_b, unordered=unordered)
+        assert (info.released_count, info.requested_count, info.apply_status) == (len(released), len(requested), 0), frame
+        moved += len(requested)
+        if frame > 0:  # the height the update of this frame used = the sample of the previous frame
+            assert info.approximate_height == heights_a[frame - 1], frame
+        ea, oa, ca, fa = tree_a.read()
+        eb, ob, cb, fb = tree_b.read()
+        assert np.array_equal(ea, eb) and np.array_equal(oa, ob) and np.array_equal(ca, cb) and np.array_equal(fa, fb), frame
+        ta, ia = prepass_a.read()
+        tb, ib = prepass_b.read()
+        assert list(ia) == list(ib), frame
+        if unordered:
+            assert sorted(map(tuple, ta)) == sorted(map(tuple, tb)), frame
+        else:
+            assert np.array_equal(ta, tb), frame
+        assert len(ta) > 0
+        # after the synchronisation of read(): the host's copy has caught up
+        assert tree_b.view_state().approximate_height == heights_a[frame], frame
+    assert moved > 20
+
+
 def test_mips_of_streamed_tiles(device, tmp_path):
     model, _ = MODELS["planar"]
     root, cfg, tiles = build_terrain(device, tmp_path, model, 3)
