@@ -322,13 +322,22 @@ typedef struct {
     uint32_t lx, ly, ux, uy;
 } tile_range;
 
+/* `as_uvec2` (glam: `as u32` per component) saturates: negative and NaN -> 0, too large -> u32::MAX; a plain C cast of a negative
+ * float is undefined.  DEVIATION shared with the product (deliberate deviations): the range is then clamped to the
+ * face — a bottom_right > 1 would make the reference queue tiles with x, y >= 2^lod, which do not exist (found by the second
+ * model, tests/_second_models.py, round 4: until then this function cast without saturating and did not clamp). */
+static uint32_t as_u32_saturating(float v, uint32_t face) {
+    if (!(v > 0.0f)) return 0u;
+    if (v >= (float)face) return face;
+    return (uint32_t)v;
+}
 static tile_range overlapping_tiles(const orc_dataset* d, uint32_t lod) {
     float tile_count = (float)(1u << lod);
     tile_range r;
-    r.lx = (uint32_t)(d->top_left[0] * tile_count);
-    r.ly = (uint32_t)(d->top_left[1] * tile_count);
-    r.ux = (uint32_t)ceilf(d->bottom_right[0] * tile_count);
-    r.uy = (uint32_t)ceilf(d->bottom_right[1] * tile_count);
+    r.lx = as_u32_saturating(d->top_left[0] * tile_count, 1u << lod);
+    r.ly = as_u32_saturating(d->top_left[1] * tile_count, 1u << lod);
+    r.ux = as_u32_saturating(ceilf(d->bottom_right[0] * tile_count), 1u << lod);
+    r.uy = as_u32_saturating(ceilf(d->bottom_right[1] * tile_count), 1u << lod);
     return r;
 }
 

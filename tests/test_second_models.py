@@ -1,0 +1,147 @@
+"""The second models of the Rust-side contract (tests/_second_models.py: closed forms / whole-table numpy, written from the reference
+text independently of bt_host.cpp and the oracle) against the ORACLE, on the CPU.  tests/test_gpu_second_models.py holds the same
+comparisons against the product."""
+import numpy as np
+import pytest
+
+import _oracle as O
+import _second_models as S
+import bevy_terrain_amd as bt
+from test_tile_tree_host import MODELS, positions
+
+
+def oracle_indices(atlas):
+    return {c: i for c, i in atlas.tiles()}
+
+
+PLANAR_JOBS = {
+    "full": [("tile", 0, (0.0, 0.0), (1.0, 1.0), 0, 4)],
+    "sub_rectangle": [("tile", 0, (0.25, 0.0), (0.75, 0.5), 0, 5)],
+    "odd_rectangle": [("tile", 0, (0.1, 0.37), (0.93, 0.81), 1, 5)],
+    "partial_lods": [("tile", 0, (0.0, 0.0), (1.0, 1.0), 2, 5)],
+    "overlay": [("tile", 0, (0.0, 0.0), (1.0, 1.0), 0, 4), ("tile", 0, (0.3, 0.2), (0.6, 0.9), 0, 5)],
+    "side_by_side": [("tile", 0, (0.0, 0.0), (0.5, 1.0), 0, 4), ("tile", 0, (0.5, 0.0), (1.0, 1.0), 0, 4)],
+    "beyond_the_face": [("tile", 0, (-0.25, 0.0), (1.5, 1.0), 0, 3)],
+}
+
+
+@pytest.mark.parametrize("name", sorted(PLANAR_JOBS))
+def test_atlas_indices_of_planar_jobs_equal_the_oracle(name):
+    jobs = PLANAR_JOBS[name]
+    src = np.ones((40, 40), np.uint16)
+    atlas = O.OracleAtlas(5, 2048, False, [(16, 2, 1, O.FORMAT_R16)])
+    atlas.clear_attachment(0)
+    for _, side, tl, br, l0, l1 in jobs:
+        atlas.preprocess_tile(0, src, (l0, l1), side=side, top_left=tl, bottom_right=br)
+    model = S.atlas_indices(jobs)
+    assert model == oracle_indices(atlas) and len(model) > 10
+    if len(jobs) == 1:  # one job on a fresh atlas: pure arithmetic
+        _, side, tl, br, l0, l1 = jobs[0]
+        for (s, lod, x, y), index in model.items():
+            assert S.planar_closed_form(s, lod, x, y, tl, br, l0, l1) == index
+
+
+@pytest.mark.parametrize("lods", [(0, 1), (0, 3), (1, 4)])
+def test_atlas_indices_of_cube_jobs_equal_the_oracle(lods):
+    faces = [np.ones((24, 24), np.uint16)] * 6
+    atlas = O.OracleAtlas(4, 2048, True, [(16, 2, 1, O.FORMAT_R16)])
+    atlas.clear_attachment(0).preprocess_spherical(0, faces, lods)
+    model = S.atlas_indices([("spherical",) + lods])
+    assert model == oracle_indices(atlas)
+    per_side = sum(4 ** l for l in range(*lods))
+    for (side, lod, x, y), index in model.items():  # full faces: side-major, then LODs downwards, x-major
+        assert index == side * per_side + sum(4 ** l for l in range(lod + 1, lods[1])) + x * (1 << lod) + y
+
+
+def random_jobs(rng):
+    jobs = []
+    for _ in range(rng.integers(1, 4)):
+        a, b = np.sort(rng.random(2)), np.sort(rng.random(2))
+        l0 = int(rng.integers(0, 3))
+        jobs.append(("tile", 0, (float(a[0]), float(b[0])), (float(a[1]) + 0.05, float(b[1]) + 0.05), l0, int(l0 + rng.integers(1, 4))))
+    return jobs
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_atlas_indices_of_random_job_sequences_equal_the_oracle(seed):
+    jobs = random_jobs(np.random.default_rng(700 + seed))
+    src = np.ones((40, 40), np.uint16)
+    atlas = O.OracleAtlas(6, 4096, False, [(16, 2, 1, O.FORMAT_R16)])
+    atlas.clear_attachment(0)
+    for _, side, tl, br, l0, l1 in jobs:
+        atlas.preprocess_tile(0, src, (l0, l1), side=side, top_left=tl, bottom_right=br)
+    assert S.atlas_indices(jobs) == oracle_indices(atlas)
+
+
+def tree_model(kind, lods, tree_size, load_distance=2.5):
+    model, _ = MODELS[kind]
+    return S.TileTreeModel(kind, model.translation, model.scale_vec, model.min_height, model.max_height, lods, tree_size, load_distance)
+
+
+@pytest.mark.parametrize("kind", ["planar", "sphere", "ellipsoid"])
+@pytest.mark.parametrize("lods,tree_size", [(7, 8), (12, 4), (3, 8)])
+def test_tile_tree_update_model_equals_the_oracle(kind, lods, tree_size):
+    _, omodel = MODELS[kind]
+    otree = O.TileTree(omodel, lods, O.make_view_config(tree_size=tree_size))
+    mine = tree_model(kind, lods, tree_size)
+    pushed = 0
+    for frame, pos in enumerate(positions(kind, 40, seed=11 + lods)):
+        pos = tuple(float(v) for v in pos)
+        exp_released, exp_requested = otree.update(pos)
+        # the ellipsoid's view coordinate (a 1074-step bisection) is taken from the oracle: update itself is what is modelled
+        vc = O.coordinate_from_world_position(omodel, pos) if kind == "ellipsoid" else None
+        if kind != "ellipsoid":  # ... and where it is restated here it must agree
+            side, uv = mine.view_coordinate(pos)
+            oside, ouv = O.coordinate_from_world_position(omodel, pos)
+            assert side == oside and tuple(uv) == ouv, (frame, pos)
+        released, requested = mine.update(pos, vc)
+        assert released == exp_released and requested == exp_requested, (frame, pos)
+        _, origins, coords, flags = otree.read()
+        my_coords, my_flags = mine.node_tables()
+        assert np.array_equal(origins, mine.origins) and np.array_equal(coords, my_coords) and np.array_equal(flags, my_flags), frame
+        pushed += len(requested) + len(released)
+    assert pushed > 50
+
+
+@pytest.mark.parametrize("fmt,T,mips", [(O.FORMAT_R16, 32, 4), (O.FORMAT_R16, 16, 5), (O.FORMAT_RGBA8, 32, 3), (O.FORMAT_RGBA8, 8, 4)])
+def test_generate_mipmaps_model_equals_the_oracle(fmt, T, mips):
+    rng = np.random.default_rng(T * mips)
+    if fmt == O.FORMAT_R16:
+        tile = rng.integers(0, 65536, size=(T, T), dtype=np.uint16)
+        tile[rng.random((T, T)) < 0.3] = 0  # holes: the valid-mean and the all-zero rule
+        tile[:4, :4] = 0
+    else:
+        tile = rng.integers(0, 256, size=(T, T, 4), dtype=np.uint8)
+    exp = O.generate_mipmaps(fmt, tile, mips)
+    mine = S.generate_mipmaps(tile, mips)
+    assert np.array_equal(np.asarray(exp).reshape(mine.shape), mine)
+
+
+def test_tc_bytes_equal_the_hand_rolled_bincode_writer():
+    rng = np.random.default_rng(5)
+    tiles = [(0, 0, 0, 0), (5, 31, 250, 251), (1, 17, 65535, 65536), (2, 30, (1 << 30) - 1, 4294967295), (3, 2, 1, 3)]
+    tiles += [tuple(int(v) for v in rng.integers(0, [6, 20, 1 << 20, 1 << 20])) for _ in range(300)]
+    mine = S.tc_encode(tiles)
+    assert O.tc_encode(tiles) == mine
+    assert bt.tc_encode([bt.TileCoordinate(*t) for t in tiles]) == mine
+    assert mine[:3] == bytes([251]) + (305).to_bytes(2, "little")  # 305 tiles: the u16 marker
+    assert [(t.side, t.lod, t.x, t.y) for t in bt.tc_decode(mine)] == tiles
+
+
+@pytest.mark.parametrize("seed", range(45))
+def test_tile_tree_update_model_on_the_random_sweep(seed):
+    """the sweep of tests/test_gpu_tile_tree.py (random models, configurations and teleporting views) with the numpy model in the
+    place of the device"""
+    from test_gpu_tile_tree import draw_tree_case
+
+    model, omodel, lods, cfg, pts = draw_tree_case(seed)
+    kind = {"planar": "planar", "spherical": "sphere", "ellipsoidal": "ellipsoid"}[model.kind]
+    otree = O.TileTree(omodel, lods, O.make_view_config(**cfg))
+    mine = S.TileTreeModel(kind, model.translation, model.scale_vec, model.min_height, model.max_height, lods, cfg["tree_size"], cfg["load_distance"])
+    for frame, pos in enumerate(pts):
+        exp = otree.update(pos)
+        vc = O.coordinate_from_world_position(omodel, pos) if kind == "ellipsoid" else None
+        assert mine.update(pos, vc) == exp, (seed, frame, pos)
+        _, origins, coords, flags = otree.read()
+        my_coords, my_flags = mine.node_tables()
+        assert np.array_equal(origins, mine.origins) and np.array_equal(coords, my_coords) and np.array_equal(flags, my_flags), (seed, frame)

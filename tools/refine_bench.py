@@ -90,9 +90,34 @@ def measure(device, sweep=False):
             released, requested = tree.update(p)
             tree_us.append((time.perf_counter() - t0) * 1e6)
             requests.append(len(released) + len(requested))
+        # the whole per-frame chain (plugin.rs:46-56): as separate calls (a synchronisation in update, the height read back,
+        # the view state derived on the host, the prepass enqueued) and as ONE call (bt_frame_update: one synchronisation, the
+        # height stays on the device); host wall time per frame, the stream drained at the end of every frame in both
+        chain_us, frame_us = [], []
+        fp = bt.TilingPrepass(device, cfg.geometry_tile_count)
+        for p in positions[:4]:
+            tree.frame_update(p, fp, unordered=True)
+        device.synchronize()
+        for p in positions:
+            t0 = time.perf_counter()
+            tree.update(p)
+            tree.apply_requests()
+            tree.adjust_to_tile_atlas()
+            tree.approximate_height()
+            fp.run(tree.view_state(), unordered=True)
+            device.synchronize()
+            chain_us.append((time.perf_counter() - t0) * 1e6)
+        for p in positions:
+            t0 = time.perf_counter()
+            tree.frame_update(p, fp, unordered=True)
+            device.synchronize()
+            frame_us.append((time.perf_counter() - t0) * 1e6)
         tree.close()
         out[name + "_tile_tree"] = {"nodes": tree.nodes, "lod_count": lods, "us_per_update_avg_host_wall": float(np.mean(tree_us)),
-                                     "us_per_update_max_host_wall": float(np.max(tree_us)), "requests_plus_releases_avg": float(np.mean(requests))}
+                                     "us_per_update_max_host_wall": float(np.max(tree_us)), "requests_plus_releases_avg": float(np.mean(requests)),
+                                     "frame_chain_separate_calls_us_avg_host_wall": float(np.mean(chain_us)), "frame_chain_separate_calls_us_max": float(np.max(chain_us)),
+                                     "frame_update_one_call_us_avg_host_wall": float(np.mean(frame_us)), "frame_update_one_call_us_max": float(np.max(frame_us)),
+                                     "frame_note": "update -> apply requests -> adjust_to_tile_atlas -> approximate_height -> unordered prepass, through the Python binding, stream drained per frame"}
         out[name] = {"frames": len(views), "us_per_frame_avg": 1e3 * float(np.mean(ms)), "us_per_frame_max": 1e3 * float(np.max(ms)),
                      "final_tiles_avg": float(np.mean(counts)), "final_tiles_max": int(np.max(counts)),
                      "launches_per_frame": 2, "reference_dispatches_per_frame": 2 * cfg.refinement_count + 3,
