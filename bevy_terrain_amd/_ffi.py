@@ -35,7 +35,7 @@ INVALID_ATLAS_INDEX = 0xFFFFFFFF
 MAX_ATTACHMENTS = 8
 
 BT_OK = 0
-RUN_AUTO, RUN_GENERIC, RUN_KEEP_QUEUE, RUN_PROFILE, RUN_SHARD_LOCAL, RUN_SHARD_FINISH, RUN_SHARD_DISTRIBUTED, RUN_SHARD_EXCHANGE = 0, 1, 2, 4, 8, 16, 32, 64
+RUN_AUTO, RUN_GENERIC, RUN_KEEP_QUEUE, RUN_PROFILE, RUN_SHARD_LOCAL, RUN_SHARD_FINISH, RUN_SHARD_DISTRIBUTED, RUN_SHARD_EXCHANGE, RUN_SHARD_OVERLAP = 0, 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class BtError(RuntimeError):
@@ -208,6 +208,7 @@ PROTOTYPES = {
     "bt_comm_destroy": (None, [_vp]),
     "bt_comm_check": (_i32, [_vp]),
     "bt_preprocessor_run_sharded": (_i32, [_vp, _vp, _vp, _u32]),
+    "bt_preprocessor_finish_sharded": (_i32, [_vp, _vp, _vp, _u32]),
     "bt_preprocessor_profile": (_i32, [_vp, _P(LaunchProfileC), _u32, _P(_u32)]),
     "bt_tiling_prepass_create": (_i32, [_vp, _u32, _P(_vp)]),
     "bt_tiling_prepass_destroy": (None, [_vp]),

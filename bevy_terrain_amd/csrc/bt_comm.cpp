@@ -85,6 +85,7 @@ struct bt_comm {
     Comm comm = nullptr;
     uint32_t world = 1, rank = 0;
     bool owned = false;
+    hipStream_t stream = nullptr;  // BT_RUN_SHARD_OVERLAP: the collectives' own queue (created on first use)
 };
 
 extern "C" {
@@ -132,6 +133,10 @@ bt_status bt_comm_adopt(bt_ctx* ctx, void* nccl_comm, uint32_t world, uint32_t r
 
 void bt_comm_destroy(bt_comm* comm) {
     if (!comm) return;
+    if (comm->stream) {
+        hipStreamSynchronize(comm->stream);
+        hipStreamDestroy(comm->stream);
+    }
     if (comm->owned && comm->comm && rccl().ok) rccl().CommDestroy(comm->comm);
     delete comm;
 }
@@ -181,19 +186,86 @@ bt_status bt_preprocessor_shard_pieces(const bt_preprocessor* p, bt_shard_piece*
     return BT_OK;
 }
 
-bt_status bt_preprocessor_run_sharded(bt_preprocessor* p, bt_atlas* a, bt_comm* comm, uint32_t flags) {
-    if (!p || !a || !comm) return BT_ERR_INVALID_ARGUMENT;
+}  // extern "C"
+
+namespace {
+// the exchange of one step as ONE grouped collective on `stream`: an in-place all-gather per LOD for the regular (planar)
+// layout, an in-place broadcast per piece otherwise
+bt_status grouped_exchange(bt_preprocessor* p, bt_atlas* a, bt_comm* comm, hipStream_t stream, bool distributed) {
+    const Rccl& R = rccl();
+    // BT_RUN_SHARD_DISTRIBUTED: the finest LOD of every attachment stays where it was computed
+    auto stays = [&](uint32_t attachment, uint32_t lod) { return distributed && lod == shard_finest_lod(p, attachment); };
+    BT_NCCL(R.GroupStart());
+    int rc = 0;
+    if (!p->shard_ranges.empty()) {
+        for (const bt_shard_range& r : p->shard_ranges) {
+            if (stays(r.attachment_index, r.lod)) continue;
+            const Attachment& at = a->attachments[r.attachment_index];
+            uint8_t* base = (uint8_t*)at.level0 + at.tile_bytes * r.first_layer;
+            const size_t count = size_t(at.tile_bytes) * r.layers_per_rank;
+            if (!rc) rc = R.AllGather(base + count * comm->rank, base, count, kNcclUint8, comm->comm, stream);
+        }
+    } else {
+        for (const bt_shard_piece& piece : p->shard_pieces) {
+            if (stays(piece.attachment_index, piece.lod)) continue;
+            const Attachment& at = a->attachments[piece.attachment_index];
+            uint8_t* buf = (uint8_t*)at.level0 + at.tile_bytes * piece.first_layer;
+            if (!rc) rc = R.Broadcast(buf, buf, size_t(at.tile_bytes) * piece.layers, kNcclUint8, int(piece.owner_rank), comm->comm, stream);
+        }
+    }
+    const int end = R.GroupEnd();
+    if (rc) return nccl_fail(rc, "grouped collective");
+    if (end) return nccl_fail(end, "ncclGroupEnd");
+    return BT_OK;
+}
+
+bt_status check_comm(const bt_preprocessor* p, const bt_comm* comm) {
     if (comm->ctx != p->ctx || comm->world != p->shard_world || comm->rank != p->shard_rank) {
         set_error("communicator (rank %u of %u) does not match set_shard(%u, %u) / the preprocessor's context", comm->rank, comm->world, p->shard_rank,
                   p->shard_world);
         return BT_ERR_INVALID_ARGUMENT;
     }
+    return BT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+bt_status bt_preprocessor_run_sharded(bt_preprocessor* p, bt_atlas* a, bt_comm* comm, uint32_t flags) {
+    if (!p || !a || !comm) return BT_ERR_INVALID_ARGUMENT;
+    if (bt_status s = check_comm(p, comm)) return s;
     const uint32_t pass = flags & (BT_RUN_GENERIC | BT_RUN_PROFILE);
     const bool local_only = (flags & BT_RUN_SHARD_LOCAL) && !(flags & BT_RUN_SHARD_FINISH);
     const bool exchange_only = (flags & BT_RUN_SHARD_EXCHANGE) != 0;  // timing: the grouped collective of the compiled plan alone
+    const bool overlap = (flags & BT_RUN_SHARD_OVERLAP) != 0;
     if (exchange_only && (local_only || comm->world == 1 || (p->shard_ranges.empty() && p->shard_pieces.empty()))) {
         set_error("BT_RUN_SHARD_EXCHANGE needs a sharded queue that has run once (and no BT_RUN_SHARD_LOCAL)");
         return BT_ERR_INVALID_ARGUMENT;
+    }
+    if (overlap) {
+        // The local phase on the context's stream, the collective behind it on the communicator's own stream, nothing else:
+        // the caller goes on with ANOTHER job's local phase (a second atlas) and comes back with bt_preprocessor_finish_sharded.
+        if (exchange_only || local_only || !(flags & BT_RUN_KEEP_QUEUE)) {
+            set_error("BT_RUN_SHARD_OVERLAP: a whole step of a kept queue (BT_RUN_KEEP_QUEUE, neither BT_RUN_SHARD_LOCAL nor BT_RUN_SHARD_EXCHANGE)");
+            return BT_ERR_INVALID_ARGUMENT;
+        }
+        if (p->shard_exchange_pending) {
+            set_error("BT_RUN_SHARD_OVERLAP: the previous step of this preprocessor has not been finished (bt_preprocessor_finish_sharded)");
+            return BT_ERR_INVALID_ARGUMENT;
+        }
+        BT_HIP(hipSetDevice(p->ctx->device));
+        if (!comm->stream) BT_HIP(hipStreamCreateWithFlags(&comm->stream, hipStreamNonBlocking));
+        if (!p->shard_local_done) BT_HIP(hipEventCreateWithFlags(&p->shard_local_done, hipEventDisableTiming));
+        if (!p->shard_exchange_done) BT_HIP(hipEventCreateWithFlags(&p->shard_exchange_done, hipEventDisableTiming));
+        const uint32_t local_flags = comm->world == 1 ? 0u : BT_RUN_SHARD_LOCAL;  // (a world of one: the whole plan is "local")
+        if (bt_status s = bt_preprocessor_run(p, a, pass | BT_RUN_KEEP_QUEUE | local_flags | (flags & BT_RUN_SHARD_DISTRIBUTED))) return s;
+        BT_HIP(hipEventRecord(p->shard_local_done, p->ctx->stream));
+        BT_HIP(hipStreamWaitEvent(comm->stream, p->shard_local_done, 0));
+        if (comm->world > 1)
+            if (bt_status s = grouped_exchange(p, a, comm, comm->stream, (flags & BT_RUN_SHARD_DISTRIBUTED) != 0)) return s;
+        BT_HIP(hipEventRecord(p->shard_exchange_done, comm->stream));
+        p->shard_exchange_pending = true;
+        return BT_OK;
     }
     if (comm->world == 1) {
         // a world of one: nothing to exchange; the sharded entry point still runs both halves
@@ -202,36 +274,30 @@ bt_status bt_preprocessor_run_sharded(bt_preprocessor* p, bt_atlas* a, bt_comm* 
         if (!exchange_only)
             if (bt_status s = bt_preprocessor_run(p, a, pass | BT_RUN_KEEP_QUEUE | BT_RUN_SHARD_LOCAL | (flags & BT_RUN_SHARD_DISTRIBUTED))) return s;
         if (!local_only) {
-            hipStream_t stream = p->ctx->stream;
-            const Rccl& R = rccl();
-            // BT_RUN_SHARD_DISTRIBUTED: the finest LOD of every attachment stays where it was computed
-            const bool distributed = (flags & BT_RUN_SHARD_DISTRIBUTED) != 0;
-            auto stays = [&](uint32_t attachment, uint32_t lod) { return distributed && lod == shard_finest_lod(p, attachment); };
-            BT_NCCL(R.GroupStart());
-            int rc = 0;
-            if (!p->shard_ranges.empty()) {  // regular layout: one in-place all-gather per LOD
-                for (const bt_shard_range& r : p->shard_ranges) {
-                    if (stays(r.attachment_index, r.lod)) continue;
-                    const Attachment& at = a->attachments[r.attachment_index];
-                    uint8_t* base = (uint8_t*)at.level0 + at.tile_bytes * r.first_layer;
-                    const size_t count = size_t(at.tile_bytes) * r.layers_per_rank;
-                    if (!rc) rc = R.AllGather(base + count * comm->rank, base, count, kNcclUint8, comm->comm, stream);
-                }
-            } else {
-                for (const bt_shard_piece& piece : p->shard_pieces) {
-                    if (stays(piece.attachment_index, piece.lod)) continue;
-                    const Attachment& at = a->attachments[piece.attachment_index];
-                    uint8_t* buf = (uint8_t*)at.level0 + at.tile_bytes * piece.first_layer;
-                    if (!rc) rc = R.Broadcast(buf, buf, size_t(at.tile_bytes) * piece.layers, kNcclUint8, int(piece.owner_rank), comm->comm, stream);
-                }
-            }
-            const int end = R.GroupEnd();
-            if (rc) return nccl_fail(rc, "grouped collective");
-            if (end) return nccl_fail(end, "ncclGroupEnd");
+            if (bt_status s = grouped_exchange(p, a, comm, p->ctx->stream, (flags & BT_RUN_SHARD_DISTRIBUTED) != 0)) return s;
             if (!exchange_only)
                 if (bt_status s = bt_preprocessor_run(p, a, (flags & (BT_RUN_GENERIC | BT_RUN_SHARD_DISTRIBUTED)) | BT_RUN_KEEP_QUEUE | BT_RUN_SHARD_FINISH)) return s;
         }
     }
+    if (!(flags & BT_RUN_KEEP_QUEUE)) return release_queue(p);
+    return BT_OK;
+}
+
+// The second half of a BT_RUN_SHARD_OVERLAP step: the context's stream waits for the job's collective, then the finishing
+// kernels (cross-strip aprons, the top LODs, cube seams) run.  Between the two calls the context's stream is free for the local
+// phase of other jobs — that is the overlap: per step max(kernels, collective) instead of their sum.
+bt_status bt_preprocessor_finish_sharded(bt_preprocessor* p, bt_atlas* a, bt_comm* comm, uint32_t flags) {
+    if (!p || !a || !comm) return BT_ERR_INVALID_ARGUMENT;
+    if (bt_status s = check_comm(p, comm)) return s;
+    if (!p->shard_exchange_pending) {
+        set_error("bt_preprocessor_finish_sharded: no BT_RUN_SHARD_OVERLAP step is pending");
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    BT_HIP(hipSetDevice(p->ctx->device));
+    BT_HIP(hipStreamWaitEvent(p->ctx->stream, p->shard_exchange_done, 0));
+    p->shard_exchange_pending = false;
+    if (comm->world > 1)
+        if (bt_status s = bt_preprocessor_run(p, a, (flags & (BT_RUN_GENERIC | BT_RUN_SHARD_DISTRIBUTED | BT_RUN_PROFILE)) | BT_RUN_KEEP_QUEUE | BT_RUN_SHARD_FINISH)) return s;
     if (!(flags & BT_RUN_KEEP_QUEUE)) return release_queue(p);
     return BT_OK;
 }

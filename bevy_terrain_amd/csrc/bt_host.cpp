@@ -1119,6 +1119,8 @@ void bt_preprocessor_destroy(bt_preprocessor* p) {
     fused_release(p);
     for (hipEvent_t e : p->events) hipEventDestroy(e);
     for (hipEvent_t e : p->event_pool) hipEventDestroy(e);
+    if (p->shard_local_done) hipEventDestroy(p->shard_local_done);
+    if (p->shard_exchange_done) hipEventDestroy(p->shard_exchange_done);
     if (p->tasks_dev) hipFree(p->tasks_dev);
     if (p->rasters_dev) hipFree(p->rasters_dev);
     delete p;

@@ -223,6 +223,9 @@ struct bt_preprocessor {
     bool shard_distributed = false;  // the last sharded run kept the finest LOD on its owners (BT_RUN_SHARD_DISTRIBUTED)
     std::vector<bt_shard_range> shard_ranges;
     std::vector<bt_shard_piece> shard_pieces;
+    // BT_RUN_SHARD_OVERLAP: the job's collective runs on the communicator's stream between these two events
+    hipEvent_t shard_local_done = nullptr, shard_exchange_done = nullptr;
+    bool shard_exchange_pending = false;  // bt_preprocessor_finish_sharded has to follow
     // compiled plan (rebuilt when the queue changes)
     bool compiled = false;
     bool saves_recorded = false;  // the kept queue's Save tasks are already in the atlas's to_save list

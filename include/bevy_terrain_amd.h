@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-/* 4 (round 4): + bt_frame_update / bt_frame_info; the fused plan no longer has a fused_todo launch (kind 6 of bt_launch_profile
+/* 4 (round 4): + bt_frame_update / bt_frame_info, BT_RUN_SHARD_OVERLAP + bt_preprocessor_finish_sharded; the fused plan no longer has a fused_todo launch (kind 6 of bt_launch_profile
  * does not occur any more) — additions only.
  * 3 (round 3): + bt_preprocessor_run_streamed, BT_RASTER_HOST_DEFERRED, BT_RUN_SHARD_EXCHANGE, bt_tiling_prepass_run_plain /
  * _run_unordered / _set_window, launch kind 6 (fused todo) in bt_launch_profile — additions only, every version-2 call keeps its
@@ -274,6 +274,11 @@ enum {
                                     * than one side (cube seams read neighbour tiles of the finest LOD): BT_ERR_UNSUPPORTED. */
     BT_RUN_SHARD_EXCHANGE = 64,    /* bt_preprocessor_run_sharded only: issue just the grouped collective of the compiled plan
                                     * (no kernels) — lets a benchmark time the exchange alone */
+    BT_RUN_SHARD_OVERLAP = 128,    /* bt_preprocessor_run_sharded only (with BT_RUN_KEEP_QUEUE): the local phase on the context's
+                                    * stream, the grouped collective behind it on the communicator's OWN stream, and return — the
+                                    * finishing kernels come with bt_preprocessor_finish_sharded.  In between the caller runs the
+                                    * local phase of another job (its own preprocessor + atlas): the collective of step k hides
+                                    * behind the kernels of step k + 1 */
 };
 /* Replaces select_ready_tasks + GpuPreprocessor::prepare + TerrainPreprocessNode::run for the whole
  * queue: enqueues every kernel on the context's stream and returns (asynchronous).  Save tasks are
@@ -347,6 +352,9 @@ bt_status bt_comm_check(bt_comm* comm);
  * (BT_RUN_SHARD_FINISH).  `flags`: BT_RUN_GENERIC / BT_RUN_KEEP_QUEUE / BT_RUN_PROFILE, and BT_RUN_SHARD_LOCAL alone to
  * skip the collective and the finish (kernel-only timing).  set_shard(rank, world) must match the communicator. */
 bt_status bt_preprocessor_run_sharded(bt_preprocessor* p, bt_atlas* atlas, bt_comm* comm, uint32_t flags);
+/* Second half of a BT_RUN_SHARD_OVERLAP step: the context's stream waits for that step's collective, then the finishing kernels
+ * run.  flags: BT_RUN_GENERIC / BT_RUN_SHARD_DISTRIBUTED as in the first half, BT_RUN_PROFILE, BT_RUN_KEEP_QUEUE. */
+bt_status bt_preprocessor_finish_sharded(bt_preprocessor* p, bt_atlas* atlas, bt_comm* comm, uint32_t flags);
 
 /* Per-launch device time of the runs made with BT_RUN_PROFILE since the last call (hipEvents on the
  * context's stream, averaged over those runs).  `kind`: 0 split, 1 downsample, 2 stitch, 3 fused main,

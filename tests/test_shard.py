@@ -581,3 +581,142 @@ def test_rgba8_job_at_tile_size_512_sharded_over_emulated_ranks(world):
     pieces = _emulate_ranks(device, world, make_job, 1365, oracle, lods - 1, T, b)
     assert len({p["owner_rank"] for p in pieces}) == world
     device.free(ptr)
+
+
+class _LocalGroup:
+    """An in-process stand-in for torch.distributed over EMULATED ranks (one process, one GPU): a rank's collective calls are
+    recorded; `run()` then moves the bytes between the ranks' atlases the way the collectives do (in-place all-gather: every
+    rank's slice to every rank; broadcast: the owner's piece to every rank)."""
+
+    def __init__(self, world):
+        self.world, self.ops = world, {r: [] for r in range(world)}
+
+    def for_rank(self, rank):
+        group = self
+
+        class Dist:
+            def all_gather_into_tensor(self, whole, mine, group_=None, group=None):
+                self_ops.append(("gather", whole, mine))
+
+            def broadcast(self, tensor, src, group=None):
+                self_ops.append(("broadcast", tensor, src))
+
+        self_ops = group.ops[rank]
+        return Dist()
+
+    def run(self):
+        import torch
+
+        torch.cuda.synchronize()
+        n = len(self.ops[0])
+        assert all(len(v) == n for v in self.ops.values())
+        for i in range(n):
+            kind = self.ops[0][i][0]
+            if kind == "gather":
+                count = self.ops[0][i][2].numel()
+                slices = [self.ops[r][i][2].clone() for r in range(self.world)]  # (in place: a rank's slice aliases its `whole`)
+                for dst in range(self.world):
+                    for src in range(self.world):
+                        self.ops[dst][i][1][src * count:(src + 1) * count].copy_(slices[src])
+            else:
+                src = self.ops[0][i][2]
+                data = self.ops[src][i][1].clone()
+                for dst in range(self.world):
+                    self.ops[dst][i][1].copy_(data)
+        torch.cuda.synchronize()
+        for v in self.ops.values():
+            v.clear()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,cube", [(2, False), (4, False), (8, False), (4, True)])
+def test_overlapped_steps_over_emulated_ranks(world, cube):
+    """The overlapped step (begin_step: local kernels + the exchange on its own queue; finish_step: the finishing kernels behind
+    it, one step late; TWO atlases per rank that alternate) over emulated ranks: after four steps and the flush BOTH atlases of
+    EVERY rank equal the oracle's.  The ranks' collectives are the in-process stand-in above; the real ones run in
+    test_bench_two_ranks_end_to_end_on_one_gpu."""
+    import bevy_terrain_amd as bt
+    from bevy_terrain_amd.shard import ShardedPreprocess
+
+    device = bt.Device(0)
+    T, b = (32, 2) if cube else (64, 2)
+    lods = 4 if cube else 6
+    if cube:
+        faces = [K.random_raster(O.FORMAT_R16, 230, 230, seed=60 + s, holes=0.003) for s in range(6)]
+        paths = [f"face{s}" for s in range(6)]
+        oracle = O.OracleAtlas(lods, 1024, True, [(T, b, 1, O.FORMAT_R16)])
+        oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(O.usable_cores())
+        n_tiles = 6 * 85
+    else:
+        src = K.random_raster(O.FORMAT_R16, 1100, 1100, seed=37, holes=0.01)
+        oracle = K.oracle_planar(src, lods, T, b, O.FORMAT_R16, atlas_size=2048)
+        n_tiles = 1365
+    group = _LocalGroup(world)
+    jobs = []  # [rank][slot]
+    for rank in range(world):
+        pair = []
+        for _ in range(2):
+            if cube:
+                cfg = bt.TerrainConfig(lod_count=lods, atlas_size=1024, path="terrains/spherical")
+                cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=T, border_size=b, format=bt.AttachmentFormat.R16))
+                server = bt.AssetServer()
+                for p, f in zip(paths, faces):
+                    server.insert(p, f)
+                path = paths
+            else:
+                cfg = bt.TerrainConfig(lod_count=lods, atlas_size=2048, path="t", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+                cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=T, border_size=b))
+                server, path = bt.AssetServer().insert("s", src), "s"
+            atlas = bt.TileAtlas.new(cfg, device)
+            pair.append(ShardedPreprocess(bt.Preprocessor.new().clear_attachment(0, atlas), atlas, server, path, range(0, lods), rank, world,
+                                          collective="torch", dist=group.for_rank(rank)))
+        jobs.append(pair)
+    for k in range(4):
+        cur, prev = k & 1, (k + 1) & 1
+        for rank in range(world):
+            jobs[rank][cur].begin_step()
+        group.run()  # step k's exchange ...
+        for rank in range(world):  # ... and, behind it on the compute streams, step k - 1's finishing kernels
+            if jobs[rank][prev].pending:
+                jobs[rank][prev].finish_step()
+    for rank in range(world):
+        for j in jobs[rank]:
+            if j.pending:
+                j.finish_step()
+    device.synchronize()
+    for rank in range(world):
+        for j in jobs[rank]:
+            assert K.assert_atlas_equal(j.atlas, oracle) == n_tiles, rank
+
+
+@pytest.mark.gpu
+def test_library_overlapped_step_single_rank():
+    """BT_RUN_SHARD_OVERLAP + bt_preprocessor_finish_sharded through the library's own communicator and its collectives' stream:
+    a world of one rank (all a 1-GPU box can form), two atlases alternating under OverlappedSharded."""
+    import bevy_terrain_amd as bt
+    from bevy_terrain_amd.shard import OverlappedSharded, ShardedPreprocess
+
+    device = bt.Device(0)
+    src = K.random_raster(O.FORMAT_R16, 1100, 1100, seed=38)
+    oracle = K.oracle_planar(src, 4, 128, 2, O.FORMAT_R16, atlas_size=128)
+
+    def make(comm=None):
+        cfg = bt.TerrainConfig(lod_count=4, atlas_size=128, path="t", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+        cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=128, border_size=2))
+        atlas = bt.TileAtlas.new(cfg, device)
+        return ShardedPreprocess(bt.Preprocessor.new(), atlas, bt.AssetServer().insert("s", src), "s", range(0, 4), 0, 1, collective="library", comm=comm)
+
+    a = make()
+    b = make(comm=a._comm)
+    pair = OverlappedSharded(a, b)
+    for k in range(5):
+        pair.step(profile=k == 3)
+    with pytest.raises(bt._ffi.BtError):  # a pending step must be finished before the same preprocessor starts another
+        pending = a if a.pending else b
+        bt._ffi.check(bt._ffi.lib().bt_preprocessor_run_sharded(pending.pre._h, pending.atlas._h, pending._comm, pending.flags | bt._ffi.RUN_SHARD_OVERLAP))
+    pair.flush()
+    device.synchronize()
+    for j in (a, b):
+        assert K.assert_atlas_equal(j.atlas, oracle) == 85
+    b.close()
+    a.close()
