@@ -330,7 +330,11 @@ def main():
                                model=bt.TerrainModel.sphere((0.0, 0.0, 0.0), 6371000.0, -12000.0, 9000.0))
     else:
         size, lod_count, paths = SIZE, LOD_COUNT, "synthetic/fbm16k"
-        src_ptr = device.synth_fbm_r16(SIZE, SIZE, SEED)
+        if world > 1:  # a rank generates only the window of the source its own launches read (below, once the plan is known)
+            src_zero = torch.zeros(SIZE * SIZE * 2, dtype=torch.uint8, device="cuda")
+            src_ptr = src_zero.data_ptr()
+        else:
+            src_ptr = device.synth_fbm_r16(SIZE, SIZE, SEED)
         cfg = bt.TerrainConfig(lod_count=LOD_COUNT, atlas_size=ATLAS_SIZE, path="terrains/bench16k",
                                model=bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 1.0))
     cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=TEXTURE_SIZE, border_size=BORDER,
@@ -368,6 +372,15 @@ def main():
         else:
             pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path=paths, lod_range=range(0, lod_count)), server, atlas)
         job = None
+    source_window = None
+    if world > 1 and not cube:
+        # a rank holds its strip of the source + halo.  The plan names the window (bt_preprocessor_source_window);
+        # only that part of the synthetic raster is generated on this rank, the rest of the buffer stays zero (= no data: a
+        # launch that strayed outside would show in --verify)
+        (wx0, wy0, wx1, wy1), _ = job.pre.source_window(atlas, 0, generic=args.generic)
+        device.synth_fbm_r16(wx1 - wx0, wy1 - wy0, SEED, x0=wx0, y0=wy0, base_cell=SIZE // 4, dst=src_ptr + (wy0 * SIZE + wx0) * 2, pitch=SIZE * 2)
+        device.synchronize()
+        source_window = {"x0": wx0, "y0": wy0, "x1": wx1, "y1": wy1, "bytes": (wx1 - wx0) * (wy1 - wy0) * 2, "of_bytes": SIZE * SIZE * 2}
 
     # N = 1: independent jobs in flight — `depth` contexts (a HIP stream each) with their own atlas, the same queue for
     # each, the source shared in HBM; steps are issued round-robin, so the short serial tail of one job and the drain of
@@ -457,6 +470,8 @@ def main():
 
     compute_only_ms = exchange_only_ms = None
     other_result = None
+    overlapped = None       # N > 1 extra: {"ms_per_step", "tiles_per_s"} of the overlapped pair (two atlases per rank)
+    overlap_atlases = []    # ... and its atlases, for --verify
 
     # N = 1 extra: two independent jobs in flight (two contexts / streams, an atlas each): the tail, the todo launch and the
     # drain of one job's main kernel run beside the main kernel of the next
@@ -518,7 +533,7 @@ def main():
                    "ms_per_step_one_stream": one_stream_ms if depth > 1 else ms_per_step,
                    "ms_per_step_two_in_flight": two_in_flight_ms,  # N = 1 extra pass: two contexts (streams + atlases), steps round-robin
                    "tiles_per_s_two_in_flight": (tiles / (two_in_flight_ms / 1e3)) if two_in_flight_ms else None,
-                   "kernels_per_step": stats["kernel_launches"],  # fused_main, fused_todo, fused_tail: what rocprofv3 --stats counts
+                   "kernels_per_step": stats["kernel_launches"],  # fused_main, fused_tail: what rocprofv3 --stats counts
                    "algorithmic_bytes_per_step": stats["algorithmic_bytes"],
                    "whole_step_GBps": stats["algorithmic_bytes"] / (ms_per_step / 1e3) / 1e9,
                    "host_wall_ms_per_step": wall_ms / args.steps,
@@ -526,6 +541,7 @@ def main():
                    "collective_only_ms_per_step": exchange_only_ms,  # N > 1: the grouped collective alone
                    "other_result_mode": other_result,  # N > 1: the same job with the other --result, timed in the same run
                    "all_gather_bytes_per_rank": (job.gather_bytes if job is not None else 0),
+                   "source_window_rank0": source_window,  # N > 1: the part of the source rank 0 generated (its strips + halo); the rest stays zero
                    "result": (None if job is None else
                               "replicated: every rank ends with the full atlas" if job.held is None else
                               "distributed: the finest LOD stays on the rank that computed it (complete there), the two parent "
@@ -575,6 +591,32 @@ def main():
                                     "all_gather_bytes_per_rank": job2.gather_bytes}
                 if job2 is not None:
                     job2.close()
+            # the same result mode with the exchange of step k hidden behind the kernels of step k + 1: a second atlas +
+            # preprocessor of this rank, the same communicator, collectives on its own queue (bevy_terrain_amd.shard.OverlappedSharded)
+            from bevy_terrain_amd.shard import OverlappedSharded
+
+            ok, job_b = 1, None
+            try:
+                atlas_b = bt.TileAtlas.new(cfg, device)
+                pre_b = bt.Preprocessor.new().clear_attachment(0, atlas_b)
+                job_b = ShardedPreprocess(pre_b, atlas_b, server, paths, range(0, lod_count), rank, world, generic=args.generic, collective=collective,
+                                          result=result, comm=job._comm)
+            except Exception as e:
+                print(f"[rank {rank}] overlapped pass unavailable: {e!r}", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                pair = OverlappedSharded(job, job_b)
+                for _ in range(4):
+                    pair.step()
+                t_pair = timed_pass(lambda i: pair.step())
+                pair.flush()
+                fence()
+                overlapped = {"ms_per_step": t_pair, "tiles_per_s": tiles / (t_pair / 1e3), "atlases_per_rank": 2,
+                              "note": "step k's grouped collective on the communicator's own stream while step k + 1's local kernels run; "
+                                      "the finishing kernels of a step follow its collective one step late"}
+                overlap_atlases.append(atlas_b)
         except Exception as e:  # (an exception every rank raises at the same point, e.g. an unsupported flag)
             line["config"]["extras_error"] = repr(e)
         finally:
@@ -582,6 +624,7 @@ def main():
         line["config"]["kernels_only_ms_per_step"] = compute_only_ms
         line["config"]["collective_only_ms_per_step"] = exchange_only_ms
         line["config"]["other_result_mode"] = other_result
+        line["config"][f"{result}_overlapped"] = overlapped
     if dominant:
         achieved = dominant["algorithmic_bytes"] / (dominant["avg_ms"] / 1e3) / 1e9
         # HBM bytes per launch from the PMC passes of the same command (rocprofv3 cannot run inside this
@@ -617,7 +660,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(device, src_ptr)  # reported at N = 1 only
     if rank == 0 and args.verify:
-        oracle, shape, line["verify_checker"] = oracle_atlas(device, src_ptr)
+        full_src = device.synth_fbm_r16(SIZE, SIZE, SEED) if source_window is not None else src_ptr  # the checker works from the whole raster
+        oracle, shape, line["verify_checker"] = oracle_atlas(device, full_src)
+        if full_src != src_ptr:
+            device.free(full_src)
         held = None
         if job is not None and job.held is not None:  # distributed result: rank 0 holds its finest pieces + every lower LOD
             finest = max(c[1] for c, _ in oracle.tiles())
@@ -627,6 +673,8 @@ def main():
         line["verify_vs_oracle"] = verify_against(atlas, oracle, shape, held)
         for k, (_, a, _) in enumerate(lanes[1:], 1):  # every lane's atlas holds a complete, identical job
             line[f"verify_vs_oracle_lane{k}"] = verify_against(a, oracle, shape)
+        for a in overlap_atlases:  # the second atlas of the overlapped pair: the same job, finished one step late
+            line["verify_vs_oracle_overlapped_second_atlas"] = verify_against(a, oracle, shape, held)
     if world > 1:
         dist.barrier()  # the other ranks wait for rank 0's oracle run before tearing the group down
     if rank == 0 and world == 1:

@@ -209,6 +209,7 @@ PROTOTYPES = {
     "bt_comm_check": (_i32, [_vp]),
     "bt_preprocessor_run_sharded": (_i32, [_vp, _vp, _vp, _u32]),
     "bt_preprocessor_finish_sharded": (_i32, [_vp, _vp, _vp, _u32]),
+    "bt_preprocessor_source_window": (_i32, [_vp, _vp, _u32, _u32, _P(C.c_uint32), _P(C.c_uint64)]),
     "bt_preprocessor_profile": (_i32, [_vp, _P(LaunchProfileC), _u32, _P(_u32)]),
     "bt_tiling_prepass_create": (_i32, [_vp, _u32, _P(_vp)]),
     "bt_tiling_prepass_destroy": (None, [_vp]),

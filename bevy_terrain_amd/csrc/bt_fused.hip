@@ -2263,6 +2263,49 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) { retur
 
 // Bands of whole tile rows of a fused main launch, with the last source row each band's kernels read (the bottom apron rows
 // of its last tile row are evaluated with the next tile row's formula: same f32 operations as the kernel's row tables).
+// The source texels [x0, x1) x [y0, y1) of raster `raster` that the fused main launches of the compiled plan read — for a sharded
+// preprocessor: this rank's column strips + their halo (finest aprons are evaluated from the source, staged windows start on an
+// 8-texel boundary and are lds_pitch wide).  Conservative (a missing neighbour tile only shrinks what the kernel reads).
+// false: no fused main launch reads this raster (or the plan is not fused): the caller assumes the whole raster.
+bool fused_source_window(const bt_preprocessor* p, uint32_t raster, uint32_t out[4]) {
+    if (!p->fused || raster >= p->rasters.size()) return false;
+    const RasterDev& r = p->rasters[raster].dev;
+    uint32_t x0 = r.width, y0 = r.height, x1 = 0, y1 = 0;
+    bool any = false, known = false;
+    for (const FusedJobDev& job : p->fused->jobs) {
+        if (job.host_items.empty()) continue;
+        known = true;
+        const FusedArgs& A = job.args;
+        const uint32_t c = A.m.center_size, b = A.m.border_size, n = 1u << A.lod;
+        const float scale = float(n);
+        auto ax = [&](uint32_t tile, uint32_t col) { return split_axis(col, c, tile, scale, A.tlx, A.brx, r.width); };
+        auto ay = [&](uint32_t tile, uint32_t row) { return split_axis(row, c, tile, scale, job.tly, job.bry, r.height); };
+        for (const MainItem& it : job.host_items) {
+            if (it.raster != raster) continue;
+            any = true;
+            const int lo_x = std::min(it.x > 0 ? ax(it.x - 1, c - b).i0 : ax(it.x, 0).i0, ax(it.x, 0).i0);
+            const int hi_x = std::max(it.x + 1 < n ? ax(it.x + 1, b - 1).i1 : ax(it.x, c - 1).i1, ax(it.x, c - 1).i1);
+            const int lo_y = std::min(it.y > 0 ? ay(it.y - 1, c - b).i0 : ay(it.y, 0).i0, ay(it.y, 0).i0);
+            const int hi_y = std::max(it.y + 1 < n ? ay(it.y + 1, b - 1).i1 : ay(it.y, c - 1).i1, ay(it.y, c - 1).i1);
+            const uint32_t xa = uint32_t(std::max(lo_x, 0)) & ~7u;
+            uint32_t xe = uint32_t(hi_x) + 1u;
+            if (A.lds_rows) xe = std::max(xe, xa + A.lds_pitch);  // the staged window: lds_pitch texels from the aligned start
+            if (xe + 8u > r.width) xe = r.width;                   // (pieces past the row's end re-read its last 16 bytes)
+            x0 = std::min(x0, xa);
+            x1 = std::max(x1, std::min(xe, r.width));
+            y0 = std::min(y0, uint32_t(std::max(lo_y, 0)));
+            y1 = std::max(y1, std::min(uint32_t(hi_y) + 1u, r.height));
+        }
+    }
+    if (!known) return false;
+    if (!any) x0 = y0 = x1 = y1 = 0;  // a cube face none of this rank's units lie on
+    out[0] = x0;
+    out[1] = y0;
+    out[2] = x1;
+    out[3] = y1;
+    return true;
+}
+
 bool fused_stream_bands(bt_preprocessor* p, const Launch& l, uint32_t tile_rows_per_band, int32_t* raster, std::vector<StreamBand>* bands) {
     if (l.kind != kLaunchFusedMain || !p->fused || l.aux0 >= p->fused->jobs.size() || tile_rows_per_band == 0) return false;
     const FusedJobDev& job = p->fused->jobs[l.aux0];

@@ -1402,13 +1402,31 @@ bt_status bt_preprocessor_save(bt_preprocessor* p, bt_atlas* a, const char* asse
 }  // extern "C"
 
 namespace bt {
+bool fused_source_window(const bt_preprocessor* p, uint32_t raster, uint32_t out[4]);
+
+// Deferred host rasters travel when the queue runs.  A SHARDED preprocessor (compiled plan known) uploads only the texels its
+// own launches read — its column strips + halo (a rank never touches the rest of the source).
 bt_status upload_pending_rasters(bt_preprocessor* p) {
-    for (Raster& r : p->rasters)
-        if (r.pending) {
+    for (size_t i = 0; i < p->rasters.size(); i++) {
+        Raster& r = p->rasters[i];
+        if (!r.pending) continue;
+        uint32_t w[4];
+        const uint64_t px = r.format == BT_FORMAT_R16 ? 2 : 4;
+        if (p->shard_world > 1 && p->compiled && fused_source_window(p, uint32_t(i), w)) {
+            p->uploaded_source_bytes = 0;
+            if (w[2] > w[0] && w[3] > w[1]) {
+                const uint64_t off = uint64_t(w[1]) * r.dev.pitch + uint64_t(w[0]) * px;
+                BT_HIP(hipMemcpy2DAsync((uint8_t*)r.dev.data + off, r.dev.pitch, (const uint8_t*)r.host + off, r.dev.pitch, (w[2] - w[0]) * px, w[3] - w[1],
+                                        hipMemcpyHostToDevice, p->ctx->stream));
+                p->uploaded_source_bytes = uint64_t(w[2] - w[0]) * px * (w[3] - w[1]);
+            }
+        } else {
             BT_HIP(hipMemcpyAsync((void*)r.dev.data, r.host, r.host_bytes, hipMemcpyHostToDevice, p->ctx->stream));
-            BT_HIP(hipStreamSynchronize(p->ctx->stream));
-            r.pending = false;
+            p->uploaded_source_bytes = r.host_bytes;
         }
+        BT_HIP(hipStreamSynchronize(p->ctx->stream));
+        r.pending = false;
+    }
     return BT_OK;
 }
 }  // namespace bt

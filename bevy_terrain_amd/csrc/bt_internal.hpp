@@ -226,6 +226,7 @@ struct bt_preprocessor {
     // BT_RUN_SHARD_OVERLAP: the job's collective runs on the communicator's stream between these two events
     hipEvent_t shard_local_done = nullptr, shard_exchange_done = nullptr;
     bool shard_exchange_pending = false;  // bt_preprocessor_finish_sharded has to follow
+    uint64_t uploaded_source_bytes = 0;   // bytes of the last deferred host raster that actually travelled (a sharded run: its window)
     // compiled plan (rebuilt when the queue changes)
     bool compiled = false;
     bool saves_recorded = false;  // the kept queue's Save tasks are already in the atlas's to_save list

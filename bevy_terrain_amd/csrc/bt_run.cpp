@@ -179,8 +179,8 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
     }
     BT_HIP(hipSetDevice(p->ctx->device));
     const uint32_t mode = flags & BT_RUN_GENERIC;
-    if (bt_status s = upload_pending_rasters(p)) return s;  // rasters handed over with BT_RASTER_HOST_DEFERRED
     if (bt_status s = ensure_compiled(p, a, mode)) return s;
+    if (bt_status s = upload_pending_rasters(p)) return s;  // rasters handed over with BT_RASTER_HOST_DEFERRED (sharded: this rank's window of them)
 
     if ((flags & BT_RUN_PROFILE) != 0 && p->profiled_runs >= kMaxProfiledRuns) {
         set_error("BT_RUN_PROFILE: %u profiled runs are pending; read them with bt_preprocessor_profile() first", kMaxProfiledRuns);
@@ -285,6 +285,28 @@ extern "C" bt_status bt_preprocessor_profile(bt_preprocessor* p, bt_launch_profi
     p->event_pool.insert(p->event_pool.end(), p->events.begin(), p->events.end());
     p->events.clear();
     p->profiled_runs = 0;
+    return BT_OK;
+}
+
+namespace bt {
+bool fused_source_window(const bt_preprocessor* p, uint32_t raster, uint32_t out[4]);
+}
+
+// Which texels of source raster `raster_index` (the order of the preprocess_* calls; a cube job adds six) does this preprocessor
+// read?  Compiles the plan if necessary.  A sharded fused plan: this rank's column strips + halo; anything else: the whole raster.
+extern "C" bt_status bt_preprocessor_source_window(bt_preprocessor* p, bt_atlas* a, uint32_t raster_index, uint32_t flags, uint32_t window[4], uint64_t* uploaded_bytes) {
+    if (!p || !a || !window) return BT_ERR_INVALID_ARGUMENT;
+    if (raster_index >= p->rasters.size()) {
+        set_error("raster %u of %zu", raster_index, p->rasters.size());
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    if (bt_status s = ensure_compiled(p, a, flags & BT_RUN_GENERIC)) return s;
+    if (!fused_source_window(p, raster_index, window)) {
+        window[0] = window[1] = 0;
+        window[2] = p->rasters[raster_index].dev.width;
+        window[3] = p->rasters[raster_index].dev.height;
+    }
+    if (uploaded_bytes) *uploaded_bytes = p->uploaded_source_bytes;
     return BT_OK;
 }
 

@@ -156,15 +156,25 @@ class Preprocessor:
         _ffi.check(_ffi.lib().bt_preprocessor_preprocess_tile(self._handle(tile_atlas), tile_atlas._h, C.byref(d), C.byref(raster)))
         return self
 
-    def preprocess_spherical(self, dataset: SphericalDataset, asset_server: AssetServer, tile_atlas: TileAtlas) -> "Preprocessor":
+    def preprocess_spherical(self, dataset: SphericalDataset, asset_server: AssetServer, tile_atlas: TileAtlas, *,
+                             defer_upload: bool = False) -> "Preprocessor":
         fmt = tile_atlas.config.attachments[dataset.attachment_index].format
         def load(path):  # (duck-typed asset servers predate the `fmt` argument: same guard as preprocess_tile)
             return asset_server.load(path, fmt) if isinstance(asset_server, AssetServer) else asset_server.load(path)
 
-        rasters = (_ffi.RasterC * 6)(*[_raster_struct(load(p), fmt, self._keep) for p in dataset.paths])
+        rasters = (_ffi.RasterC * 6)(*[_raster_struct(load(p), fmt, self._keep, defer_upload) for p in dataset.paths])
         d = _ffi.SphericalDatasetC(dataset.attachment_index, dataset.lod_range.start, dataset.lod_range.stop)
         _ffi.check(_ffi.lib().bt_preprocessor_preprocess_spherical(self._handle(tile_atlas), tile_atlas._h, C.byref(d), rasters))
         return self
+
+    def source_window(self, tile_atlas: TileAtlas, raster_index: int = 0, *, generic: bool = False):
+        """((x0, y0, x1, y1), uploaded_bytes): the texels of source raster `raster_index` this preprocessor's launches read (a
+        sharded fused plan: this rank's column strips + halo; else the whole raster) and the bytes of the last deferred host
+        raster that actually travelled."""
+        w, n = (C.c_uint32 * 4)(), C.c_uint64()
+        _ffi.check(_ffi.lib().bt_preprocessor_source_window(self._handle(tile_atlas), tile_atlas._h, raster_index,
+                                                            _ffi.RUN_GENERIC if generic else 0, w, C.byref(n)))
+        return tuple(w), n.value
 
     def task_counts(self) -> Dict[str, int]:
         counts = (C.c_uint32 * 5)()

@@ -76,8 +76,10 @@ class ShardedPreprocess:
 
     def __init__(self, pre: Preprocessor, tile_atlas: TileAtlas, asset_server: AssetServer, path, lod_range: range,
                  rank: int, world: int, *, attachment_index: int = 0, generic: bool = False, collective: str = "torch",
-                 result: str = "replicated", comm=None, dist=None):
-        """result="replicated": every rank ends with the full atlas.  result="distributed" (planar jobs): the finest LOD is
+                 result: str = "replicated", comm=None, dist=None, defer_upload: bool = False):
+        """defer_upload: host rasters travel when the first step runs — and then only the window this rank's launches read (its
+        column strips + halo: Preprocessor.source_window).
+        result="replicated": every rank ends with the full atlas.  result="distributed" (planar jobs): the finest LOD is
         not exchanged — its tiles stay on the rank that computed them, only the two parent LODs travel (a quarter of the
         bytes); every rank still holds every lower LOD, and Preprocessor.save writes each rank's share."""
         import torch
@@ -95,10 +97,10 @@ class ShardedPreprocess:
         self.flags = (_ffi.RUN_GENERIC if generic else 0) | _ffi.RUN_KEEP_QUEUE | (_ffi.RUN_SHARD_DISTRIBUTED if result == "distributed" else 0)
         if isinstance(path, (list, tuple)):
             pre.preprocess_spherical(SphericalDataset(attachment_index=attachment_index, paths=list(path), lod_range=lod_range),
-                                     asset_server, tile_atlas)
+                                     asset_server, tile_atlas, defer_upload=defer_upload)
         else:
             pre.preprocess_tile(PreprocessDataset(attachment_index=attachment_index, path=path, lod_range=lod_range),
-                                asset_server, tile_atlas)
+                                asset_server, tile_atlas, defer_upload=defer_upload)
         _ffi.check(_ffi.lib().bt_preprocessor_set_shard(pre._handle(tile_atlas), rank, world))
         ptr, tile_bytes, layers = tile_atlas.attachment_storage(attachment_index)
         self.tile_bytes = tile_bytes

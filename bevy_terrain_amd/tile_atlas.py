@@ -65,11 +65,12 @@ class Device:
         _ffi.check(_ffi.lib().bt_memcpy_d2h(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes))
         return out
 
-    def synth_fbm_r16(self, width, height, seed, *, x0=0, y0=0, base_cell=None, octaves=6, dst: Optional[int] = None) -> int:
-        """Deterministic integer fBm heightmap in HBM; returns the device pointer (u16, tightly packed)."""
+    def synth_fbm_r16(self, width, height, seed, *, x0=0, y0=0, base_cell=None, octaves=6, dst: Optional[int] = None, pitch: Optional[int] = None) -> int:
+        """Deterministic integer fBm heightmap in HBM; returns the device pointer (u16, tightly packed).  With dst / pitch / x0 / y0
+        / base_cell it fills a WINDOW of a larger raster: texel (i, j) of the call is texel (x0 + i, y0 + j) of the pattern."""
         base_cell = base_cell or max(max(width, height) // 4, 1)
         ptr = dst if dst is not None else self.malloc(width * height * 2)
-        _ffi.check(_ffi.lib().bt_synth_fbm_r16(self._h, C.c_void_p(ptr), width, height, width * 2, x0, y0, base_cell,
+        _ffi.check(_ffi.lib().bt_synth_fbm_r16(self._h, C.c_void_p(ptr), width, height, pitch or width * 2, x0, y0, base_cell,
                                                octaves, seed & 0xFFFFFFFF))
         return ptr
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-/* 4 (round 4): + bt_frame_update / bt_frame_info, BT_RUN_SHARD_OVERLAP + bt_preprocessor_finish_sharded; the fused plan no longer has a fused_todo launch (kind 6 of bt_launch_profile
+/* 4 (round 4): + bt_frame_update / bt_frame_info, BT_RUN_SHARD_OVERLAP + bt_preprocessor_finish_sharded, bt_preprocessor_source_window; the fused plan no longer has a fused_todo launch (kind 6 of bt_launch_profile
  * does not occur any more) — additions only.
  * 3 (round 3): + bt_preprocessor_run_streamed, BT_RASTER_HOST_DEFERRED, BT_RUN_SHARD_EXCHANGE, bt_tiling_prepass_run_plain /
  * _run_unordered / _set_window, launch kind 6 (fused todo) in bt_launch_profile — additions only, every version-2 call keeps its
@@ -322,6 +322,14 @@ typedef struct bt_shard_range {
 bt_status bt_preprocessor_set_shard(bt_preprocessor* p, uint32_t rank, uint32_t world);
 /* valid after the first run of the current queue; *count = 0 means "not sharded: every rank computed everything"
  * (or: sharded, but not the regular one-side layout — see bt_preprocessor_shard_pieces) */
+/* The window [x0, x1) x [y0, y1) (window = {x0, y0, x1, y1}) of source raster `raster_index` (rasters in the order of the
+ * preprocess_* calls; preprocess_spherical adds six) that this preprocessor's launches read; compiles the plan if necessary
+ * (flags: BT_RUN_GENERIC).  For a sharded preprocessor with a fused plan that is this rank's column strips + halo — a rank needs
+ * no other texel of the source: a BT_RASTER_HOST_DEFERRED raster is uploaded window-only by bt_preprocessor_run, and a caller
+ * that fills a device raster itself fills only this (bench.py --gpus N generates only the window).  Otherwise the whole raster.
+ * uploaded_bytes (may be NULL): the bytes of the last deferred raster that actually travelled. */
+bt_status bt_preprocessor_source_window(bt_preprocessor* p, bt_atlas* atlas, uint32_t raster_index, uint32_t flags, uint32_t window[4],
+                                        uint64_t* uploaded_bytes);
 bt_status bt_preprocessor_shard_ranges(const bt_preprocessor* p, bt_shard_range* out, uint32_t cap, uint32_t* count);
 /* The general form of the exchange (planar AND cube jobs): ownership goes by UNITS — one column strip of one cube side
  * at the granularity of the coarsest LOD the main kernel produces, numbered side-major, `units / world` consecutive

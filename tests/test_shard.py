@@ -199,6 +199,10 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(result, held_tiles):
     assert cfg["kernels_only_ms_per_step"] > 0 and cfg["collective_only_ms_per_step"] > 0
     other = cfg["other_result_mode"]
     assert other["result"] == ("distributed" if result == "replicated" else "replicated") and other["ms_per_step"] > 0
+    # ... and the overlapped pair (two atlases per rank, the exchange of a step behind the kernels of the next): timed, and the
+    # second atlas verified like the first
+    assert cfg[f"{result}_overlapped"]["ms_per_step"] > 0 and cfg[f"{result}_overlapped"]["atlases_per_rank"] == 2
+    assert line["verify_vs_oracle_overlapped_second_atlas"] == {"tiles": held_tiles, "identical": held_tiles, "index_contract": True}
     full, quarter = 1024 * 524288 + 256 * 524288 + 64 * 524288, 256 * 524288 + 64 * 524288
     assert cfg["all_gather_bytes_per_rank"] == (full if result == "replicated" else quarter)
     assert other["all_gather_bytes_per_rank"] == (quarter if result == "replicated" else full)
@@ -720,3 +724,86 @@ def test_library_overlapped_step_single_rank():
         assert K.assert_atlas_equal(j.atlas, oracle) == 85
     b.close()
     a.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,cube", [(2, False), (8, False), (4, True)])
+def test_a_rank_reads_only_its_window_of_the_source(world, cube):
+    """a rank needs its column strips of the source + the halo, nothing else.  Every emulated rank gets a host raster
+    that is GARBAGE (zeros = no data) outside the window bt_preprocessor_source_window reports and hands it over deferred: the
+    library uploads only the window (bytes asserted), and the rank's pieces must still come out as the oracle computes them
+    from the intact raster."""
+    import bevy_terrain_amd as bt
+    from bevy_terrain_amd import _ffi
+    from bevy_terrain_amd.shard import shard_pieces
+
+    device = bt.Device(0)
+    L = _ffi.lib()
+    if cube:
+        T, b, lods, W = 32, 2, 4, 230
+        faces = [K.random_raster(O.FORMAT_R16, W, W, seed=70 + s) for s in range(6)]
+        oracle = O.OracleAtlas(lods, 1024, True, [(T, b, 1, O.FORMAT_R16)])
+        oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(O.usable_cores())
+    else:
+        T, b, lods, W = 64, 2, 6, 2100
+        faces = [K.random_raster(O.FORMAT_R16, W, W, seed=39)]
+        oracle = K.oracle_planar(faces[0], lods, T, b, O.FORMAT_R16, atlas_size=2048)
+    c = T - 2 * b
+    total_uploaded = 0
+    for rank in range(world):
+        def job(rasters):
+            if cube:
+                cfg = bt.TerrainConfig(lod_count=lods, atlas_size=1024, path="terrains/spherical")
+                cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=T, border_size=b, format=bt.AttachmentFormat.R16))
+                atlas = bt.TileAtlas.new(cfg, device)
+                server = bt.AssetServer()
+                paths = [f"f{s}" for s in range(6)]
+                for p, f in zip(paths, rasters):
+                    server.insert(p, f)
+                pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_spherical(
+                    bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lods)), server, atlas, defer_upload=True)
+            else:
+                cfg = bt.TerrainConfig(lod_count=lods, atlas_size=2048, path="t", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+                cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=T, border_size=b))
+                atlas = bt.TileAtlas.new(cfg, device)
+                pre = bt.Preprocessor.new().preprocess_tile(bt.PreprocessDataset(path="s", lod_range=range(0, lods)), bt.AssetServer().insert("s", rasters[0]), atlas,
+                                                            defer_upload=True)
+            _ffi.check(L.bt_preprocessor_set_shard(pre._h, rank, world))
+            return atlas, pre
+
+        # first the windows (the plan is compiled, nothing travels yet) ...
+        atlas, pre = job(faces)
+        windows = [pre.source_window(atlas, i)[0] for i in range(len(faces))]
+        # ... then the real run from rasters that hold nothing outside them
+        poisoned = []
+        for f, (x0, y0, x1, y1) in zip(faces, windows):
+            g = np.zeros_like(f)
+            g[y0:y1, x0:x1] = f[y0:y1, x0:x1]
+            poisoned.append(g)
+        atlas, pre = job(poisoned)
+        _ffi.check(L.bt_preprocessor_run(pre._h, atlas._h, _ffi.RUN_KEEP_QUEUE | _ffi.RUN_SHARD_LOCAL))
+        device.synchronize()
+        uploaded = pre.source_window(atlas, len(faces) - 1)[1]
+        x0, y0, x1, y1 = windows[-1]
+        assert uploaded == (x1 - x0) * (y1 - y0) * 2
+        area = sum((w[2] - w[0]) * (w[3] - w[1]) for w in windows)
+        total_uploaded += area * 2
+        # a rank's share of the source: 1 / world of it + the halo of its strips (a strip of 8-texel-aligned staging windows)
+        assert area * world < 1.35 * sum(f.size for f in faces), (rank, windows)
+        if not cube:
+            assert (y0, y1) == (0, W) and x1 - x0 < W // world + 2 * (T + 16)
+        pieces = [p for p in shard_pieces(pre) if p["owner_rank"] == rank]
+        assert pieces
+        coords = {i: cc for cc, i in oracle.tiles()}
+        finest = max(p["lod"] for p in pieces)
+        for p in pieces:
+            data = atlas.download_tiles(0, p["first_layer"], p["layers"])
+            for k in range(0, p["layers"], max(1, p["layers"] // 11)):
+                exp = oracle.tile(0, p["first_layer"] + k)
+                side, lod, x, y = coords[p["first_layer"] + k]
+                edge = x in (0, (1 << lod) - 1) or y in (0, (1 << lod) - 1)
+                if p["lod"] == finest and not (cube and edge):
+                    assert np.array_equal(data[k], exp), (rank, p, coords[p["first_layer"] + k])
+                else:
+                    assert np.array_equal(data[k][b:b + c, b:b + c], exp[b:b + c, b:b + c]), (rank, p)
+    assert total_uploaded < 1.35 * sum(f.nbytes for f in faces)
