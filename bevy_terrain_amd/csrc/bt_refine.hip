@@ -67,7 +67,10 @@ __device__ __forceinline__ float length3(float x, float y, float z) { return sqr
 
 // refine_tiles.wgsl:17-22 -> compute_subdivision_coordinate (functions.wgsl:133-154) ->
 // approximate_view_distance (:117-131) -> compute_local_position (:73-96)
-__device__ bool should_be_divided(const bt_view_state& v, const bt_tile_coordinate& tile) {
+// approximate_height: the view's (bt_view_state::approximate_height), or the value bt_frame_update left on the device — passed
+// beside the view: writing it into the by-value kernel argument makes the compiler copy the whole struct to scratch (224 bytes,
+// 14 -> 52 VGPRs in the divide-bits kernel: measured, round 4)
+__device__ bool should_be_divided(const bt_view_state& v, const bt_tile_coordinate& tile, float approximate_height) {
     Coordinate vc{tile.side, v.origin_lod, uint32_t(v.sides[tile.side].view_xy[0]), uint32_t(v.sides[tile.side].view_xy[1]),
                   v.sides[tile.side].view_uv[0], v.sides[tile.side].view_uv[1]};
     coordinate_change_lod(vc, tile.lod);
@@ -118,9 +121,9 @@ __device__ bool should_be_divided(const bt_view_state& v, const bt_tile_coordina
     nx = nx / nl;
     ny = ny / nl;
     nz = nz / nl;
-    const float dx = (wx + v.approximate_height * nx) - v.world_position[0];
-    const float dy = (wy + v.approximate_height * ny) - v.world_position[1];
-    const float dz = (wz + v.approximate_height * nz) - v.world_position[2];
+    const float dx = (wx + approximate_height * nx) - v.world_position[0];
+    const float dy = (wy + approximate_height * ny) - v.world_position[1];
+    const float dz = (wz + approximate_height * nz) - v.world_position[2];
     const float view_distance = length3(dx, dy, dz);
     return view_distance < v.subdivision_distance * inv_tc;
 }
@@ -163,7 +166,7 @@ constexpr uint32_t kCntVisited = 8, kCntDivide = 40, kCounterWords = 72;  // (bt
 // the indirect arguments the unordered collector (next launch) accumulates into
 __global__ __launch_bounds__(256) void tiling_divide_bits_kernel(bt_view_state view, uint32_t lods, int radius, unsigned long long* __restrict__ bits,
                                                                  uint32_t* __restrict__ counters, bt_indirect* __restrict__ indirect, const float* __restrict__ height) {
-    if (height) view.approximate_height = *height;  // (bt_frame_update: the height sampled earlier on this stream, never seen by the host)
+    const float approximate_height = height ? *height : view.approximate_height;  // (bt_frame_update: the height sampled earlier on this stream, never seen by the host)
     const uint32_t W = 2u * uint32_t(radius) + 1u, chunks = (W * W + 255u) / 256u;
     const uint32_t chunk = blockIdx.x % chunks, lod = (blockIdx.x / chunks) % lods, side = blockIdx.x / (chunks * lods);
     if (counters && blockIdx.x == 0) {
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void tiling_divide_bits_kernel(bt_view_state v
     const uint32_t b = chunk * 256u + threadIdx.x;
     const int tx = ox + int(b % W), ty = oy + int(b / W), last = int((1u << lod) - 1u);
     bool divide = false;
-    if (b < W * W && tx >= 0 && ty >= 0 && tx <= last && ty <= last) divide = should_be_divided(view, bt_tile_coordinate{side, lod, uint32_t(tx), uint32_t(ty)});
+    if (b < W * W && tx >= 0 && ty >= 0 && tx <= last && ty <= last) divide = should_be_divided(view, bt_tile_coordinate{side, lod, uint32_t(tx), uint32_t(ty)}, approximate_height);
     const unsigned long long word = __ballot(divide);
     if ((threadIdx.x & 63u) == 0) bits[(size_t(side) * kMaxLods + lod) * kWinWords + chunk * 4u + (threadIdx.x >> 6)] = word;
 }
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256) void tiling_collect_kernel(bt_view_state view,
                                                              const unsigned long long* __restrict__ bits, bt_tile_coordinate* __restrict__ final_tiles,
                                                              bt_indirect* __restrict__ indirect, uint32_t* __restrict__ counters, const float* __restrict__ height) {
     __shared__ unsigned long long s_bits[kMaxLods * kWinWords];
-    if (height) view.approximate_height = *height;
+    const float approximate_height = height ? *height : view.approximate_height;
     __shared__ int2 s_origin[kMaxLods];
     const uint32_t W = 2u * uint32_t(radius) + 1u, chunks = (W * W + 255u) / 256u;
     const uint32_t chunk = blockIdx.x % chunks, lod = (blockIdx.x / chunks) % lods, side = blockIdx.x / (chunks * lods);
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256) void tiling_collect_kernel(bt_view_state view,
         for (uint32_t a = lod; reach && a-- > 0;) {  // all ancestors divide (order is irrelevant; an ancestor outside its window is evaluated in place)
             const uint32_t ax = uint32_t(tx) >> (lod - a), ay = uint32_t(ty) >> (lod - a);
             uint32_t ab;
-            reach = wb.inside(a, ax, ay, ab) ? wb.bit(a, ab) : should_be_divided(view, bt_tile_coordinate{side, a, ax, ay});
+            reach = wb.inside(a, ax, ay, ab) ? wb.bit(a, ab) : should_be_divided(view, bt_tile_coordinate{side, a, ax, ay}, approximate_height);
         }
         const bool divide = reach && wb.bit(lod, b);
         const bool fin = reach && !divide;
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(256) void tiling_collect_kernel(bt_view_state view,
                     if (!wb.inside(nl, nx, ny, nb)) {
                         atomicAdd(&counters[kCntVisited + nl], 1u);
                         const bt_tile_coordinate node{side, nl, nx, ny};
-                        if (should_be_divided(view, node)) {
+                        if (should_be_divided(view, node, approximate_height)) {
                             atomicAdd(&counters[kCntDivide + nl], 1u);
                             descend = nl < rc;
                         } else {
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(kThreads) void tiling_prepass_kernel(bt_view_state 
                                                                   bt_indirect* __restrict__ indirect,
                                                                   uint32_t* __restrict__ counters, const unsigned long long* __restrict__ bits, uint32_t assist_lods,
                                                                   const float* __restrict__ height) {
-    if (height) view.approximate_height = *height;
+    const float approximate_height = height ? *height : view.approximate_height;
     // The pass state (Parameters, types.wgsl:43-48) is uniform and kept in registers by every thread; only the
     // per-wave counts of a sweep go through LDS (double-buffered by sweep parity: ONE barrier per sweep).
     __shared__ uint32_t s_divide[2][kWaves], s_final[2][kWaves];
@@ -374,10 +377,10 @@ __global__ __launch_bounds__(kThreads) void tiling_prepass_kernel(bt_view_state 
                         const uint32_t b = uint32_t(by) * kWinW + uint32_t(bx);
                         divide = (s_bits[(tile.side * kMaxLods + tile.lod) * kWinWords + (b >> 6)] >> (b & 63u)) & 1ull;
                     } else {
-                        divide = should_be_divided(view, tile);  // outside its window: the same function, in place
+                        divide = should_be_divided(view, tile, approximate_height);  // outside its window: the same function, in place
                     }
                 } else {
-                    divide = should_be_divided(view, tile);
+                    divide = should_be_divided(view, tile, approximate_height);
                 }
             }
             const bool fin = active && !divide;

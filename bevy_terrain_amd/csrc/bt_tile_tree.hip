@@ -64,7 +64,9 @@ __global__ __launch_bounds__(kThreads) void tile_tree_update_kernel(TreeParams P
                                                                     bt_tile_coordinate* __restrict__ released, bt_tile_coordinate* __restrict__ requested,
                                                                     uint32_t* __restrict__ counts, const float* __restrict__ height) {
     __shared__ uint32_t s_rel[2][kWaves], s_req[2][kWaves];
-    if (height) P.approximate_height = *height;  // the tree's height lives on the device (bt_frame_update: the host's copy may lag a frame)
+    // the tree's height lives on the device (bt_frame_update: the host's copy may lag a frame).  Kept beside P: writing into the
+    // by-value kernel argument makes the compiler copy the struct to scratch
+    const float approximate_height = height ? *height : P.approximate_height;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const uint32_t ts = P.tree_size, per_layer = ts * ts, total = P.sides * P.lod_count * per_layer;
     uint32_t rel_base = 0, req_base = 0, sweep = 0;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(kThreads) void tile_tree_update_kernel(TreeParams P
                 origins[2 * layer + 1] = origin[1];
             }
             const bt_tile_coordinate tile = {side, lod, origin[0] + x, origin[1] + y};
-            const double tile_distance = compute_tile_distance(tile, vc, P.model, P.approximate_height, P.view_world_position);
+            const double tile_distance = compute_tile_distance(tile, vc, P.model, approximate_height, P.view_world_position);
             const double load_distance = P.load_distance / double(1u << lod);
             const bool want = lod == 0 || tile_distance < load_distance;
             NodeState* slot = nodes + layer * per_layer + (tile.x % ts) * ts + (tile.y % ts);
@@ -254,9 +256,9 @@ __global__ __launch_bounds__(128) void tile_tree_sample_kernel(TreeParams P, con
                                                                float4* __restrict__ out, float* __restrict__ heights, const float* __restrict__ height) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    if (height) P.approximate_height = *height;
+    const float approximate_height = height ? *height : P.approximate_height;
     const V3 p = {positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]};
-    const V3 surface = surface_position(P.model, p, double(P.approximate_height));
+    const V3 surface = surface_position(P.model, p, double(approximate_height));
     // compute_blend (tile_tree.rs:223-239)
     const double view_distance = distance3(P.view_world_position, surface);
     const double cap = double(P.lod_count) - 0.00001;
