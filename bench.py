@@ -162,7 +162,7 @@ def end_to_end(device, src_ptr):
         for _ in range(3):
             dt, st = streamed_pass(host, LOD_COUNT, root)
             times.append(dt)
-        streamed = {"ms": min(times) * 1e3, "ms_all": [t * 1e3 for t in times], "bands": st["bands"], "overlapped": st["streamed"],
+        streamed = {"ms": sorted(times)[1] * 1e3, "ms_best": min(times) * 1e3, "ms_all": [t * 1e3 for t in times], "bands": st["bands"], "overlapped": st["streamed"],
                     "files_identical_to_serial_pass": digest(root) == serial_digest}
         # the same pipeline into the default temporary directory (the box's disk / overlay file system)
         other = tempfile.mkdtemp(prefix="bt_e2e_disk_")
@@ -213,7 +213,7 @@ def end_to_end(device, src_ptr):
     total = up + run + save
     best = streamed["ms"] / 1e3 if streamed and "ms" in streamed else total
     return {"ms": best * 1e3, "tiles_per_s": len(files) / best,
-            "pipeline": streamed,  # bt_preprocessor_run_streamed: H2D in bands || kernels || D2H + writes; "ms" above is its best of 3
+            "pipeline": streamed,  # bt_preprocessor_run_streamed: H2D in bands || kernels || D2H + writes; "ms" above is the median of its 3 passes
             "serial": {"ms": total * 1e3, "tiles_per_s": len(files) / total,
                        "note": "the same span with the legs one after the other: preprocess_tile (upload) -> run -> save"},
             "upload_ms": up * 1e3, "upload_GBps": host.nbytes / up / 1e9,
@@ -221,7 +221,7 @@ def end_to_end(device, src_ptr):
             "save_ms": save * 1e3, "save_GBps": written / save / 1e9, "files": len(files), "bytes_written": written,
             "load_back": load,  # not part of "ms"
             "filesystem": fs, "directory": root, "warm_up_pass_ms": sum(results[0]) * 1e3,
-            "span": "source raster in pageable host memory -> hipMalloc + H2D -> 3 kernels -> D2H through 3 pinned "
+            "span": "source raster in pageable host memory -> hipMalloc + H2D -> 2 kernels -> D2H through 3 pinned "
                     "buffers + writer threads -> 1365 .bin files + config.tc (preprocessor.rs:363,419)"}
 
 

@@ -1363,13 +1363,14 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
 
 
 // ---- fused_direct (Rgba8): split + the two parent LODs WITHOUT LDS staging ------------------------------------------
-// Workgroup = 8 centre rows of one finest tile, thread = one centre column (two sweeps of 256).  The 9 source rows x 2
-// texels a column needs are requested up front straight from global memory (a 4-byte texel needs no sub-dword
-// extraction, neighbouring lanes share their texels through L1), filtered horizontally once each; row pairs reduce in
-// registers and lane pairs / quads through DPP to LOD-1 and LOD-2, whose centres are written into the parent tiles (their
-// aprons come from the batched stitch kernel).  Validity is handled in line: a pixel without data is not stored (it keeps the atlas
-// value, split.wgsl:37-42) and its previous value is fetched for the reduction.  The tile's own apron pixels (4 columns
-// per row, whole apron rows in the first / last block) take the general per-pixel path with the neighbour tile's formula.
+// Workgroup = several 4-row blocks of one finest tile (c = 508 = 127 x 4: no partial block), thread = one centre column (two
+// sweeps of 256).  The 5 source rows x 2 texels a column needs per block are requested ONE BLOCK AHEAD straight from global
+// memory (a 4-byte texel needs no sub-dword extraction, neighbouring lanes share their texels through L1), filtered
+// horizontally once each; row pairs reduce in registers and lane pairs / quads through DPP to LOD-1 and LOD-2, whose centres are
+// written into the parent tiles (their aprons come from the tail launch).  Validity is handled in line: a pixel without data is
+// not stored (it keeps the atlas value, split.wgsl:37-42) and its previous value is fetched for the reduction.  The tile's own
+// apron pixels (4 columns per row, whole apron rows in the first / last block) take the general per-pixel path with the
+// neighbour tile's formula.
 __device__ __forceinline__ uint32_t float_to_unorm8(float e) {
     const float cl = e < 0.0f ? 0.0f : (e > 1.0f ? 1.0f : e);
     return uint32_t(floorf(0.5f + 255.0f * cl));
@@ -1493,7 +1494,7 @@ __device__ __forceinline__ uint32_t quad_dpp(uint32_t v) {
     return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), kCtrl, 0xf, 0xf, true));
 }
 
-constexpr uint32_t kDirectRows = 8, kDirectMaxBlocks = 8;
+constexpr uint32_t kDirectRows = 4, kDirectMaxBlocks = 16;
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_direct_rgba8_kernel(FusedArgs A) {
     constexpr uint32_t kRows = kDirectRows;
@@ -1559,30 +1560,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const uint32_t half_sh = (tid & 1u) * 16u;  // the channel pair this lane finishes in the lane-split reductions
         const uint32_t off0 = uint32_t(ax.i0) * 4u, off1 = uint32_t(ax.i1) * 4u;  // (host: raster rows shorter than 2^32 bytes)
 
-        for (uint32_t blk = blk_begin; blk < blk_end; blk++) {
+        // The blocks of a sweep form a software pipeline: the source texels of block k + 1 are requested before block k is
+        // shaded, into the other of two register sets (the loop is unrolled by two so that no set is ever copied) — a
+        // workgroup's loads, arithmetic and stores overlap inside the wave instead of only across the four waves of a SIMD,
+        // which start in phase on a one-generation launch (config 2: 1024 workgroups) and stay in phase.
+        uint32_t set_a0[kRows + 1], set_a1[kRows + 1], set_b0[kRows + 1], set_b1[kRows + 1];
+        auto is_fast = [&](uint32_t blk) -> bool {  // (wave-uniform) kRows + 1 consecutive source rows, a whole block
+            return blk < blk_end && __builtin_amdgcn_readfirstlane(s_consecutive[blk - blk_begin]) != 0;
+        };
+        // (always issued, so that the compiler's counted waits see one straight line of memory operations: past the last block, or
+        // in front of a block that takes the general path, it requests row 0 kRows + 1 times into registers nobody reads)
+        auto request = [&](uint32_t blk, uint32_t (&d0)[kRows + 1], uint32_t (&d1)[kRows + 1]) {
+            const bool wanted = is_fast(blk);
+            const int y_first = wanted ? __builtin_amdgcn_readfirstlane(s_ay[(blk - blk_begin) * kRows].i0) : 0;
+            const uint64_t step = wanted ? raster.pitch : 0u;
+            // uniform row pointer (stepped by the pitch) + this lane's 32-bit byte offsets: scalar-base loads, no per-load address arithmetic
+            global_bytes_t rowp = data + uint64_t(uint32_t(y_first)) * raster.pitch;
+            uint32_t o0 = off0, o1 = off1;
+            asm volatile("" : "+v"(o0), "+v"(o1));  // keeps the zero-extension next to the loads (scalar base + 32-bit VGPR offset form)
+#pragma unroll
+            for (uint32_t j = 0; j <= kRows; j++) {
+                d0[j] = BT_ABLATE(A, 8u) ? 0x01010101u * (tid + j + 1u) | 1u : *(global_u32_t)(rowp + o0);  // (8: no source loads)
+                d1[j] = BT_ABLATE(A, 8u) ? 0x01010101u * (tid + j + 2u) | 1u : *(global_u32_t)(rowp + o1);
+                rowp += step;
+            }
+        };
+        auto block = [&](uint32_t blk, uint32_t (&raw0)[kRows + 1], uint32_t (&raw1)[kRows + 1], uint32_t (&next0)[kRows + 1], uint32_t (&next1)[kRows + 1]) {
             const uint32_t cr0 = blk * kRows, nrows = min(kRows, c - cr0);
             const Axis* ay_blk = s_ay + (blk - blk_begin) * kRows;
+            request(blk + 1u, next0, next1);
             uint32_t out[kRows];
 #pragma unroll
             for (uint32_t r = 0; r < kRows; r++) out[r] = 0;
-            // ---- the fast path: the block's 8 rows use 9 consecutive source rows, and no texel any lane of the wave reads is
-            // "no data" (channel 0 == 0, split.wgsl:34): no per-pixel validity, plain stores
-            bool fast = __builtin_amdgcn_readfirstlane(s_consecutive[blk - blk_begin]) != 0;
+            // ---- the fast path: the block's rows use kRows + 1 consecutive source rows (requested one block ago), and no texel any
+            // lane of the wave reads is "no data" (channel 0 == 0, split.wgsl:34): no per-pixel validity, plain stores
+            bool fast = is_fast(blk);
             if (__builtin_expect(fast, 1)) {
-                const int y_first = __builtin_amdgcn_readfirstlane(ay_blk[0].i0);
-                uint32_t raw0[kRows + 1], raw1[kRows + 1];
-                // uniform row pointer (stepped by the pitch) + this lane's 32-bit byte offsets: scalar-base loads, no per-load address arithmetic
-                global_bytes_t rowp = data + uint64_t(uint32_t(y_first)) * raster.pitch;
-                uint32_t o0 = off0, o1 = off1;
-                asm volatile("" : "+v"(o0), "+v"(o1));  // keeps the zero-extension next to the loads (scalar base + 32-bit VGPR offset form)
-#pragma unroll
-                for (uint32_t j = 0; j <= kRows; j++) {
-                    raw0[j] = BT_ABLATE(A, 8u) ? 0x01010101u * (tid + j + 1u) | 1u : *(global_u32_t)(rowp + o0);  // (8: no source loads)
-                    raw1[j] = BT_ABLATE(A, 8u) ? 0x01010101u * (tid + j + 2u) | 1u : *(global_u32_t)(rowp + o1);
-                    rowp += raster.pitch;
-                }
-                // rolling over the source rows as they arrive (the loads were all requested above); the no-data test rides along
-                // and is evaluated before anything is stored
+                // rolling over the source rows as they arrive; the no-data test rides along and is evaluated before anything is stored
                 uint32_t z = min(raw0[0] & 0xFFu, raw1[0] & 0xFFu);
                 H4p top = hrow_rgba8_packed(raw0[0], raw1[0], ax.fr);
 #pragma unroll
@@ -1638,8 +1652,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                             if (apron_lane) tile[(b + cr0 + r) * T + store_px] = out[r];
                         }
                 }
+                // the fetched values arrive HERE: left pending, the compiler would guard the reductions below — which the fast path
+                // shares — with a wait for every memory operation in flight, the next block's requests included
+#pragma unroll
+                for (uint32_t r = 0; r < kRows; r++) asm volatile("" : "+v"(out[r]));
             }
-            if (A.levels < 2 || self4 == kInvalid || BT_ABLATE(A, 1u)) continue;  // (1: no pyramid)
+            if (A.levels < 2 || self4 == kInvalid || BT_ABLATE(A, 1u)) return;  // (1: no pyramid)
             // ---- LOD-1: rows (2i, 2i+1) in registers, columns (cx, cx + 1) in the lane pair.  Common case (every texel of the
             // wave counts, rgb != 0): the two lanes of a pair split the four channels — each gathers the pair's four texels
             // (left column = even lane, downsample.wgsl OFFSETS order) and finishes two channels; the halves meet by one DPP swap.
@@ -1667,7 +1685,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (uint32_t i = 0; i < kRows / 2; i++)
                 if (active && (tid & 1u) == 0 && 2 * i + 1 < nrows)  // centre texel; the parents' aprons come from the batched stitch kernel
                     atlas[uint64_t(self4) * tile_texels + (b + (it.y & 1u) * (c / 2u) + (cr0 >> 1) + i) * T + b + (it.x & 1u) * (c / 2u) + (cx >> 1)] = q[i];
-            if (A.levels < 3 || self3 == kInvalid) continue;
+            if (A.levels < 3 || self3 == kInvalid) return;
             // ---- LOD-2: every lane of a quad holds the quad's two LOD-1 texels of a row (lanes 0, 1 the left, 2, 3 the right)
             uint32_t w[kRows / 4];
             uint32_t zq = 0xFFFFFFFFu;
@@ -1690,6 +1708,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (uint32_t j = 0; j < kRows / 4; j++)
                 if (active && (tid & 3u) == 0 && 4 * j + 3 < nrows)
                     atlas[uint64_t(self3) * tile_texels + (b + (it.y & 3u) * (c / 4u) + (cr0 >> 2) + j) * T + b + (it.x & 3u) * (c / 4u) + (cx >> 2)] = w[j];
+        };
+        request(blk_begin, set_a0, set_a1);
+        for (uint32_t blk = blk_begin; blk < blk_end; blk += 2u) {
+            block(blk, set_a0, set_a1, set_b0, set_b1);
+            if (blk + 1u < blk_end) block(blk + 1u, set_b0, set_b1, set_a0, set_a1);
         }
     }
 
@@ -2043,7 +2066,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             job.args.item_count = uint32_t(items.size());
             {   // row blocks per workgroup: as many as keep at least one resident generation (1024 workgroups) busy
                 const uint64_t blocks = uint64_t(items.size()) * ((m.center_size + kDirectRows - 1) / kDirectRows);
-                job.args.groups = uint32_t(std::min<uint64_t>(kDirectMaxBlocks, std::max<uint64_t>(1, blocks / 1024)));
+                job.args.groups = uint32_t(std::min<uint64_t>(kDirectMaxBlocks, std::max<uint64_t>(1, (blocks + 1023) / 1024)));
 #ifdef BT_DEBUG_HOOKS
                 if (const char* e = getenv("BT_FUSED_PARTS")) job.args.groups = std::max(1u, std::min(kDirectMaxBlocks, uint32_t(atoi(e))));
 #endif

@@ -389,8 +389,8 @@ def _nodata_mask_16k(seed=43):
 @pytest.mark.parametrize("masked", [False, True])
 def test_config3_16k_single_gpu_all_tiles(device, masked):
     """BASELINE config 3 at N = 1, the workload bench.py times: 16384^2 fBm (seed 42), T = 512, b = 2, lod_count 6 ->
-    1365 tiles through the fused plan (1024 workgroups, fused_main / fused_todo / fused_tail), every tile byte-compared
-    with the reference's own WGSL executed on the CPU (oracle/_ref); the masked variant (seed 43, 5 % no-data) drives fused_todo at full size."""
+    1365 tiles through the fused plan (1024 workgroups, fused_main / fused_tail), every tile byte-compared
+    with the reference's own WGSL executed on the CPU (oracle/_ref); the masked variant (seed 43, 5 % no-data) drives fused_main's no-data redo at full size."""
     size, lods = 16384, 6
     ptr = device.synth_fbm_r16(size, size, 42)
     src = device.download(ptr, (size, size), np.uint16)
@@ -585,7 +585,7 @@ def test_direct_rgba8_several_row_blocks_per_workgroup(device, T, b, lod_count, 
 def test_streamed_run_writes_the_same_files(device, tmp_path, holes):
     """bt_preprocessor_run_streamed (upload in bands of tile rows || kernels || download + file writes) against run() + save()
     of the same job, file by file, and against the oracle's atlas: 8192^2 R16, lod_count 5 -> 256 finest tiles in 4 bands of 4
-    tile rows; with no-data patches (fused_todo runs band by band) and without."""
+    tile rows; with no-data patches (fused_main's redo runs band by band) and without."""
     size, lods = 8192, 5
     src = K.smooth_raster(size, size, seed=91, device=device)
     if holes:

@@ -71,6 +71,9 @@ def main():
             bt.PreprocessDataset(attachment_index=att, path=path, lod_range=range(0, 4)), server, atlas)
         ms, prof, st = time_job(device, pre, atlas)
         out[name] = {"ms": ms, "tiles": st["tiles"], "launches": [(l["kind"], round(l["avg_ms"] * 1e3, 1)) for l in prof]}
+    if "--config2" in sys.argv:
+        print(json.dumps(out))
+        return
     # config 5 (height)
     faces = [(device.synth_fbm_r16(8192, 8192, 7 + s), 8192, 8192) for s in range(6)]
     cfg = bt.TerrainConfig(lod_count=5, atlas_size=2048, path="terrains/spherical")
