@@ -1474,6 +1474,12 @@ __device__ __forceinline__ uint32_t vmix_rgba8_packed(const H4p& top, const H4p&
     const direct_f2 lo = khalf + kn * (top.lo * g2y + bot.lo * f2y), hi = khalf + kn * (top.hi * g2y + bot.hi * f2y);
     return uint32_t(lo.x) | (uint32_t(lo.y) << 8) | (uint32_t(hi.x) << 16) | (uint32_t(hi.y) << 24);
 }
+// the same with the row's (fy, 1 - fy) handed in (vector registers read at a uniform LDS address: no subtraction, no v_readfirstlane)
+__device__ __forceinline__ uint32_t vmix_rgba8_weights(const H4p& top, const H4p& bot, float fy, float gy) {
+    const direct_f2 f2y = {fy, fy}, g2y = {gy, gy}, kn = {255.0f / 256.0f, 255.0f / 256.0f}, khalf = {0.5f, 0.5f};
+    const direct_f2 lo = khalf + kn * (top.lo * g2y + bot.lo * f2y), hi = khalf + kn * (top.hi * g2y + bot.hi * f2y);
+    return uint32_t(lo.x) | (uint32_t(lo.y) << 8) | (uint32_t(hi.x) << 16) | (uint32_t(hi.y) << 24);
+}
 // 2 x 2 average of four texels that all count (rgb != 0), two of the four channels: the ones at bit `sh` (0 or 16) of the
 // texels.  Sum order and arithmetic of downsample4_rgba8's common case: ((t00 + t01) + t10) + t11, x 0.25 (exact), quantise
 // — 0.5 + (255 / 256) * (sum * 0.25) == 0.5 + (255 / 1024) * sum, both products being the same real number with an exactly
@@ -1513,27 +1519,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     uint32_t* atlas = reinterpret_cast<uint32_t*>(A.atlas);
     const uint32_t tile_texels = T * T;
     uint32_t* tile = atlas + uint64_t(it.atlas_index) * tile_texels;
+#ifdef BT_DEBUG_HOOKS
+    // (134217728: real-time (100 MHz) stamps per workgroup — entry, set-up done, after each sweep, end — into the atlas's last layer; tools/direct_probe.py)
+    auto stamp = [&](uint32_t slot) {
+        if (BT_ABLATE(A, 134217728u) && tid == 0)
+            reinterpret_cast<unsigned long long*>(atlas + uint64_t(A.m.atlas_size - 1u) * tile_texels)[work * 8u + slot] = __builtin_amdgcn_s_memrealtime();
+    };
+#else
+    auto stamp = [&](uint32_t) {};
+#endif
+    stamp(0);
     const uint32_t self4 = A.levels >= 2 ? grid_lookup(A, it.side, A.lod - 1, int(it.x >> 1), int(it.y >> 1)) : kInvalid;
     const uint32_t self3 = A.levels >= 3 ? grid_lookup(A, it.side, A.lod - 2, int(it.x >> 2), int(it.y >> 2)) : kInvalid;
 
+    // per block of the workgroup (+ 2: requests run two blocks ahead): chain = 0 if the block takes the general path, else 0x100 |
+    // bit r = (source row r + 1 of the block is one further down than row r); the block's first / last source row
+    struct BlockInfo {
+        int chain, y_first, y_last, pad;
+    };
     __shared__ Axis s_ay[kDirectMaxBlocks * kRows];
-    __shared__ int s_consecutive[kDirectMaxBlocks];
-    for (uint32_t i = tid; i < row_end - row_begin; i += 256u) s_ay[i] = split_axis_pow2(row_begin + i, c, it.y, inv_scale, A.tly, A.bry, raster.height);
+    __shared__ float2 s_wy[kDirectMaxBlocks * kRows];  // (fy, 1 - fy) of the row: read at a uniform address, used from vector registers
+    __shared__ BlockInfo s_blk[kDirectMaxBlocks + 2];
+    for (uint32_t i = tid; i < row_end - row_begin; i += 256u) {
+        const Axis a = split_axis_pow2(row_begin + i, c, it.y, inv_scale, A.tly, A.bry, raster.height);
+        s_ay[i] = a;
+        s_wy[i] = float2{a.fr, 1.0f - a.fr};
+    }
     __syncthreads();
-    if (tid < blk_end - blk_begin) {
-        const Axis* ay = s_ay + tid * kRows;
-        bool ok = (blk_begin + tid) * kRows + kRows <= c;
-        for (uint32_t r = 0; ok && r < kRows; r++) ok = ay[r].i0 == ay[0].i0 + int(r) && ay[r].i1 == ay[r].i0 + 1;
-        s_consecutive[tid] = ok ? 1 : 0;
+    if (tid < kDirectMaxBlocks + 2) {
+        // the fast path rolls over a chain of kRows + 1 source rows: row r's lower source row is row r + 1's upper one, and a pair is
+        // one row apart — or the same row, where the source's first / last row is clamped (the tiles along the raster's top and bottom)
+        BlockInfo bi = BlockInfo{0, 0, -1, 0};
+        if (blk_begin + tid < blk_end && (blk_begin + tid) * kRows + kRows <= c) {
+            const Axis* ay = s_ay + tid * kRows;
+            bool ok = true;
+            int chain = 0x100;
+            for (uint32_t r = 0; ok && r < kRows; r++) {
+                const int d = ay[r].i1 - ay[r].i0;
+                ok = (d == 0 || d == 1) && (r == 0 || ay[r].i0 == ay[r - 1].i1);
+                chain |= d << r;
+            }
+            if (ok) bi = BlockInfo{chain, ay[0].i0, ay[kRows - 1].i1, 0};
+        }
+        s_blk[tid] = bi;
     }
     __syncthreads();
     const global_bytes_t data = (global_bytes_t)raster.data;
+    typedef uint8_t __attribute__((address_space(1))) * global_wbytes_t;
+    typedef uint32_t __attribute__((address_space(1))) * global_wu32_t;
+    const global_wbytes_t tile_bytes = (global_wbytes_t)tile;
+    // the parent tiles' quadrants this tile reduces into (their first centre texel)
+    const global_wbytes_t base4 = (global_wbytes_t)(atlas + uint64_t(self4 == kInvalid ? 0u : self4) * tile_texels + (b + (it.y & 1u) * (c / 2u)) * T + b + (it.x & 1u) * (c / 2u));
+    const global_wbytes_t base3 = (global_wbytes_t)(atlas + uint64_t(self3 == kInvalid ? 0u : self3) * tile_texels + (b + (it.y & 3u) * (c / 4u)) * T + b + (it.x & 3u) * (c / 4u));
+    const bool narrow = raster.pitch <= (1ull << 28);  // kRows + 1 rows fit a 32-bit lane offset
 
+    stamp(1);
     const uint32_t c_lanes = (c + 3u) & ~3u;  // whole lane quads take part in the reductions
     // the 2b apron columns of the block's rows ride in spare lanes of the last sweep when there are enough of them (T = 512,
     // b = 2: lanes 252..255): same rows, the column axis of the west / east neighbour (or the own edge column clamped)
     const uint32_t last_cx0 = (c_lanes - 1u) / 256u * 256u;
     const bool aprons_in_sweep = last_cx0 + 256u >= c + 2u * b;
+    // A wave's priority falls as it gets on: the arbiter serves the OLDEST wave of a SIMD first, so on a one-generation launch the four
+    // waves of a SIMD finish one after the other and the last runs alone at a single wave's issue rate (stamps of
+    // tools/direct_probe.py: workgroups ended 26 .. 62 us after the launch).  Waves that are behind overtake instead.
+    const uint32_t prio_step = max(1u, (last_cx0 / 256u + 1u) * (blk_end - blk_begin) / 4u);
+    uint32_t prio_left = prio_step, prio_level = 0;
+    __builtin_amdgcn_s_setprio(3);
     for (uint32_t cx0 = 0; cx0 < c_lanes || (aprons_in_sweep && cx0 <= last_cx0); cx0 += 256u) {
         const uint32_t cx = cx0 + tid;
         const bool active = cx < c;
@@ -1559,67 +1610,129 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         const uint32_t half_sh = (tid & 1u) * 16u;  // the channel pair this lane finishes in the lane-split reductions
         const uint32_t off0 = uint32_t(ax.i0) * 4u, off1 = uint32_t(ax.i1) * 4u;  // (host: raster rows shorter than 2^32 bytes)
-
-        // The blocks of a sweep form a software pipeline: the source texels of block k + 1 are requested before block k is
-        // shaded, into the other of two register sets (the loop is unrolled by two so that no set is ever copied) — a
-        // workgroup's loads, arithmetic and stores overlap inside the wave instead of only across the four waves of a SIMD,
-        // which start in phase on a one-generation launch (config 2: 1024 workgroups) and stay in phase.
-        uint32_t set_a0[kRows + 1], set_a1[kRows + 1], set_b0[kRows + 1], set_b1[kRows + 1];
-        auto is_fast = [&](uint32_t blk) -> bool {  // (wave-uniform) kRows + 1 consecutive source rows, a whole block
-            return blk < blk_end && __builtin_amdgcn_readfirstlane(s_consecutive[blk - blk_begin]) != 0;
-        };
-        // (always issued, so that the compiler's counted waits see one straight line of memory operations: past the last block, or
-        // in front of a block that takes the general path, it requests row 0 kRows + 1 times into registers nobody reads)
-        auto request = [&](uint32_t blk, uint32_t (&d0)[kRows + 1], uint32_t (&d1)[kRows + 1]) {
-            const bool wanted = is_fast(blk);
-            const int y_first = wanted ? __builtin_amdgcn_readfirstlane(s_ay[(blk - blk_begin) * kRows].i0) : 0;
-            const uint64_t step = wanted ? raster.pitch : 0u;
-            // uniform row pointer (stepped by the pitch) + this lane's 32-bit byte offsets: scalar-base loads, no per-load address arithmetic
-            global_bytes_t rowp = data + uint64_t(uint32_t(y_first)) * raster.pitch;
-            uint32_t o0 = off0, o1 = off1;
-            asm volatile("" : "+v"(o0), "+v"(o1));  // keeps the zero-extension next to the loads (scalar base + 32-bit VGPR offset form)
+        // Every instruction a wave issues — scalar ones too — takes a turn of its SIMD's one issue port (tools/issue_probe.hip): the
+        // per-row address steps are lane offsets computed once per sweep instead of scalar additions per row and block.
+        uint32_t lo0[kRows + 1], lo1[kRows + 1], so[kRows];
 #pragma unroll
-            for (uint32_t j = 0; j <= kRows; j++) {
-                d0[j] = BT_ABLATE(A, 8u) ? 0x01010101u * (tid + j + 1u) | 1u : *(global_u32_t)(rowp + o0);  // (8: no source loads)
-                d1[j] = BT_ABLATE(A, 8u) ? 0x01010101u * (tid + j + 2u) | 1u : *(global_u32_t)(rowp + o1);
-                rowp += step;
+        for (uint32_t j = 0; j <= kRows; j++) {
+            lo0[j] = off0 + j * uint32_t(raster.pitch);
+            lo1[j] = off1 + j * uint32_t(raster.pitch);
+            asm volatile("" : "+v"(lo0[j]), "+v"(lo1[j]));
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < kRows; r++) {
+            so[r] = (store_px + r * T) * 4u;
+            asm volatile("" : "+v"(so[r]));
+        }
+        uint32_t l4 = (cx >> 1) * 4u, l3 = (cx >> 2) * 4u;
+        asm volatile("" : "+v"(l4), "+v"(l3));
+
+        // The blocks of a sweep form a software pipeline over two register sets (the loop is unrolled by two so that no set is ever
+        // copied): block k's texels are requested when block k - 2 has consumed its own, in front of that block's stores.
+        uint32_t set_a0[kRows + 1], set_a1[kRows + 1], set_b0[kRows + 1], set_b1[kRows + 1];
+        BlockInfo info_a, info_b;
+        H4p carry_top = H4p{{0.0f, 0.0f}, {0.0f, 0.0f}};
+        uint32_t carry_z = 0;
+        int carry_row = -1;  // (wave-uniform) the source row carry_top was blended from; -1: none
+        auto block_info = [&](uint32_t blk) -> BlockInfo {  // (wave-uniform; blk < blk_begin + kDirectMaxBlocks + 2)
+            const BlockInfo v = s_blk[blk - blk_begin];
+            return BlockInfo{__builtin_amdgcn_readfirstlane(v.chain), __builtin_amdgcn_readfirstlane(v.y_first), __builtin_amdgcn_readfirstlane(v.y_last), 0};
+        };
+        // Always 2 x (kRows + 1) loads, whatever the block: the hand-counted waits below rely on it.  A block that takes the general
+        // path (chain 0) gets row 0 kRows + 1 times into registers nobody reads.  Issued from assembly and waited for by hand
+        // (arrived() below): the compiler's own counted waits assume the fewest operations in flight over all paths of this control
+        // flow and end up waiting for the other set and for the stores as well.
+        auto request = [&](const BlockInfo& bi, uint32_t (&d0)[kRows + 1], uint32_t (&d1)[kRows + 1]) {
+            global_bytes_t rowp = data + uint64_t(uint32_t(bi.y_first)) * raster.pitch;
+            if (BT_ABLATE(A, 8u)) {  // (8: no source loads)
+#pragma unroll
+                for (uint32_t j = 0; j <= kRows; j++) {
+                    d0[j] = 0x01010101u * (tid + j + 1u) | 1u;
+                    d1[j] = 0x01010101u * (tid + j + 2u) | 1u;
+                }
+            } else if (__builtin_expect(bi.chain == 0x10F && narrow, 1)) {  // kRows + 1 consecutive rows: one base, the rows in the lane offsets
+#pragma unroll
+                for (uint32_t j = 0; j <= kRows; j++)
+                    asm volatile("global_load_dword %0, %2, %4\n\tglobal_load_dword %1, %3, %4" : "=&v"(d0[j]), "=&v"(d1[j]) : "v"(lo0[j]), "v"(lo1[j]), "s"(rowp));
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j <= kRows; j++) {
+                    asm volatile("global_load_dword %0, %2, %4\n\tglobal_load_dword %1, %3, %4" : "=&v"(d0[j]), "=&v"(d1[j]) : "v"(off0), "v"(off1), "s"(rowp));
+                    rowp += (uint32_t(bi.chain) >> j) & 1u ? raster.pitch : 0u;
+                }
             }
         };
-        auto block = [&](uint32_t blk, uint32_t (&raw0)[kRows + 1], uint32_t (&raw1)[kRows + 1], uint32_t (&next0)[kRows + 1], uint32_t (&next1)[kRows + 1]) {
+        // row j of a set has arrived when at most the set's later rows and the other set's request (always issued after it: kRows + 1
+        // pairs) are in flight; whatever else was issued in between only makes the count conservative
+        auto arrived = [&](uint32_t j, uint32_t& t0, uint32_t& t1) {
+            switch (j) {
+                case 0: asm volatile("s_waitcnt vmcnt(18)" : "+v"(t0), "+v"(t1)); break;
+                case 1: asm volatile("s_waitcnt vmcnt(16)" : "+v"(t0), "+v"(t1)); break;
+                case 2: asm volatile("s_waitcnt vmcnt(14)" : "+v"(t0), "+v"(t1)); break;
+                case 3: asm volatile("s_waitcnt vmcnt(12)" : "+v"(t0), "+v"(t1)); break;
+                default: asm volatile("s_waitcnt vmcnt(10)" : "+v"(t0), "+v"(t1)); break;
+            }
+        };
+        static_assert(kRows == 4, "arrived() counts 2 x (kRows + 1) loads per request");
+        auto block = [&](uint32_t blk, BlockInfo& bi, uint32_t (&raw0)[kRows + 1], uint32_t (&raw1)[kRows + 1]) {
+            if (--prio_left == 0) {
+                prio_left = prio_step;
+                prio_level++;
+                if (prio_level == 1u) __builtin_amdgcn_s_setprio(2);
+                else if (prio_level == 2u) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
             const uint32_t cr0 = blk * kRows, nrows = min(kRows, c - cr0);
             const Axis* ay_blk = s_ay + (blk - blk_begin) * kRows;
-            request(blk + 1u, next0, next1);
             uint32_t out[kRows];
 #pragma unroll
             for (uint32_t r = 0; r < kRows; r++) out[r] = 0;
-            // ---- the fast path: the block's rows use kRows + 1 consecutive source rows (requested one block ago), and no texel any
+            // ---- the fast path: the block's rows use a chain of kRows + 1 source rows (requested two blocks ago), and no texel any
             // lane of the wave reads is "no data" (channel 0 == 0, split.wgsl:34): no per-pixel validity, plain stores
-            bool fast = is_fast(blk);
-            if (__builtin_expect(fast, 1)) {
-                // rolling over the source rows as they arrive; the no-data test rides along and is evaluated before anything is stored
-                uint32_t z = min(raw0[0] & 0xFFu, raw1[0] & 0xFFu);
-                H4p top = hrow_rgba8_packed(raw0[0], raw1[0], ax.fr);
+            const bool chained = bi.chain != 0;
+            bool fast = chained;
+            uint32_t z = 1;
+            if (__builtin_expect(chained, 1)) {
+                // rolling over the source rows as they arrive; the no-data test rides along and is evaluated before anything is stored.
+                // The block's first source row is usually the previous block's last: its blended texel (and its no-data byte) is carried
+                const float2* wy = s_wy + (blk - blk_begin) * kRows;
+                H4p top;
+                if (__builtin_expect(carry_row == bi.y_first, 1)) {
+                    z = carry_z;
+                    top = carry_top;
+                } else {
+                    arrived(0, raw0[0], raw1[0]);
+                    z = min(raw0[0] & 0xFFu, raw1[0] & 0xFFu);
+                    top = hrow_rgba8_packed(raw0[0], raw1[0], ax.fr);
+                }
 #pragma unroll
                 for (uint32_t r = 0; r < kRows; r++) {
-                    z = min(z, min(raw0[r + 1] & 0xFFu, raw1[r + 1] & 0xFFu));
+                    arrived(r + 1, raw0[r + 1], raw1[r + 1]);
+                    const uint32_t z_row = min(raw0[r + 1] & 0xFFu, raw1[r + 1] & 0xFFu);
+                    z = min(z, z_row);
                     const H4p bot = hrow_rgba8_packed(raw0[r + 1], raw1[r + 1], ax.fr);
-                    const float fy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ay_blk[r].fr)));
-                    out[r] = vmix_rgba8_packed(top, bot, fy);
+                    const float2 w = wy[r];
+                    out[r] = vmix_rgba8_weights(top, bot, w.x, w.y);
                     top = bot;
+                    if (r + 1 == kRows) carry_z = z_row;
                 }
+                carry_top = top;
+                carry_row = bi.y_last;
+            } else {
+                carry_row = -1;
+            }
+            // the block after the next one, into the registers just consumed — BEFORE this block's stores: the memory counter is in
+            // order, so a wait for a request covers everything issued before it.  Requests issued behind the previous block's stores (as
+            // a plain prefetch would) make every block wait for a store acknowledge.
+            bi = block_info(blk + 2u);
+            request(bi, raw0, raw1);
+            if (__builtin_expect(chained, 1)) {
                 if (__builtin_expect(__ballot(used && z == 0u) != 0ull, 0)) {
                     fast = false;  // (wave-uniform) the general path below redoes the block
                 } else if (used && !BT_ABLATE(A, 2u)) {  // (2: no finest stores)
-                    typedef uint8_t __attribute__((address_space(1))) * global_wbytes_t;
-                    typedef uint32_t __attribute__((address_space(1))) * global_wu32_t;
-                    global_wbytes_t rowq = (global_wbytes_t)(tile + (b + cr0) * T);  // uniform row pointer + 32-bit lane offset, like the loads
-                    uint32_t so = store_px * 4u;
-                    asm volatile("" : "+v"(so));
+                    const global_wbytes_t rowq = tile_bytes + (b + cr0) * T * 4u;  // uniform row pointer + 32-bit lane offsets, like the loads
 #pragma unroll
-                    for (uint32_t r = 0; r < kRows; r++) {
-                        *(global_wu32_t)(rowq + so) = out[r];
-                        rowq += T * 4u;
-                    }
+                    for (uint32_t r = 0; r < kRows; r++) *(global_wu32_t)(rowq + so[r]) = out[r];
                 }
             }
             if (__builtin_expect(!fast, 0)) {
@@ -1653,7 +1766,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         }
                 }
                 // the fetched values arrive HERE: left pending, the compiler would guard the reductions below — which the fast path
-                // shares — with a wait for every memory operation in flight, the next block's requests included
+                // shares — with a wait for every memory operation in flight, the next blocks' requests included
 #pragma unroll
                 for (uint32_t r = 0; r < kRows; r++) asm volatile("" : "+v"(out[r]));
             }
@@ -1681,10 +1794,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     q[i] = quad_dpp<0xA0>(v);
                 }
             }
+            {   // centre texels; the parents' aprons come from the tail launch
+                const global_wbytes_t row4 = base4 + (cr0 >> 1) * T * 4u;
 #pragma unroll
-            for (uint32_t i = 0; i < kRows / 2; i++)
-                if (active && (tid & 1u) == 0 && 2 * i + 1 < nrows)  // centre texel; the parents' aprons come from the batched stitch kernel
-                    atlas[uint64_t(self4) * tile_texels + (b + (it.y & 1u) * (c / 2u) + (cr0 >> 1) + i) * T + b + (it.x & 1u) * (c / 2u) + (cx >> 1)] = q[i];
+                for (uint32_t i = 0; i < kRows / 2; i++)
+                    if (active && (tid & 1u) == 0 && 2 * i + 1 < nrows) *(global_wu32_t)(row4 + i * T * 4u + l4) = q[i];
+            }
             if (A.levels < 3 || self3 == kInvalid) return;
             // ---- LOD-2: every lane of a quad holds the quad's two LOD-1 texels of a row (lanes 0, 1 the left, 2, 3 the right)
             uint32_t w[kRows / 4];
@@ -1704,16 +1819,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 for (uint32_t j = 0; j < kRows / 4; j++)
                     w[j] = downsample4_rgba8(quad_dpp<0x00>(q[2 * j]), quad_dpp<0x00>(q[2 * j + 1]), quad_dpp<0xAA>(q[2 * j]), quad_dpp<0xAA>(q[2 * j + 1]));
             }
+            {
+                const global_wbytes_t row3 = base3 + (cr0 >> 2) * T * 4u;
 #pragma unroll
-            for (uint32_t j = 0; j < kRows / 4; j++)
-                if (active && (tid & 3u) == 0 && 4 * j + 3 < nrows)
-                    atlas[uint64_t(self3) * tile_texels + (b + (it.y & 3u) * (c / 4u) + (cr0 >> 2) + j) * T + b + (it.x & 3u) * (c / 4u) + (cx >> 2)] = w[j];
+                for (uint32_t j = 0; j < kRows / 4; j++)
+                    if (active && (tid & 3u) == 0 && 4 * j + 3 < nrows) *(global_wu32_t)(row3 + j * T * 4u + l3) = w[j];
+            }
         };
-        request(blk_begin, set_a0, set_a1);
-        for (uint32_t blk = blk_begin; blk < blk_end; blk += 2u) {
-            block(blk, set_a0, set_a1, set_b0, set_b1);
-            if (blk + 1u < blk_end) block(blk + 1u, set_b0, set_b1, set_a0, set_a1);
+        if (BT_ABLATE(A, 16u)) continue;  // (16: set-up and aprons only — timing experiment)
+        info_a = block_info(blk_begin);
+        request(info_a, set_a0, set_a1);
+        info_b = block_info(blk_begin + 1u);
+        request(info_b, set_b0, set_b1);
+        for (uint32_t blk = blk_begin;;) {  // (no path from one use of a set to its next use without the other set's block in between: the counted waits rely on it)
+            block(blk, info_a, set_a0, set_a1);
+            if (++blk >= blk_end) break;
+            block(blk, info_b, set_b0, set_b1);
+            if (++blk >= blk_end) break;
         }
+        stamp(2u + cx0 / 256u);
     }
 
     // the tile's own apron: stitch.wgsl:53-118 with the neighbour's centre pixel evaluated from the source (its own
@@ -1743,6 +1867,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const uint32_t qy = have ? uint32_t(int(py) - int(b) - ry * int(c)) : min(max(py, b), b + c - 1u) - b;
         tile[py * T + px] = rgba8_value_slow(A, raster, sx, qx, sy, qy, have ? n : it.atlas_index);
     }
+    stamp(4);
 }
 
 // exhaustive device check of the fast unorm conversion against correctly rounded division
