@@ -35,7 +35,7 @@ INVALID_ATLAS_INDEX = 0xFFFFFFFF
 MAX_ATTACHMENTS = 8
 
 BT_OK = 0
-RUN_AUTO, RUN_GENERIC, RUN_KEEP_QUEUE, RUN_PROFILE, RUN_SHARD_LOCAL, RUN_SHARD_FINISH, RUN_SHARD_DISTRIBUTED, RUN_SHARD_EXCHANGE, RUN_SHARD_OVERLAP = 0, 1, 2, 4, 8, 16, 32, 64, 128
+RUN_AUTO, RUN_GENERIC, RUN_KEEP_QUEUE, RUN_PROFILE, RUN_SHARD_LOCAL, RUN_SHARD_FINISH, RUN_SHARD_DISTRIBUTED, RUN_SHARD_EXCHANGE, RUN_SHARD_OVERLAP, RUN_REFERENCE_DISPATCH = 0, 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 
 class BtError(RuntimeError):

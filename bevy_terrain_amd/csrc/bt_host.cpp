@@ -317,7 +317,7 @@ bt_status bt_atlas_create(bt_ctx* ctx, const bt_terrain_config* config, bt_atlas
         }
         // pixel sizes: terrain_data/mod.rs:77-84
         const uint32_t px = c.format == BT_FORMAT_R16 ? 2 : c.format == BT_FORMAT_RGB8 ? 3 : 4;
-        at.meta = {c.format, c.texture_size, c.border_size, c.texture_size - 2 * c.border_size, config->atlas_size, px};
+        at.meta = {c.format, c.texture_size, c.border_size, c.texture_size - 2 * c.border_size, config->atlas_size, px, c.texture_size};
         at.tile_bytes = uint64_t(c.texture_size) * c.texture_size * px;
         const size_t bytes = size_t(at.tile_bytes) * config->atlas_size;
         hipError_t e = hipMalloc(&at.level0, bytes ? bytes : 1);
@@ -1458,7 +1458,7 @@ bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* a, const ch
     }
     BT_HIP(hipSetDevice(p->ctx->device));
     bt_stream_stats st{};
-    if (bt_status s = ensure_compiled(p, a, flags & BT_RUN_GENERIC)) return s;
+    if (bt_status s = ensure_compiled(p, a, flags & (BT_RUN_GENERIC | BT_RUN_REFERENCE_DISPATCH))) return s;
     // streamable: the plan starts with ONE fused main launch over one deferred host raster (planar job, one attachment)
     int32_t raster = -1;
     std::vector<StreamBand> bands;
@@ -1477,7 +1477,7 @@ bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* a, const ch
         p->saves_recorded = true;
     }
     if (!streamable) {  // the same result, one leg after the other
-        if (bt_status s = bt_preprocessor_run(p, a, (flags & BT_RUN_GENERIC) | BT_RUN_KEEP_QUEUE)) return s;
+        if (bt_status s = bt_preprocessor_run(p, a, (flags & (BT_RUN_GENERIC | BT_RUN_REFERENCE_DISPATCH)) | BT_RUN_KEEP_QUEUE)) return s;
         if (bt_status s = bt_preprocessor_save(p, a, assets_root)) return s;
         if (out) *out = st;
         return (flags & BT_RUN_KEEP_QUEUE) ? BT_OK : release_queue(p);

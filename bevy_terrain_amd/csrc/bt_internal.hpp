@@ -56,6 +56,7 @@ struct AttachmentMeta {
     uint32_t center_size;   // c = T - 2b
     uint32_t atlas_size;    // layers
     uint32_t pixel_size;    // bytes
+    uint32_t row_limit;     // rows [0, row_limit) of a tile are written by the batched kernels: T, or (T / 8) * 8 under BT_RUN_REFERENCE_DISPATCH
 };
 
 struct RasterDev {

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void split_kernel(AttachmentMeta m, void* __re
     const bool consecutive = __builtin_amdgcn_readfirstlane(s_consecutive) != 0;
     auto store = [&](uint32_t py, uint32_t ex, const uint32_t (&texels)[kPer], const bool (&keep)[kPer]) {
         // a pixel whose footprint has no data keeps what the atlas holds (split.wgsl:37-42): it is not stored
+        if (py >= m.row_limit) return;  // (BT_RUN_REFERENCE_DISPATCH: rows the reference never dispatches)
         if constexpr (FORMAT == BT_FORMAT_R16) {
             if (!keep[0] && !keep[1]) ((uint32_t*)tile)[(uint64_t(py) * Tsz) / 2 + ex] = texels[0] | (texels[1] << 16);
             else if (!keep[0]) tile[uint64_t(py) * Tsz + 2 * ex] = T(texels[0]);
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(256) void downsample_kernel(AttachmentMeta m, void*
             const T* child = layer < m.atlas_size ? base + uint64_t(layer) * Tsz * Tsz : nullptr;
             texels[k] = downsample_texel<FORMAT>(child, Tsz, 2u * (tx % child_size) + b, 2u * (ty % child_size) + b);
         }
+        if (py >= m.row_limit) continue;
         if constexpr (FORMAT == BT_FORMAT_R16)
             ((uint32_t*)tile)[(uint64_t(py) * Tsz) / 2 + ex] = texels[0] | (texels[1] << 16);
         else
@@ -389,6 +391,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(AttachmentMeta m, void* __r
         py = b + j / (2u * b);
         px = k < b ? k : (c + k);
     }
+    if (py >= m.row_limit) return;
     if (task.regions) {
         const uint32_t o = b + c;
         const int rx = px < b ? -1 : (px >= o ? 1 : 0), ry = py < b ? -1 : (py >= o ? 1 : 0);
@@ -417,6 +420,7 @@ __global__ __launch_bounds__(256) void stitch_region_kernel(AttachmentMeta m, vo
     T* atlas = (T*)atlas_;
     for (uint32_t i = threadIdx.x; i < (w / kPack) * h; i += 256u) {
         const uint32_t px = x0 + kPack * (i % (w / kPack)), py = y0 + i / (w / kPack);
+        if (py >= m.row_limit) continue;
         uint32_t v[kPack];
 #pragma unroll
         for (uint32_t e = 0; e < kPack; e++) {
@@ -451,6 +455,7 @@ __global__ __launch_bounds__(256) void stitch_pairs_kernel(AttachmentMeta m, uin
         py = b + j / b;
         px = k < b / 2u ? 2u * d : o + 2u * d;
     }
+    if (py >= m.row_limit) return;
     if (task.regions) {  // a pair lies in one region (b even)
         const int rx = px < b ? -1 : (px >= o ? 1 : 0), ry = py < b ? -1 : (py >= o ? 1 : 0);
         const uint32_t region = ry < 0 ? (rx < 0 ? 4u : (rx > 0 ? 5u : 0u)) : (ry > 0 ? (rx < 0 ? 7u : (rx > 0 ? 6u : 2u)) : (rx > 0 ? 1u : 3u));

@@ -108,6 +108,11 @@ bt_status ensure_device_array(void** ptr, size_t* cap, size_t bytes) {
 namespace bt {
 // queue -> launch plan (once per queue and mode)
 bt_status ensure_compiled(bt_preprocessor* p, bt_atlas* a, uint32_t mode) {
+    if (mode & BT_RUN_REFERENCE_DISPATCH) {  // only attachments with T % 8 != 0 behave differently: without one in the queue the flag is dropped
+        bool odd = false;
+        for (const Task& t : p->queue) odd = odd || a->attachments[t.attachment_index].meta.texture_size % 8u != 0;
+        if (!odd) mode &= ~uint32_t(BT_RUN_REFERENCE_DISPATCH);
+    }
     if (!p->compiled || p->compiled_flags != mode) {
         std::vector<TaskDev> tasks;
         p->plan.clear();
@@ -158,13 +163,15 @@ bt_status ensure_compiled(bt_preprocessor* p, bt_atlas* a, uint32_t mode) {
 
 bt_status run_plan_entry(bt_preprocessor* p, bt_atlas* a, const Launch& l) {
     const Attachment& at = a->attachments[l.attachment];
+    AttachmentMeta meta = at.meta;
+    if (p->compiled_flags & BT_RUN_REFERENCE_DISPATCH) meta.row_limit = meta.texture_size / 8u * 8u;  // (gpu_tile_atlas.rs:105)
     switch (l.kind) {
         case kLaunchSplit:
-            return launch_split(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count, p->rasters_dev);
+            return launch_split(p->ctx, meta, at.level0, p->tasks_dev + l.first_task, l.task_count, p->rasters_dev);
         case kLaunchDownsample:
-            return launch_downsample(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count);
+            return launch_downsample(p->ctx, meta, at.level0, p->tasks_dev + l.first_task, l.task_count);
         case kLaunchStitch:
-            return launch_stitch(p->ctx, at.meta, at.level0, p->tasks_dev + l.first_task, l.task_count, l.aux0 == 1u, l.aux0 == 2u);
+            return launch_stitch(p->ctx, meta, at.level0, p->tasks_dev + l.first_task, l.task_count, l.aux0 == 1u, l.aux0 == 2u);
         default:
             return fused_launch(p, a, l);
     }
@@ -178,7 +185,7 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
         return BT_ERR_INVALID_ARGUMENT;
     }
     BT_HIP(hipSetDevice(p->ctx->device));
-    const uint32_t mode = flags & BT_RUN_GENERIC;
+    const uint32_t mode = flags & (BT_RUN_GENERIC | BT_RUN_REFERENCE_DISPATCH);
     if (bt_status s = ensure_compiled(p, a, mode)) return s;
     if (bt_status s = upload_pending_rasters(p)) return s;  // rasters handed over with BT_RASTER_HOST_DEFERRED (sharded: this rank's window of them)
 
@@ -300,7 +307,7 @@ extern "C" bt_status bt_preprocessor_source_window(bt_preprocessor* p, bt_atlas*
         set_error("raster %u of %zu", raster_index, p->rasters.size());
         return BT_ERR_INVALID_ARGUMENT;
     }
-    if (bt_status s = ensure_compiled(p, a, flags & BT_RUN_GENERIC)) return s;
+    if (bt_status s = ensure_compiled(p, a, flags & (BT_RUN_GENERIC | BT_RUN_REFERENCE_DISPATCH))) return s;
     if (!fused_source_window(p, raster_index, window)) {
         window[0] = window[1] = 0;
         window[2] = p->rasters[raster_index].dev.width;

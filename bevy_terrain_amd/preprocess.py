@@ -183,9 +183,11 @@ class Preprocessor:
         return dict(zip(("split", "stitch", "downsample", "save", "barrier"), list(counts)))
 
     def run(self, tile_atlas: TileAtlas, *, generic: bool = False, keep_queue: bool = False, sync: bool = True,
-            profile: bool = False) -> "Preprocessor":
+            profile: bool = False, reference_dispatch: bool = False) -> "Preprocessor":
+        """reference_dispatch: leave the last texture_size % 8 rows of every tile unwritten, as the reference's dispatch of
+        texture_size / 8 workgroup rows does (gpu_tile_atlas.rs:105); default: every row is processed."""
         flags = ((_ffi.RUN_GENERIC if generic else 0) | (_ffi.RUN_KEEP_QUEUE if keep_queue else 0)
-                 | (_ffi.RUN_PROFILE if profile else 0))
+                 | (_ffi.RUN_PROFILE if profile else 0) | (_ffi.RUN_REFERENCE_DISPATCH if reference_dispatch else 0))
         _ffi.check(_ffi.lib().bt_preprocessor_run(self._handle(tile_atlas), tile_atlas._h, flags))
         if sync:
             self._device.synchronize()
@@ -193,11 +195,12 @@ class Preprocessor:
             self._keep.clear()
         return self
 
-    def run_streamed(self, tile_atlas: TileAtlas, assets_root: str = "assets", *, generic: bool = False, keep_queue: bool = False) -> dict:
+    def run_streamed(self, tile_atlas: TileAtlas, assets_root: str = "assets", *, generic: bool = False, keep_queue: bool = False,
+                     reference_dispatch: bool = False) -> dict:
         """run() + save() as one overlapped pipeline (bt_preprocessor_run_streamed): upload of deferred host rasters, kernels,
         downloads and file writes at the same time where the plan allows it.  Returns {"streamed": bool, "bands": n}."""
         st = _ffi.StreamStatsC()
-        flags = (_ffi.RUN_GENERIC if generic else 0) | (_ffi.RUN_KEEP_QUEUE if keep_queue else 0)
+        flags = (_ffi.RUN_GENERIC if generic else 0) | (_ffi.RUN_KEEP_QUEUE if keep_queue else 0) | (_ffi.RUN_REFERENCE_DISPATCH if reference_dispatch else 0)
         _ffi.check(_ffi.lib().bt_preprocessor_run_streamed(self._handle(tile_atlas), tile_atlas._h, assets_root.encode(), flags, C.byref(st)))
         if not keep_queue:
             self._keep.clear()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-/* 4 (round 4): + bt_frame_update / bt_frame_info, BT_RUN_SHARD_OVERLAP + bt_preprocessor_finish_sharded, bt_preprocessor_source_window; the fused plan no longer has a fused_todo launch (kind 6 of bt_launch_profile
+/* 4 (round 4): + bt_frame_update / bt_frame_info, BT_RUN_SHARD_OVERLAP + bt_preprocessor_finish_sharded, bt_preprocessor_source_window, BT_RUN_REFERENCE_DISPATCH; the fused plan no longer has a fused_todo launch (kind 6 of bt_launch_profile
  * does not occur any more) — additions only.
  * 3 (round 3): + bt_preprocessor_run_streamed, BT_RASTER_HOST_DEFERRED, BT_RUN_SHARD_EXCHANGE, bt_tiling_prepass_run_plain /
  * _run_unordered / _set_window, launch kind 6 (fused todo) in bt_launch_profile — additions only, every version-2 call keeps its
@@ -279,6 +279,11 @@ enum {
                                     * finishing kernels come with bt_preprocessor_finish_sharded.  In between the caller runs the
                                     * local phase of another job (its own preprocessor + atlas): the collective of step k hides
                                     * behind the kernels of step k + 1 */
+    BT_RUN_REFERENCE_DISPATCH = 256, /* bt_preprocessor_run / _run_streamed: reproduce the reference's dispatch for texture sizes
+                                    * that are not multiples of 8 — it launches texture_size / 8 workgroup rows of 8 x 8
+                                    * (src/terrain_data/gpu_tile_atlas.rs:105), so split, downsample and stitch never write the
+                                    * last texture_size % 8 rows of a tile (they keep what the atlas held).  Default: every row is
+                                    * processed.  No effect on attachments whose texture size is a multiple of 8 */
 };
 /* Replaces select_ready_tasks + GpuPreprocessor::prepare + TerrainPreprocessNode::run for the whole
  * queue: enqueues every kernel on the context's stream and returns (asynchronous).  Save tasks are

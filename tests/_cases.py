@@ -34,7 +34,7 @@ def smooth_raster(h, w, seed, device=None):
     return M.fbm_u16(w, h, seed)
 
 
-def product_planar(device, src, lod_count, T, b, fmt, atlas_size=128, generic=False, mips=1, **ds):
+def product_planar(device, src, lod_count, T, b, fmt, atlas_size=128, generic=False, mips=1, reference_dispatch=False, **ds):
     cfg = bt.TerrainConfig(lod_count=lod_count, atlas_size=atlas_size, path="terrains/test",
                            model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
     cfg.add_attachment(bt.AttachmentConfig(name="att", texture_size=T, border_size=b, format=FMT[fmt],
@@ -43,7 +43,7 @@ def product_planar(device, src, lod_count, T, b, fmt, atlas_size=128, generic=Fa
     server = bt.AssetServer().insert("src", src)
     pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_tile(
         bt.PreprocessDataset(attachment_index=0, path="src", lod_range=range(0, lod_count), **ds), server, atlas)
-    pre.run(atlas, generic=generic)
+    pre.run(atlas, generic=generic, reference_dispatch=reference_dispatch)
     return atlas, pre
 
 

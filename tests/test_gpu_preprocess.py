@@ -675,3 +675,24 @@ def test_config5_cube_albedo_full_size(device):
         data = atlas.download_tiles(0, first, count)
         for k in range(count):
             assert np.array_equal(data[k], oracle.tile(0, first + k)), (first + k, oracle.tiles()[first + k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", [O.FORMAT_R16, O.FORMAT_RGBA8])
+@pytest.mark.parametrize("T, b, holes", [(20, 2, 0.0), (44, 4, 0.03), (30, 1, 0.0)])
+def test_reference_dispatch_flag_reproduces_the_unwritten_rows(device, fmt, T, b, holes):
+    """BT_RUN_REFERENCE_DISPATCH: for a texture size that is not a multiple of 8 the reference dispatches texture_size / 8
+    workgroup rows (gpu_tile_atlas.rs:105) and never writes the last texture_size % 8 rows of a tile; stitch then copies
+    those unwritten rows into the neighbours' top aprons.  With the flag the product's tiles are the executed WGSL's byte for
+    byte (all three shaders, 3 LODs); without it every row is processed (the default, DESIGN.md section 2 finding 1)."""
+    lods = 3
+    src = K.random_raster(fmt, 150, 170, 77 + T, holes)
+    ref = K.reference_kernels(O.OracleAtlas(lods, 128, False, [(T, b, 1, fmt)]))
+    ref.clear_attachment(0).preprocess_tile(0, src, (0, lods)).run(4)
+    atlas, _ = K.product_planar(device, src, lods, T, b, fmt, reference_dispatch=True)
+    assert K.assert_atlas_equal(atlas, ref) == 21
+    covered = T // 8 * 8
+    data = atlas.download_tiles(0, 0, 21)
+    assert not data[:, covered:].any()  # the rows nobody wrote still hold the cleared atlas
+    full, _ = K.product_planar(device, src, lods, T, b, fmt)
+    assert full.download_tiles(0, 0, 21)[:, covered:].any()
