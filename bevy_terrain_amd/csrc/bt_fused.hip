@@ -593,7 +593,9 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     auto dma_issue = [&](uint16_t* s_dst, int ymin, uint32_t slots) {
         static_assert(!kDma || kP == 528, "the DMA variant assumes 1056-byte LDS rows");
         const lds_bytes dst = (lds_bytes)reinterpret_cast<uint8_t*>(s_dst);
-        for (uint32_t slot = tid >> 6; slot < slots; slot += 4u) {  // wave-uniform
+        // (the wave index through v_readfirstlane: as a function of tid the row pointer was computed per lane — two 64-bit vector
+        // multiply-adds per row; every instruction, scalar or vector, takes a turn of the SIMD's one issue port: tools/issue_probe.hip)
+        for (uint32_t slot = uint32_t(__builtin_amdgcn_readfirstlane(int(tid >> 6))); slot < slots; slot += 4u) {
             const global_bytes row = data + uint64_t(uint32_t(ymin) + slot) * raster.pitch;
             if (BT_ABLATE(A, 32768u))  // (32768: the non-temporal policy on the source stream — timing experiment)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + dma_off_main),
@@ -657,7 +659,6 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     u32x4 pre[kBatch];
     window(k_begin, ymin, slots);
     if constexpr (kDma) {
-        if (tid == 0) S.nodata[0][0] = S.nodata[1][0] = 0;
         dma_issue(s_buf + (k_begin & 1u) * buf_texels, ymin, slots);
         nodata = false;
     } else if (kStaged && !BT_ABLATE(A, 8u)) {
@@ -819,13 +820,6 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                 dma_issue(s_buf + ((k + 1) & 1u) * buf_texels, next_ymin, next_slots);
             }
             else if (kStaged && wide && !BT_ABLATE(A, 8u)) stage_issue(next_ymin, next_slots, pre);
-        }
-        // kDma: the chunk before this one was flagged by some thread: note it for the redo (once), clear the flag
-        if constexpr (kDma) {
-            if (tid == 0 && k > k_begin && S.nodata[(k - 1u) & 1u][0]) {
-                S.nodata[(k - 1u) & 1u][0] = 0;
-                flag_chunk(k - 1u);
-            }
         }
         dirty = 0;
 
@@ -1093,7 +1087,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         }
 
         if constexpr (kDma) {
-            if (dirty) S.nodata[k & 1u][0] = 1;  // read and cleared by thread 0 after the barrier
+            if (dirty) atomicOr(&S.redo[(k - k_begin) >> 5], 1u << ((k - k_begin) & 31u));  // (rare: straight into the mask the redo reads behind the loop)
         }
         if (!more) break;
         // chunk k + 1 goes into the other staging buffer (nobody reads it any more: its last readers passed the
@@ -1106,10 +1100,6 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         ymin = next_ymin;
         slots = next_slots;
         has_nodata = any_nodata(nodata, (k + 1) & 1u);
-    }
-    if constexpr (kDma) {  // the last chunk's flag
-        __syncthreads();
-        if (tid == 0 && k_end > k_begin && S.nodata[(k_end - 1u) & 1u][0]) flag_chunk(k_end - 1u);
     }
     if constexpr (kStaged && !kGeneric) {
         // ---- redo of the flagged chunks with the generic rows: stage the window once more (nobody reads LDS any more), run the
@@ -1535,7 +1525,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // per block of the workgroup (+ 2: requests run two blocks ahead): chain = 0 if the block takes the general path, else 0x100 |
     // bit r = (source row r + 1 of the block is one further down than row r); the block's first / last source row
     struct BlockInfo {
-        int chain, y_first, y_last, pad;
+        int chain, y_first, y_last;
+        uint32_t byte_lo, byte_hi;  // y_first x the raster's pitch
+        int pad[3];
     };
     __shared__ Axis s_ay[kDirectMaxBlocks * kRows];
     __shared__ float2 s_wy[kDirectMaxBlocks * kRows];  // (fy, 1 - fy) of the row: read at a uniform address, used from vector registers
@@ -1549,7 +1541,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (tid < kDirectMaxBlocks + 2) {
         // the fast path rolls over a chain of kRows + 1 source rows: row r's lower source row is row r + 1's upper one, and a pair is
         // one row apart — or the same row, where the source's first / last row is clamped (the tiles along the raster's top and bottom)
-        BlockInfo bi = BlockInfo{0, 0, -1, 0};
+        BlockInfo bi = BlockInfo{0, 0, -1, 0u, 0u, {0, 0, 0}};
         if (blk_begin + tid < blk_end && (blk_begin + tid) * kRows + kRows <= c) {
             const Axis* ay = s_ay + tid * kRows;
             bool ok = true;
@@ -1559,7 +1551,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 ok = (d == 0 || d == 1) && (r == 0 || ay[r].i0 == ay[r - 1].i1);
                 chain |= d << r;
             }
-            if (ok) bi = BlockInfo{chain, ay[0].i0, ay[kRows - 1].i1, 0};
+            const uint64_t bytes = uint64_t(uint32_t(ay[0].i0)) * raster.pitch;
+            if (ok) bi = BlockInfo{chain, ay[0].i0, ay[kRows - 1].i1, uint32_t(bytes), uint32_t(bytes >> 32), {0, 0, 0}};
         }
         s_blk[tid] = bi;
     }
@@ -1635,15 +1628,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         uint32_t carry_z = 0;
         int carry_row = -1;  // (wave-uniform) the source row carry_top was blended from; -1: none
         auto block_info = [&](uint32_t blk) -> BlockInfo {  // (wave-uniform; blk < blk_begin + kDirectMaxBlocks + 2)
-            const BlockInfo v = s_blk[blk - blk_begin];
-            return BlockInfo{__builtin_amdgcn_readfirstlane(v.chain), __builtin_amdgcn_readfirstlane(v.y_first), __builtin_amdgcn_readfirstlane(v.y_last), 0};
+            const BlockInfo* v = s_blk + (blk - blk_begin);
+            return BlockInfo{__builtin_amdgcn_readfirstlane(v->chain), __builtin_amdgcn_readfirstlane(v->y_first), __builtin_amdgcn_readfirstlane(v->y_last),
+                             uint32_t(__builtin_amdgcn_readfirstlane(int(v->byte_lo))), uint32_t(__builtin_amdgcn_readfirstlane(int(v->byte_hi))), {0, 0, 0}};
         };
         // Always 2 x (kRows + 1) loads, whatever the block: the hand-counted waits below rely on it.  A block that takes the general
         // path (chain 0) gets row 0 kRows + 1 times into registers nobody reads.  Issued from assembly and waited for by hand
         // (arrived() below): the compiler's own counted waits assume the fewest operations in flight over all paths of this control
         // flow and end up waiting for the other set and for the stores as well.
         auto request = [&](const BlockInfo& bi, uint32_t (&d0)[kRows + 1], uint32_t (&d1)[kRows + 1]) {
-            global_bytes_t rowp = data + uint64_t(uint32_t(bi.y_first)) * raster.pitch;
+            global_bytes_t rowp = data + (uint64_t(bi.byte_lo) | uint64_t(bi.byte_hi) << 32);
             if (BT_ABLATE(A, 8u)) {  // (8: no source loads)
 #pragma unroll
                 for (uint32_t j = 0; j <= kRows; j++) {
@@ -1732,7 +1726,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 } else if (used && !BT_ABLATE(A, 2u)) {  // (2: no finest stores)
                     const global_wbytes_t rowq = tile_bytes + (b + cr0) * T * 4u;  // uniform row pointer + 32-bit lane offsets, like the loads
 #pragma unroll
-                    for (uint32_t r = 0; r < kRows; r++) *(global_wu32_t)(rowq + so[r]) = out[r];
+                    for (uint32_t r = 0; r < kRows; r++)  // (written out: the compiler widened the lane offsets to 64-bit vector additions)
+                        asm volatile("global_store_dword %0, %1, %2" ::"v"(so[r]), "v"(out[r]), "s"(rowq) : "memory");
                 }
             }
             if (__builtin_expect(!fast, 0)) {
@@ -1796,9 +1791,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
             {   // centre texels; the parents' aprons come from the tail launch
                 const global_wbytes_t row4 = base4 + (cr0 >> 1) * T * 4u;
+                if (active && (tid & 1u) == 0) {
 #pragma unroll
-                for (uint32_t i = 0; i < kRows / 2; i++)
-                    if (active && (tid & 1u) == 0 && 2 * i + 1 < nrows) *(global_wu32_t)(row4 + i * T * 4u + l4) = q[i];
+                    for (uint32_t i = 0; i < kRows / 2; i++)
+                        if (2 * i + 1 < nrows) *(global_wu32_t)(row4 + i * T * 4u + l4) = q[i];
+                }
             }
             if (A.levels < 3 || self3 == kInvalid) return;
             // ---- LOD-2: every lane of a quad holds the quad's two LOD-1 texels of a row (lanes 0, 1 the left, 2, 3 the right)
