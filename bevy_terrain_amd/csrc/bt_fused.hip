@@ -429,6 +429,17 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     // instruction immediates in the static fast path
     const uint32_t T = kT ? kT : A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
     const uint32_t tid = threadIdx.x;
+#ifdef BT_DEBUG_HOOKS
+    // (134217728: real-time (100 MHz) stamps per WORKGROUP — entry, prologue done, chunk loop done, end — behind the per-tile stamps in
+    // the atlas's last layer; tools/main_probe.py)
+    auto wg_stamp = [&](uint32_t slot) {
+        if (BT_ABLATE(A, 134217728u) && tid == 0 && blockIdx.x < 4096u)
+            reinterpret_cast<unsigned long long*>(A.atlas + uint64_t(A.m.atlas_size - 1u) * T * T)[16384u + blockIdx.x * 4u + slot] = __builtin_amdgcn_s_memrealtime();
+    };
+#else
+    auto wg_stamp = [&](uint32_t) {};
+#endif
+    wg_stamp(0);
     const float scale = float(1u << A.lod);
     const uint32_t tile_texels = T * T;
     const uint32_t chunks_per_tile = (c + kMainRows - 1) / kMainRows;
@@ -802,6 +813,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     };
 
     bool has_nodata = any_nodata(nodata, k_begin & 1u);
+    wg_stamp(1);
 
     for (uint32_t k = k_begin; k < k_end; k++) {
         const int* row_y0 = S.row_y0 + (k - k_begin) * kMainRows;
@@ -1101,6 +1113,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         slots = next_slots;
         has_nodata = any_nodata(nodata, (k + 1) & 1u);
     }
+    wg_stamp(2);
     if constexpr (kStaged && !kGeneric) {
         // ---- redo of the flagged chunks with the generic rows: stage the window once more (nobody reads LDS any more), run the
         // apron rows and the rows with validity.  Clean inputs pay one barrier and one LDS read per tile.
@@ -1133,6 +1146,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     if (BT_ABLATE(A, 134217728u) && tid == 0)
         reinterpret_cast<unsigned long long*>(A.atlas + uint64_t(A.m.atlas_size - 1u) * tile_texels)[item_index * 8u + 4u] = __builtin_amdgcn_s_memrealtime();
 #endif
+    wg_stamp(3);
 }
 
 // fast / non-staged variants: workgroup = (tile, part of its chunks), XCD-contiguous order
