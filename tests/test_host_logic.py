@@ -136,3 +136,16 @@ def test_c99_consumer_of_the_header_and_ctypes_mirror_layouts(tmp_path):
             assert (d.offset, d.size) == (offset, size), (name, field)
             checked += 1
     assert checked > 80
+
+
+def test_run_flags_of_the_binding_are_the_header_s():
+    """the BT_RUN_* values of include/bevy_terrain_amd.h, parsed from the text, against the constants the Python binding passes"""
+    import re
+
+    from bevy_terrain_amd import _ffi
+
+    text = open(_ffi.HEADER_PATH).read()
+    header = {m.group(1): int(m.group(2)) for m in re.finditer(r"\bBT_RUN_([A-Z_]+)\s*=\s*(\d+)", text)}
+    assert len(header) == 10 and header["REFERENCE_DISPATCH"] == 256
+    for name, value in header.items():
+        assert getattr(_ffi, "RUN_" + name) == value, name
