@@ -141,7 +141,7 @@ def test_streaming_loop_entries_and_heights(device, tmp_path, kind, atlas_size):
         # TileTree::approximate_height + a batch of sample_height queries around the view
         h = tree.approximate_height()
         _, exp_h = otree.sample_attachment(O.FORMAT_R16, T, b, layers, [pos])
-        assert h == pytest.approx(float(exp_h[0]), rel=1e-5, abs=1e-3), frame
+        assert h == float(exp_h[0]), (frame, h, float(exp_h[0]))
         otree.set_approximate_height(h)  # both sides continue from the same (f32) value
         if kind == "planar":
             pts = np.column_stack([rng.uniform(-480, 480, 64) + 10.0, rng.uniform(0, 300, 64), rng.uniform(-480, 480, 64) + 3.0])
@@ -149,10 +149,10 @@ def test_streaming_loop_entries_and_heights(device, tmp_path, kind, atlas_size):
             pts = np.asarray(pos) + rng.normal(size=(64, 3)) * 4.0e5
         ours, ours_h = tree.sample_attachment(0, pts)
         exp, exp_heights = otree.sample_attachment(O.FORMAT_R16, T, b, layers, pts)
-        # compute_blend's log2 is OCML on the device and libm in the oracle: the blend ratio may differ in its last
-        # bits; the values are unorm heights in [0, 1]
-        assert np.allclose(ours, exp, rtol=1e-5, atol=2e-6), (frame, np.abs(ours - exp).max())
-        assert np.allclose(ours_h, exp_heights, rtol=1e-5, atol=0.05)
+        # compute_blend's f64 log2 is OCML's on the device and libm's in the oracle (<= 1 ULP of a double apart): its conversion
+        # to f32 absorbs that except within 2^-29 of a rounding boundary — with these fixed seeds every value is bit-equal
+        assert np.array_equal(ours, exp), (frame, np.abs(ours - exp).max(), int((ours != exp).sum()))
+        assert np.array_equal(ours_h, exp_heights), (frame, np.abs(ours_h - exp_heights).max())
     assert loaded_total > 20
     if atlas_size == 40:
         assert evictions > 0
