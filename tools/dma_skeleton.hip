@@ -213,6 +213,67 @@ template <int ARITH, bool LOADER_WAVE, bool NTL = false, bool NTS = false> __glo
     }
 }
 
+// ------------------------------------------------------------------------------------------------ V1 with 16-row chunks
+// (round 4: VERDICT r03 suggested 16-row chunks at four workgroups per CU.)  One chunk ahead like the product: a ring of 36 rows
+// (chunk k's 18 + the 16 new rows of chunk k + 1) = 38 KB, four workgroups per CU; 32 barriers per tile instead of 64, 16 + 8
+// stores per thread behind every DMA group.
+constexpr uint32_t kRing16 = 36, kTailBase16 = kRing16 * kRowMain;
+template <int ARITH> __global__ __launch_bounds__(256) void v16(const uint8_t* src, uint8_t* tiles, uint8_t* parents, int stores) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kRing16 * (kRowMain + kRowTail)];
+    uint32_t tx, ty;
+    tile_of(tx, ty);
+    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    const gbytes base = (gbytes)src + uint64_t(ty) * 512 * kPitch + uint64_t(tx) * 1024;
+    const lbytes ring = (lbytes)lds;
+    auto dma_rows = [&](uint32_t y_begin, uint32_t count) {  // wave w moves rows w, w + 4, ... of the group; lanes 0, 1 the 32-byte tail
+        for (uint32_t i = wave; i < count; i += 4) {
+            const uint32_t y = y_begin + i, slot = y % kRing16;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(base + uint64_t(y) * kPitch + lane * 16),
+                                             (void __attribute__((address_space(3)))*)(ring + slot * kRowMain), 16, 0, 0);
+            if (lane < 2)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(base + uint64_t(y) * kPitch + 1024 + lane * 16),
+                                                 (void __attribute__((address_space(3)))*)(ring + kTailBase16 + slot * kRowTail), 16, 0, 0);
+        }
+    };
+    dma_rows(0, 18);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    uint32_t* d5 = reinterpret_cast<uint32_t*>(tiles + uint64_t(tx * 32 + ty) * 524288 + 4) + tid;
+    uint32_t* d4 = reinterpret_cast<uint32_t*>(parents + uint64_t((tx / 2) * 16 + ty / 2) * 524288 + uint64_t(ty & 1u) * 262144 + (tx & 1u) * 512 + 4) + (tid >> 1);
+    const uint32_t c0 = 2 * tid, c1 = 2 * tid + 2;
+    auto col = [&](uint32_t c, uint32_t& off, uint32_t& stride) {
+        if (c < 512) { off = c * 2; stride = kRowMain; } else { off = kTailBase16 + (c - 512) * 2; stride = kRowTail; }
+    };
+    uint32_t o00, s00, o01, s01, o10, s10, o11, s11;
+    col(c0, o00, s00); col(c0 + 1, o01, s01); col(c1, o10, s10); col(c1 + 1, o11, s11);
+    for (uint32_t k = 0; k < 32; k++) {
+        if (k + 1 < 32 + 1) dma_rows(16 * k + 18, 16);  // (the last group runs past the tile like the 8-row skeleton's)
+        const uint32_t slot0 = (16 * k) % kRing16;
+        auto tex = [&](uint32_t r, uint32_t off, uint32_t stride) -> uint32_t {
+            uint32_t sl = slot0 + r;
+            sl -= sl >= kRing16 ? kRing16 : 0u;
+            return *reinterpret_cast<const uint16_t*>(lds + off + sl * stride);
+        };
+        f2 carry = {float(tex(0, o00, s00)), float(tex(0, o10, s10))};
+        uint32_t out[16];
+#pragma unroll
+        for (uint32_t r = 0; r < 16; r++) out[r] = shade<ARITH>(tex(r + 1, o00, s00), tex(r + 1, o01, s01), tex(r + 1, o10, s10), tex(r + 1, o11, s11), carry, 0.0625f * float(r));
+        if (stores & 1) {
+#pragma unroll
+            for (uint32_t r = 0; r < 16; r++) d5[(k * 16 + r) * 256] = out[r];
+        }
+        if ((stores & 2) && (tid & 1u) == 0) {
+#pragma unroll
+            for (uint32_t r = 0; r < 8; r++) d4[(k * 8 + r) * 256] = out[2 * r] + out[2 * r + 1];
+        }
+        // the rows of chunk k + 1 were issued BEFORE this chunk's stores: the 16 finest stores may stay in flight
+        if (stores & 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 template <typename F> static float timeit(F f) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -235,6 +296,15 @@ int main(int argc, char** argv) {
     hipMemset(src, 3, 16384ull * kPitch + (1 << 20));
     for (int i = 0; i < 200; i++) v0<0><<<1024, 256>>>(src, tiles, parents, 3);
     hipDeviceSynchronize();
+    if (argc > 1 && !strcmp(argv[1], "rows16")) {  // round 4: 16-row chunks against 8-row chunks (V1), same lease, alternating
+        for (int rep = 0; rep < 3; rep++) {
+            printf("arith  0: 8-row chunks %6.1f   16-row chunks %6.1f us\n", timeit([&] { v12<0, false><<<1024, 256>>>(src, tiles, parents, 3); }), timeit([&] { v16<0><<<1024, 256>>>(src, tiles, parents, 3); }));
+            printf("arith 24: 8-row chunks %6.1f   16-row chunks %6.1f us\n", timeit([&] { v12<24, false><<<1024, 256>>>(src, tiles, parents, 3); }), timeit([&] { v16<24><<<1024, 256>>>(src, tiles, parents, 3); }));
+            printf("arith 48: 8-row chunks %6.1f   16-row chunks %6.1f us\n", timeit([&] { v12<48, false><<<1024, 256>>>(src, tiles, parents, 3); }), timeit([&] { v16<48><<<1024, 256>>>(src, tiles, parents, 3); }));
+            fflush(stdout);
+        }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "nt")) {  // round 4: every source row read once (V1's ring) — does the non-temporal policy pay in the tile-stream pattern?
         for (int rep = 0; rep < 2; rep++) {
             printf("V1 arith  0: plain %6.1f   nt loads %6.1f   nt stores %6.1f   both %6.1f us\n", timeit([&] { v12<0, false, false, false><<<1024, 256>>>(src, tiles, parents, 3); }),
