@@ -274,6 +274,66 @@ template <int ARITH> __global__ __launch_bounds__(256) void v16(const uint8_t* s
     }
 }
 
+// ------------------------------------------------------------------------------------------------ V1 with CH-row chunks, D chunks ahead
+// (the trend of section 10 of the experiments file followed the other way: are SHORTER chunks better?)  Ring of R rows >= CH * (D + 1) + 2.
+template <int ARITH, uint32_t CH, uint32_t D, uint32_t R> __global__ __launch_bounds__(256) void vch(const uint8_t* src, uint8_t* tiles, uint8_t* parents, int stores) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[R * (kRowMain + kRowTail)];
+    constexpr uint32_t kChunks = 512 / CH, kTail = R * kRowMain;
+    uint32_t tx, ty;
+    tile_of(tx, ty);
+    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    const gbytes base = (gbytes)src + uint64_t(ty) * 512 * kPitch + uint64_t(tx) * 1024;
+    const lbytes ring = (lbytes)lds;
+    auto dma_rows = [&](uint32_t y_begin, uint32_t count) {
+        for (uint32_t i = wave; i < count; i += 4) {
+            const uint32_t y = y_begin + i, slot = y % R;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(base + uint64_t(y) * kPitch + lane * 16),
+                                             (void __attribute__((address_space(3)))*)(ring + slot * kRowMain), 16, 0, 0);
+            if (lane < 2)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(base + uint64_t(y) * kPitch + 1024 + lane * 16),
+                                                 (void __attribute__((address_space(3)))*)(ring + kTail + slot * kRowTail), 16, 0, 0);
+        }
+    };
+    dma_rows(0, CH * D + 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    uint32_t* d5 = reinterpret_cast<uint32_t*>(tiles + uint64_t(tx * 32 + ty) * 524288 + 4) + tid;
+    uint32_t* d4 = reinterpret_cast<uint32_t*>(parents + uint64_t((tx / 2) * 16 + ty / 2) * 524288 + uint64_t(ty & 1u) * 262144 + (tx & 1u) * 512 + 4) + (tid >> 1);
+    const uint32_t c0 = 2 * tid, c1 = 2 * tid + 2;
+    auto col = [&](uint32_t c, uint32_t& off, uint32_t& stride) {
+        if (c < 512) { off = c * 2; stride = kRowMain; } else { off = kTail + (c - 512) * 2; stride = kRowTail; }
+    };
+    uint32_t o00, s00, o01, s01, o10, s10, o11, s11;
+    col(c0, o00, s00); col(c0 + 1, o01, s01); col(c1, o10, s10); col(c1 + 1, o11, s11);
+    for (uint32_t k = 0; k < kChunks; k++) {
+        dma_rows(CH * (k + D) + 2, CH);  // the group D chunks ahead (the last ones run past the tile like the other skeletons')
+        const uint32_t slot0 = (CH * k) % R;
+        auto tex = [&](uint32_t r, uint32_t off, uint32_t stride) -> uint32_t {
+            uint32_t sl = slot0 + r;
+            sl -= sl >= R ? R : 0u;
+            return *reinterpret_cast<const uint16_t*>(lds + off + sl * stride);
+        };
+        f2 carry = {float(tex(0, o00, s00)), float(tex(0, o10, s10))};
+        uint32_t out[CH];
+#pragma unroll
+        for (uint32_t r = 0; r < CH; r++) out[r] = shade<ARITH>(tex(r + 1, o00, s00), tex(r + 1, o01, s01), tex(r + 1, o10, s10), tex(r + 1, o11, s11), carry, float(r) / float(CH));
+        if (stores & 1) {
+#pragma unroll
+            for (uint32_t r = 0; r < CH; r++) d5[(k * CH + r) * 256] = out[r];
+        }
+        if ((stores & 2) && (tid & 1u) == 0) {
+#pragma unroll
+            for (uint32_t r = 0; r < CH / 2; r++) d4[(k * (CH / 2) + r) * 256] = out[2 * r] + out[2 * r + 1];
+        }
+        // chunk k + 1's rows were issued D iterations ago (D = 1: this iteration, before the stores): what was issued since may stay in flight
+        if (D >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * (CH / 4 + CH)) : "memory");
+        else if (stores & 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 template <typename F> static float timeit(F f) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -301,6 +361,22 @@ int main(int argc, char** argv) {
             printf("arith  0: 8-row chunks %6.1f   16-row chunks %6.1f us\n", timeit([&] { v12<0, false><<<1024, 256>>>(src, tiles, parents, 3); }), timeit([&] { v16<0><<<1024, 256>>>(src, tiles, parents, 3); }));
             printf("arith 24: 8-row chunks %6.1f   16-row chunks %6.1f us\n", timeit([&] { v12<24, false><<<1024, 256>>>(src, tiles, parents, 3); }), timeit([&] { v16<24><<<1024, 256>>>(src, tiles, parents, 3); }));
             printf("arith 48: 8-row chunks %6.1f   16-row chunks %6.1f us\n", timeit([&] { v12<48, false><<<1024, 256>>>(src, tiles, parents, 3); }), timeit([&] { v16<48><<<1024, 256>>>(src, tiles, parents, 3); }));
+            fflush(stdout);
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "rows")) {  // round 4: chunk height swept, same lease, alternating
+        for (int rep = 0; rep < 2; rep++) {
+            printf("arith  0: V1 (8 rows, 2 ahead) %6.1f | 2 rows x 4 ahead %6.1f | 4 rows x 2 ahead %6.1f | 4 rows x 4 ahead %6.1f | 8 rows x 2 ahead %6.1f | 8 x 1 %6.1f | 16 x 1 %6.1f us\n",
+                   timeit([&] { v12<0, false><<<1024, 256>>>(src, tiles, parents, 3); }), timeit([&] { vch<0, 2, 4, 16><<<1024, 256>>>(src, tiles, parents, 3); }),
+                   timeit([&] { vch<0, 4, 2, 16><<<1024, 256>>>(src, tiles, parents, 3); }), timeit([&] { vch<0, 4, 4, 32><<<1024, 256>>>(src, tiles, parents, 3); }),
+                   timeit([&] { vch<0, 8, 2, 32><<<1024, 256>>>(src, tiles, parents, 3); }), timeit([&] { vch<0, 8, 1, 20><<<1024, 256>>>(src, tiles, parents, 3); }),
+                   timeit([&] { vch<0, 16, 1, 36><<<1024, 256>>>(src, tiles, parents, 3); }));
+            printf("arith 24: V1 (8 rows, 2 ahead) %6.1f | 2 rows x 4 ahead %6.1f | 4 rows x 2 ahead %6.1f | 4 rows x 4 ahead %6.1f | 8 rows x 2 ahead %6.1f | 8 x 1 %6.1f | 16 x 1 %6.1f us\n",
+                   timeit([&] { v12<24, false><<<1024, 256>>>(src, tiles, parents, 3); }), timeit([&] { vch<24, 2, 4, 16><<<1024, 256>>>(src, tiles, parents, 3); }),
+                   timeit([&] { vch<24, 4, 2, 16><<<1024, 256>>>(src, tiles, parents, 3); }), timeit([&] { vch<24, 4, 4, 32><<<1024, 256>>>(src, tiles, parents, 3); }),
+                   timeit([&] { vch<24, 8, 2, 32><<<1024, 256>>>(src, tiles, parents, 3); }), timeit([&] { vch<24, 8, 1, 20><<<1024, 256>>>(src, tiles, parents, 3); }),
+                   timeit([&] { vch<24, 16, 1, 36><<<1024, 256>>>(src, tiles, parents, 3); }));
             fflush(stdout);
         }
         return 0;
