@@ -154,6 +154,7 @@ PROTOTYPES = {
     "bt_ctx_set_stream": (_i32, [_vp, _vp]),
     "bt_ctx_stream": (_vp, [_vp]),
     "bt_ctx_synchronize": (_i32, [_vp]),
+    "bt_ctx_trim": (_i32, [_vp, C.POINTER(C.c_uint64)]),
     "bt_ctx_timer_begin": (_i32, [_vp]),
     "bt_ctx_timer_end": (_i32, [_vp, _P(C.c_float)]),
     "bt_device_malloc": (_i32, [_vp, C.c_size_t, _P(_vp)]),

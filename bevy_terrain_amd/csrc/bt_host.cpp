@@ -238,6 +238,30 @@ bt_status bt_ctx_synchronize(bt_ctx* ctx) {
     return BT_OK;
 }
 
+bt_status bt_ctx_trim(bt_ctx* ctx, uint64_t* freed_bytes) {
+    if (!ctx) return BT_ERR_INVALID_ARGUMENT;
+    BT_HIP(hipSetDevice(ctx->device));
+    BT_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->copy_stream) BT_HIP(hipStreamSynchronize(ctx->copy_stream));
+    if (ctx->save_stream) BT_HIP(hipStreamSynchronize(ctx->save_stream));
+    uint64_t freed = 0;
+    if (ctx->spare_raster) {
+        BT_HIP(hipFree(ctx->spare_raster));
+        freed += ctx->spare_raster_bytes;
+        ctx->spare_raster = nullptr;
+        ctx->spare_raster_bytes = 0;
+    }
+    for (void*& s : ctx->staging)
+        if (s) {
+            BT_HIP(hipHostFree(s));
+            s = nullptr;
+            freed += ctx->staging_bytes;
+        }
+    ctx->staging_bytes = 0;
+    if (freed_bytes) *freed_bytes = freed;
+    return BT_OK;
+}
+
 bt_status bt_ctx_timer_begin(bt_ctx* ctx) {
     if (!ctx) return BT_ERR_INVALID_ARGUMENT;
     BT_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));

@@ -38,6 +38,12 @@ class Device:
     def synchronize(self):
         _ffi.check(_ffi.lib().bt_ctx_synchronize(self._h))
 
+    def trim(self) -> int:
+        """bt_ctx_trim: give back the raster buffer kept for the next queue and the pinned staging buffers; bytes released"""
+        freed = C.c_uint64()
+        _ffi.check(_ffi.lib().bt_ctx_trim(self._h, C.byref(freed)))
+        return freed.value
+
     def timer_begin(self):
         _ffi.check(_ffi.lib().bt_ctx_timer_begin(self._h))
 

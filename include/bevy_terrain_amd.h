@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-/* 4 (round 4): + bt_frame_update / bt_frame_info, BT_RUN_SHARD_OVERLAP + bt_preprocessor_finish_sharded, bt_preprocessor_source_window, BT_RUN_REFERENCE_DISPATCH; the fused plan no longer has a fused_todo launch (kind 6 of bt_launch_profile
+/* 4 (round 4): + bt_frame_update / bt_frame_info, BT_RUN_SHARD_OVERLAP + bt_preprocessor_finish_sharded, bt_preprocessor_source_window, BT_RUN_REFERENCE_DISPATCH, bt_ctx_trim; the fused plan no longer has a fused_todo launch (kind 6 of bt_launch_profile
  * does not occur any more) — additions only.
  * 3 (round 3): + bt_preprocessor_run_streamed, BT_RASTER_HOST_DEFERRED, BT_RUN_SHARD_EXCHANGE, bt_tiling_prepass_run_plain /
  * _run_unordered / _set_window, launch kind 6 (fused todo) in bt_launch_profile — additions only, every version-2 call keeps its
@@ -150,6 +150,10 @@ void bt_ctx_destroy(bt_ctx* ctx);
 bt_status bt_ctx_set_stream(bt_ctx* ctx, void* stream);
 void* bt_ctx_stream(const bt_ctx* ctx);
 bt_status bt_ctx_synchronize(bt_ctx* ctx);
+/* Gives back what the context keeps between queues: the device raster a finished queue released (kept so that the next queue's
+ * source need not be allocated again: 0.5 GB for a 16k R16 raster) and the pinned staging buffers of the save / load paths.
+ * Synchronises the context's stream first.  `freed_bytes` (may be NULL): device + pinned bytes released. */
+bt_status bt_ctx_trim(bt_ctx* ctx, uint64_t* freed_bytes);
 /* hipEvent pair on the context's stream: begin .. end -> elapsed milliseconds (end synchronises) */
 bt_status bt_ctx_timer_begin(bt_ctx* ctx);
 bt_status bt_ctx_timer_end(bt_ctx* ctx, float* elapsed_ms);

@@ -696,3 +696,27 @@ def test_reference_dispatch_flag_reproduces_the_unwritten_rows(device, fmt, T, b
     assert not data[:, covered:].any()  # the rows nobody wrote still hold the cleared atlas
     full, _ = K.product_planar(device, src, lods, T, b, fmt)
     assert full.download_tiles(0, 0, 21)[:, covered:].any()
+
+
+@pytest.mark.gpu
+def test_ctx_trim_gives_back_the_kept_buffers(device, tmp_path):
+    """bt_ctx_trim: a finished queue's device raster (kept for the next queue) and the pinned staging buffers of the save path are
+    released, and the next job allocates them again (same files)."""
+    src = K.smooth_raster(1024, 1024, seed=5)
+    cfg = bt.TerrainConfig(lod_count=3, atlas_size=64, path="terrains/trim", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=256, border_size=2, format=bt.AttachmentFormat.R16))
+    digests = []
+    for rep in range(2):
+        root = str(tmp_path / f"run{rep}")
+        atlas = bt.TileAtlas.new(cfg, device)
+        server = bt.AssetServer().insert("src", src)
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas, root).preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="src", lod_range=range(0, 3)), server, atlas)
+        pre.run(atlas)
+        pre.save(atlas, root)
+        pre.close()
+        d = atlas.attachment_directory(root, 0)
+        digests.append({f: open(os.path.join(d, f), "rb").read() for f in sorted(os.listdir(d))})
+        freed = device.trim()
+        assert freed >= src.nbytes, freed  # the raster + three pinned buffers
+        assert device.trim() == 0
+    assert len(digests[0]) == 21 and digests[0] == digests[1]
