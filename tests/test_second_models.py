@@ -145,3 +145,31 @@ def test_tile_tree_update_model_on_the_random_sweep(seed):
         _, origins, coords, flags = otree.read()
         my_coords, my_flags = mine.node_tables()
         assert np.array_equal(origins, mine.origins) and np.array_equal(coords, my_coords) and np.array_equal(flags, my_flags), (seed, frame)
+
+
+@pytest.mark.parametrize("kind", ["planar", "sphere"])
+def test_view_state_fields_follow_from_the_second_model(kind):
+    """a20 (TileTree::new :133-160, TerrainViewConfigUniform::from_tile_tree, the view coordinates of
+    TerrainModelApproximation::compute :283-285): bt_view_state_from_config against values derived HERE from the numpy model's view
+    coordinate and side projection — not from the oracle's restatement."""
+    model, _ = MODELS[kind]
+    vc = bt.TerrainViewConfig(geometry_tile_count=4321, refinement_count=9, grid_size=12, origin_lod=9, morph_distance=12.5, subdivision_tolerance=0.15)
+    mine = tree_model(kind, 8, 8)
+    scale = float(model.scale_vec[0]) / 2.0 if kind == "planar" else float(model.scale_vec[0])  # TerrainModel::scale (terrain_model.rs:183-193)
+    pts = [tuple(float(v) for v in p) for p in positions(kind, 120, 23)]
+    if kind == "sphere":
+        r = 7.1e6
+        pts += [(r, 0.0, 0.0), (0.0, -r, 0.0), (0.0, 0.0, r), (-r, 0.25 * r, -r), (r, r, r)]
+    for p in pts:
+        v = bt.view_state_from_config(model, vc, p, 77.25)
+        assert (v.spherical, v.geometry_tile_count, v.refinement_count, v.origin_lod) == (int(kind != "planar"), 4321, 9, 9)
+        assert v.vertices_per_tile == 2 * 12 * (12 + 2)
+        assert v.approximate_height == np.float32(77.25)
+        assert v.subdivision_distance == np.float32(12.5 * scale * (1.0 + 0.15))
+        assert tuple(v.world_position) == tuple(np.asarray(p, np.float64).astype(np.float32))
+        side0, uv0 = mine.view_coordinate(p)
+        for side in range(6 if kind != "planar" else 1):
+            uv = mine.project_to_side(side0, uv0, side) * 512.0  # x count(origin_lod)
+            xy = np.trunc(uv)  # as_ivec2
+            assert tuple(v.sides[side].view_xy) == (int(xy[0]), int(xy[1])), (p, side)
+            assert tuple(v.sides[side].view_uv) == tuple((uv - xy).astype(np.float32)), (p, side)  # fract() then as_vec2
