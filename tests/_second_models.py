@@ -102,6 +102,7 @@ class TileTreeModel:
         model_scale = float(self.scale[0]) / 2.0 if kind == "planar" else (float(self.scale[0]) if kind == "sphere" else (float(self.scale[0]) + float(self.scale[1])) / 2.0)
         self.load_distance = load_distance * model_scale  # TileTree::new (:144)
         self.approximate_height = np.float32((np.float32(min_height) + np.float32(max_height)) / np.float32(2.0))
+        self.heights = (min_height, max_height)
         self.coords = np.full((self.sides, lod_count, tree_size, tree_size, 4), INVALID, np.uint32)
         self.requested = np.zeros((self.sides, lod_count, tree_size, tree_size), bool)
         self.origins = np.zeros((self.sides, lod_count, 2), np.uint32)
@@ -234,3 +235,66 @@ def tc_encode(tiles):
         for v in t:
             out += _varint(int(v))
     return bytes(out)
+
+
+# ------------------------------------------------------------------------------------------------ sample_attachment (f4)
+def sample_attachment_r16(model, view_position, approximate_height, blend_distance, blend_range, lod_count, entries, layers, T, b, positions):
+    """sample_attachment / sample_height (terrain_data/mod.rs:265-307) of an R16 attachment for the planar and the spherical model, one
+    sample at a time in the reference's order: surface_position (terrain_model.rs:130-173), compute_blend and lookup_tile
+    (tile_tree.rs:223-266), AtlasAttachment::sample (tile_atlas.rs:249-258) and AttachmentData::sample (terrain_data/mod.rs:220-257).
+    model: a TileTreeModel (its transform and cube-sphere warp); entries: (sides, lods, tree, tree, 2) u32 = (atlas_index, atlas_lod);
+    layers: {atlas_index: (T, T) u16}.  Returns ((n, 4) f32 values, (n,) f32 heights; min / max height from `model.heights`)."""
+    f32 = np.float32
+    INVALID_LOD = 0xFFFFFFFF
+    view = np.asarray(view_position, np.float64)
+    scale, offset = f32(T - 2 * b) / f32(T), f32(b) / f32(T)
+    ts = entries.shape[2]
+
+    def surface(p):
+        local = (np.asarray(p, np.float64) - model.t) / model.scale  # local_from_world
+        if model.spherical:
+            local = local * (1.0 / np.sqrt(local[0] * local[0] + local[1] * local[1] + local[2] * local[2]))
+            direction = local * model.scale
+        else:
+            local = np.array([1.0, 0.0, 1.0]) * local
+            direction = np.array([0.0, 1.0, 0.0]) * model.scale
+        world = local * model.scale + model.t
+        normal = direction * (1.0 / np.sqrt(direction[0] * direction[0] + direction[1] * direction[1] + direction[2] * direction[2]))
+        return world + np.float64(approximate_height) * normal
+
+    def lerp(a, c, t):  # Vec4::lerp / f32::lerp
+        return f32(a + f32(f32(c - a) * t))
+
+    def lookup_and_sample(p, lod):
+        side, uv = model.view_coordinate(p)
+        count = float(1 << lod)
+        tree_xy = np.minimum(uv * count, count - 0.000001)
+        index, atlas_lod = entries[side, lod, int(tree_xy[0]) % ts, int(tree_xy[1]) % ts]
+        if atlas_lod == INVALID_LOD or index == 0xFFFFFFFF:
+            return f32(0.0)
+        atlas_uv = np.fmod(tree_xy / float(1 << (lod - int(atlas_lod))), 1.0).astype(f32)
+        uv32 = atlas_uv * scale + offset
+        uvs = uv32 * f32(T) - f32(0.5)
+        rem = np.fmod(uvs, f32(1.0))
+        ix, iy = int(uvs[0]), int(uvs[1])  # as_ivec2 truncates
+        data = layers[int(index)].reshape(-1)
+        v = [[f32(data[(iy + y) * T + ix + x]) / f32(65535.0) for y in range(2)] for x in range(2)]
+        return lerp(lerp(v[0][0], v[0][1], rem[1]), lerp(v[1][0], v[1][1], rem[1]), rem[0])
+
+    values = np.zeros((len(positions), 4), f32)
+    for i, p in enumerate(positions):
+        s = surface(p)
+        d = s - view
+        view_distance = np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+        target = f32(min(np.log2(blend_distance / view_distance), float(lod_count) - 0.00001))
+        lod = 0 if not target > 0 else int(target)
+        value = lookup_and_sample(s, lod)
+        if lod != 0:
+            a, c = f32(lod) + f32(blend_range), f32(lod)
+            ratio = f32(f32(target - a) / f32(c - a))
+            ratio = f32(min(max(ratio, f32(0.0)), f32(1.0)))
+            if ratio > 0:
+                value = lerp(value, lookup_and_sample(s, lod - 1), ratio)
+        values[i, 0] = value
+    lo, hi = f32(model.heights[0]), f32(model.heights[1])
+    return values, (lo + f32(hi - lo) * values[:, 0]).astype(f32)

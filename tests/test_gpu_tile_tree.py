@@ -8,6 +8,7 @@ import pytest
 
 import _cases as K
 import _oracle as O
+import _second_models as S
 import bevy_terrain_amd as bt
 from test_tile_tree_host import MODELS, positions
 
@@ -153,6 +154,15 @@ def test_streaming_loop_entries_and_heights(device, tmp_path, kind, atlas_size):
         # to f32 absorbs that except within 2^-29 of a rounding boundary — with these fixed seeds every value is bit-equal
         assert np.array_equal(ours, exp), (frame, np.abs(ours - exp).max(), int((ours != exp).sum()))
         assert np.array_equal(ours_h, exp_heights), (frame, np.abs(ours_h - exp_heights).max())
+        # ... and a second, independent model of sample_attachment (tests/_second_models.py: numpy, one sample at a time, from the
+        # reference text; it takes the best-tile table and the loaded texels as given)
+        sides = 6 if kind != "planar" else 1
+        model_scale = float(model.scale_vec[0]) / 2.0 if kind == "planar" else float(model.scale_vec[0])
+        mine = S.TileTreeModel(kind, model.translation, model.scale_vec, model.min_height, model.max_height, lods, 4, 1.2)
+        m_values, m_heights = S.sample_attachment_r16(mine, pos, h, 1.0 * model_scale, vc.blend_range, lods, entries.reshape(sides, lods, 4, 4, 2),
+                                                      layers, T, b, pts)
+        assert np.array_equal(ours, m_values), (frame, np.abs(ours - m_values).max(), int((ours != m_values).sum()))
+        assert np.array_equal(ours_h, m_heights), (frame, np.abs(ours_h - m_heights).max())
     assert loaded_total > 20
     if atlas_size == 40:
         assert evictions > 0
