@@ -173,3 +173,58 @@ def test_view_state_fields_follow_from_the_second_model(kind):
             xy = np.trunc(uv)  # as_ivec2
             assert tuple(v.sides[side].view_xy) == (int(xy[0]), int(xy[1])), (p, side)
             assert tuple(v.sides[side].view_uv) == tuple((uv - xy).astype(np.float32)), (p, side)  # fract() then as_vec2
+
+
+@pytest.mark.parametrize("lod", [0, 1, 2, 3])
+def test_cube_neighbours_are_geometric_neighbours(lod):
+    """a10 (coordinate.rs:208-279 with NEIGHBOURING_SIDES and SideInfo::project_to_side): checked against GEOMETRY, not against a
+    restated table — on the unit cube-sphere an edge neighbour shares exactly two corner points with the tile, a diagonal neighbour
+    exactly one, whatever faces they lie on; the diagonal across a cube corner (three faces meet) does not exist.  Corner points come
+    from the numpy model's own warp (TileTreeModel.world_position), the neighbours from bt_tile_neighbours and from the oracle."""
+    sphere = S.TileTreeModel("sphere", (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), 0.0, 0.0, 4, 4, 2.5)
+    n = 1 << lod
+
+    def corners(side, x, y):
+        uv = np.array([[x, y], [x + 1, y], [x, y + 1], [x + 1, y + 1]], np.float64) / n
+        return sphere.world_position(side, uv, 0.0)
+
+    def shared(a, c):
+        return sum(1 for p in a for q in c if np.abs(p - q).max() < 1e-12)
+
+    checked = 0
+    for side in range(6):
+        for x in range(n):
+            for y in range(n):
+                mine = corners(side, x, y)
+                nbs = bt.TileCoordinate(side, lod, x, y).neighbours(True)
+                assert [(c.side, c.lod, c.x, c.y) for c in nbs] == O.neighbours((side, lod, x, y), True)
+                for k, nb in enumerate(nbs):
+                    at_cube_corner = k >= 4 and [(-1, -1), (1, -1), (1, 1), (-1, 1)][k - 4] in [
+                        (dx, dy) for dx in (-1, 1) for dy in (-1, 1) if not (0 <= x + dx < n) and not (0 <= y + dy < n)]
+                    if at_cube_corner:
+                        assert nb.lod == 0xFFFFFFFF or nb.side == 0xFFFFFFFF, (side, x, y, k)  # TileCoordinate::INVALID
+                        continue
+                    assert nb.lod == lod and nb.side < 6
+                    if lod == 0 and nb.side == side:
+                        continue  # (never happens: a face's neighbours are other faces)
+                    assert shared(mine, corners(nb.side, nb.x, nb.y)) == (2 if k < 4 else 1), (side, x, y, k, (nb.side, nb.x, nb.y))
+                    checked += 1
+    assert checked >= 6 * n * n * 4
+
+
+def test_children_tile_their_parent_geometrically():
+    """coordinate.rs:187-206: the four children of a tile cover exactly its patch of the cube-sphere (their 9 distinct corner points
+    are the parent's 3 x 3 grid of corner / edge-midpoint / centre points in uv), and parent() undoes children()."""
+    sphere = S.TileTreeModel("sphere", (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), 0.0, 0.0, 4, 4, 2.5)
+    for side, lod, x, y in [(0, 0, 0, 0), (3, 1, 1, 0), (5, 2, 3, 2), (1, 3, 0, 7), (4, 3, 5, 5)]:
+        n = 1 << lod
+        grid = {tuple(np.round(sphere.world_position(side, np.array([[(x + i / 2) / n, (y + j / 2) / n]]), 0.0)[0], 12)) for i in range(3) for j in range(3)}
+        kids = bt.TileCoordinate(side, lod, x, y).children()
+        assert [(c.side, c.lod, c.x, c.y) for c in kids] == [(side, lod + 1, 2 * x + i % 2, 2 * y + i // 2) for i in range(4)]
+        pts = set()
+        for c in kids:
+            assert (lambda p: (p.side, p.lod, p.x, p.y))(c.parent()) == (side, lod, x, y)
+            m = 1 << c.lod
+            uv = np.array([[c.x, c.y], [c.x + 1, c.y], [c.x, c.y + 1], [c.x + 1, c.y + 1]], np.float64) / m
+            pts |= {tuple(np.round(p, 12)) for p in sphere.world_position(c.side, uv, 0.0)}
+        assert pts == grid
