@@ -298,3 +298,69 @@ def sample_attachment_r16(model, view_position, approximate_height, blend_distan
         values[i, 0] = value
     lo, hi = f32(model.heights[0]), f32(model.heights[1])
     return values, (lo + f32(hi - lo) * values[:, 0]).astype(f32)
+
+
+# ------------------------------------------------------------------------------------------------ streaming state machine
+class StreamModel:
+    """The streaming half of TileAtlasState (tile_atlas.rs:300-500) as plain Python containers: which atlas slot a requested tile gets
+    (the least recently released one), when a slot is taken back, what get_best_tile answers while a tile is still loading."""
+
+    INVALID = 0xFFFFFFFF
+
+    def __init__(self, atlas_size, attachment_count, existing=()):
+        from collections import deque
+
+        self.unused = deque((None, i) for i in range(atlas_size))  # (coordinate it last held, atlas index): front = next to go
+        self.states = {}  # coordinate -> [requests, attachments still loading, atlas index]
+        self.existing = set(existing)
+        self.attachments = attachment_count
+        self.to_load = deque()
+
+    def _allocate(self):
+        coordinate, index = self.unused.popleft()  # ("Atlas out of indices" if empty)
+        self.states.pop(coordinate, None)
+        return index
+
+    def request_tile(self, c):
+        if c not in self.existing:
+            return
+        st = self.states.get(c)
+        if st is not None:
+            if st[0] == 0:  # cached but unused: out of the queue again
+                self.unused = type(self.unused)(u for u in self.unused if u[1] != st[2])
+            st[0] += 1
+        else:
+            index = self._allocate()
+            self.states[c] = [1, self.attachments, index]
+            for a in range(self.attachments):
+                self.to_load.append((c, index, a))
+
+    def release_tile(self, c):
+        if c not in self.existing:
+            return
+        st = self.states[c]
+        st[0] -= 1
+        if st[0] == 0:
+            self.unused.append((c, st[2]))
+
+    def pending_loads(self):
+        return len(self.to_load)
+
+    def finish_loads(self, n):
+        done = []
+        for _ in range(n):
+            c, index, a = self.to_load.popleft()
+            st = self.states[c]
+            st[1] -= 1
+            done.append((c, index))
+        return done
+
+    def get_best_tile(self, c):
+        side, lod, x, y = c
+        while True:
+            st = self.states.get((side, lod, x, y))
+            if st is not None and st[1] == 0:
+                return st[2], lod
+            if lod == 0:
+                return self.INVALID, self.INVALID
+            lod, x, y = lod - 1, x >> 1, y >> 1

@@ -107,6 +107,7 @@ def test_streaming_loop_entries_and_heights(device, tmp_path, kind, atlas_size):
     tree = bt.TileTree.new(atlas, vc)
     otree = O.TileTree(omodel, lods, ovc)
     stream = O.Stream(atlas_size, 1, existing=list(tiles))
+    smodel = S.StreamModel(atlas_size, 1, existing=list(tiles))  # the second model of the slot state machine, driven by the DEVICE's lists
     layers = {}  # oracle's copy of the atlas contents: atlas_index -> texels
     rng = np.random.default_rng(17)
     loaded_total, evictions = 0, 0
@@ -115,15 +116,22 @@ def test_streaming_loop_entries_and_heights(device, tmp_path, kind, atlas_size):
         path = [(10.0 + 450.0 * math.sin(0.37 * i), 40.0, 3.0 + 450.0 * math.sin(0.23 * i + 1.0)) for i in range(60)]
     for frame, pos in enumerate(path):
         # TileTree::compute_requests
-        assert tree.update(pos) == otree.update(pos), frame
+        released, requested = tree.update(pos)
+        assert (released, requested) == otree.update(pos), frame
         # TileAtlas::update: finish the loads queued by earlier frames, then this frame's releases / requests
         pending = stream.pending_loads()
         assert atlas.pending_loads() == pending
         loaded, failed = atlas.update(root)
         assert (loaded, failed) == (pending, 0)
-        for coord, index in stream.finish_loads(pending):
+        finished = stream.finish_loads(pending)
+        assert smodel.pending_loads() == pending and smodel.finish_loads(pending) == finished
+        for coord, index in finished:
             evictions += index in layers
             layers[index] = tiles[coord]
+        for coord in released:  # TileAtlas::update (tile_atlas.rs:590-600): releases, then requests
+            smodel.release_tile(coord)
+        for coord in requested:
+            smodel.request_tile(coord)
         loaded_total += loaded
         tree.apply_requests()
         otree.apply_requests(stream)
@@ -136,7 +144,7 @@ def test_streaming_loop_entries_and_heights(device, tmp_path, kind, atlas_size):
         # every loaded slot holds the bytes of its tile
         for coord in list(tiles)[:: max(1, len(tiles) // 7)]:
             idx, lod = atlas.get_best_tile(bt.TileCoordinate(*coord))
-            assert (idx, lod) == stream.get_best_tile(coord)
+            assert (idx, lod) == stream.get_best_tile(coord) == smodel.get_best_tile(coord)
             if lod == coord[1]:
                 assert np.array_equal(atlas.download_tile(0, idx), tiles[coord])
         # TileTree::approximate_height + a batch of sample_height queries around the view

@@ -228,3 +228,45 @@ def test_children_tile_their_parent_geometrically():
             uv = np.array([[c.x, c.y], [c.x + 1, c.y], [c.x, c.y + 1], [c.x + 1, c.y + 1]], np.float64) / m
             pts |= {tuple(np.round(p, 12)) for p in sphere.world_position(c.side, uv, 0.0)}
         assert pts == grid
+
+
+@pytest.mark.parametrize("seed,atlas_size,attachments", [(1, 6, 1), (2, 9, 2), (3, 24, 1), (4, 5, 3)])
+def test_stream_model_equals_the_oracle_state_machine(seed, atlas_size, attachments):
+    """TileAtlasState's streaming half (tile_atlas.rs:300-500): random request / release / load-completion sequences through the
+    Python container model and through the oracle's restatement — same atlas slots (LRU reuse), same load queue, same best tiles
+    while tiles are still loading."""
+    rng = np.random.default_rng(seed)
+    tiles = [(0, lod, x, y) for lod in range(4) for x in range(1 << lod) for y in range(1 << lod)]
+    existing = [t for t in tiles if rng.random() < 0.85]
+    mine, theirs = S.StreamModel(atlas_size, attachments, existing), O.Stream(atlas_size, attachments, existing)
+    held = []  # tiles with outstanding requests (a tile may appear more than once)
+    reused = 0
+    for step in range(600):
+        r = rng.random()
+        live = len({t for t in held if t in mine.existing})
+        if r < 0.5 and (live < atlas_size - 1 or rng.random() < 0.3):
+            t = tiles[int(rng.integers(len(tiles)))]
+            if t in mine.existing and t not in mine.states and not mine.unused:
+                continue  # the reference panics ("Atlas out of indices"): not part of the comparison
+            before = mine.states.get(t)
+            mine.request_tile(t)
+            theirs.request_tile(t)
+            held.append(t)
+            reused += before is None and t in mine.existing
+        elif r < 0.8 and held:
+            # (a tile is released only once it is loaded: the reference unwraps the state of a tile whose load completes — a slot
+            # taken back while its tile is still loading makes it panic, and is not part of the comparison)
+            n = mine.pending_loads()
+            assert mine.finish_loads(n) == theirs.finish_loads(n)
+            t = held.pop(int(rng.integers(len(held))))
+            mine.release_tile(t)
+            theirs.release_tile(t)
+        else:
+            assert mine.pending_loads() == theirs.pending_loads()
+            n = int(rng.integers(0, mine.pending_loads() + 1))
+            assert mine.finish_loads(n) == theirs.finish_loads(n)
+        for t in tiles[:: 3]:
+            assert mine.get_best_tile(t) == theirs.get_best_tile(t), (step, t)
+            if t in mine.states:
+                assert theirs.atlas_index(t) == mine.states[t][2]
+    assert reused > atlas_size  # slots were taken back and handed out again
