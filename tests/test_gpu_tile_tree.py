@@ -141,6 +141,9 @@ def test_streaming_loop_entries_and_heights(device, tmp_path, kind, atlas_size):
         entries, origins, coords, flags = tree.read()
         e2, o2, c2, f2 = otree.read()
         assert np.array_equal(coords, c2) and np.array_equal(entries, e2), frame
+        # adjust_to_tile_atlas (tile_tree.rs:337-386) once more from the slot model: every node's entry is the best loaded tile of its coordinate
+        m_entries = np.array([smodel.get_best_tile(tuple(int(v) for v in c)) if c[1] != 0xFFFFFFFF else (0xFFFFFFFF, 0xFFFFFFFF) for c in coords], np.uint32)
+        assert np.array_equal(entries, m_entries), frame
         # every loaded slot holds the bytes of its tile
         for coord in list(tiles)[:: max(1, len(tiles) // 7)]:
             idx, lod = atlas.get_best_tile(bt.TileCoordinate(*coord))
