@@ -151,6 +151,7 @@ def test_streaming_loop_entries_and_heights(device, tmp_path, kind, atlas_size):
             if lod == coord[1]:
                 assert np.array_equal(atlas.download_tile(0, idx), tiles[coord])
         # TileTree::approximate_height + a batch of sample_height queries around the view
+        h_before = tree.view_state().approximate_height  # what surface_position uses while the new height is sampled
         h = tree.approximate_height()
         _, exp_h = otree.sample_attachment(O.FORMAT_R16, T, b, layers, [pos])
         assert h == float(exp_h[0]), (frame, h, float(exp_h[0]))
@@ -173,6 +174,8 @@ def test_streaming_loop_entries_and_heights(device, tmp_path, kind, atlas_size):
         m_values, m_heights = S.sample_attachment_r16(mine, pos, h, 1.0 * model_scale, vc.blend_range, lods, entries.reshape(sides, lods, 4, 4, 2),
                                                       layers, T, b, pts)
         assert np.array_equal(ours, m_values), (frame, np.abs(ours - m_values).max(), int((ours != m_values).sum()))
+        # (TileTree::approximate_height, tile_tree.rs:376-386: sample_height at the view position, with the previous height)
+        assert S.sample_attachment_r16(mine, pos, h_before, 1.0 * model_scale, vc.blend_range, lods, entries.reshape(sides, lods, 4, 4, 2), layers, T, b, [pos])[1][0] == h
         assert np.array_equal(ours_h, m_heights), (frame, np.abs(ours_h - m_heights).max())
     assert loaded_total > 20
     if atlas_size == 40:
