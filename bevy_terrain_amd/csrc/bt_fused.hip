@@ -362,6 +362,7 @@ struct MainShared {  // fixed part of the dynamic LDS block (size is a multiple 
     RowParam apron[2 * kMaxBorder];  // [0, b): top apron rows, [b, 2b): bottom apron rows (pad = mosaic row ry)
     int xmin, xmax;
     uint32_t redo[2];  // fast variants: bit (k - k_begin) = chunk k saw a no-data texel and is redone by the generic rows after the run
+    uint32_t redo_waves[kMaxChunks / 8];  // ... and which of the workgroup's four waves saw it (4 bits per chunk): only those redo their columns
 };
 static_assert(sizeof(MainShared) % 16 == 0, "LDS carve must stay 16-byte aligned");
 
@@ -499,7 +500,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     // atlas tile holding each column's pixels (keep-previous rule reads it when the source has no data)
     const uint32_t home_col = is_right && t5.e != kInvalid ? t5.e : (is_left && t5.w != kInvalid ? t5.w : t5.self);
 
-    if (tid == 0) S.redo[0] = S.redo[1] = 0;
+    if (tid < 2u + kMaxChunks / 8u) (tid < 2u ? S.redo[tid] : S.redo_waves[tid - 2u]) = 0;
     // the first left-apron pair reads the leftmost source column, the last right-apron pair the rightmost
     if (tid == half_c + half_b) S.xmin = min(axa.i0, axb.i0);
     if (tid == half_c + half_b - 1) S.xmax = max(axa.i1, axb.i1);
@@ -715,7 +716,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             return convert4(row[axa.i0], row[axa.i1], row[axb.i0], row[axb.i1]);
         }
     };
-    auto flag_chunk = [&](uint32_t kk) { S.redo[(kk - k_begin) >> 5] |= 1u << ((kk - k_begin) & 31u); };  // thread 0 only
+    auto flag_chunk = [&](uint32_t kk) {  // thread 0 only: the whole chunk, every wave
+        S.redo[(kk - k_begin) >> 5] |= 1u << ((kk - k_begin) & 31u);
+        S.redo_waves[(kk - k_begin) >> 3] |= 0xFu << (((kk - k_begin) & 7u) * 4u);
+    };
     // apron rows (first / last chunk of a tile only): the centre columns are rows like any other (the north / south
     // neighbour's centre rows, or clamped into the own centre); the b x b corners follow the diagonal neighbour alone
     // (stitch.wgsl:57-66, 105-118) and are written by corner_pixels.  gtag: with the keep-previous rule (generic rows) or without
@@ -1099,7 +1103,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         }
 
         if constexpr (kDma) {
-            if (dirty) atomicOr(&S.redo[(k - k_begin) >> 5], 1u << ((k - k_begin) & 31u));  // (rare: straight into the mask the redo reads behind the loop)
+            if (dirty) {  // (rare: straight into the masks the redo reads behind the loop)
+                atomicOr(&S.redo[(k - k_begin) >> 5], 1u << ((k - k_begin) & 31u));
+                atomicOr(&S.redo_waves[(k - k_begin) >> 3], 1u << (((k - k_begin) & 7u) * 4u + (tid >> 6)));
+            }
         }
         if (!more) break;
         // chunk k + 1 goes into the other staging buffer (nobody reads it any more: its last readers passed the
@@ -1136,8 +1143,13 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                 __syncthreads();
                 s_src = s_buf;
                 cur_ymin = ymin;
-                apron_rows(k, std::true_type{});
-                generic_rows(k);
+                // a wave whose lanes all read clean texels stored its columns of this chunk (finest rows, parents, pushes) in the fast
+                // pass — every reduction of the pyramid stays inside a lane pair — and has nothing to redo
+                const uint32_t waves = uint32_t(__builtin_amdgcn_readfirstlane(int(S.redo_waves[(k - k_begin) >> 3]))) >> (((k - k_begin) & 7u) * 4u);
+                if ((waves >> uint32_t(__builtin_amdgcn_readfirstlane(int(tid >> 6)))) & 1u) {
+                    apron_rows(k, std::true_type{});
+                    generic_rows(k);
+                }
                 __syncthreads();  // the next flagged chunk overwrites the staged rows
             }
         }
