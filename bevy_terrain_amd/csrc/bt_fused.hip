@@ -759,6 +759,17 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         for (uint32_t q = 0; q < nrows; q += 4) {
             uint32_t va[4], vb[4];
             uint32_t zany = 1;
+            // the redo of a flagged chunk (fast variants): the previous atlas values of the quad are requested BEFORE the rows are shaded
+            // — fetched only where a footprint turned out to have no data they were a round trip in the middle of every quad
+            uint32_t prev_a[4], prev_b[4];
+            if constexpr (!kGeneric) {
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) {
+                    const uint16_t* h = A.atlas + uint64_t(home_col) * tile_texels + (b + cr0 + q + i) * T + b;
+                    prev_a[i] = h[rxa];
+                    prev_b[i] = h[rxb];
+                }
+            }
 #pragma unroll
             for (uint32_t i = 0; i < 4; i++) {
                 const int yy = __builtin_amdgcn_readfirstlane(row_y0[q + i]);
@@ -780,9 +791,14 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             if (zany == 0) {  // some footprint had no data: those pixels keep their previous atlas value (split.wgsl:37-42)
 #pragma unroll
                 for (uint32_t i = 0; i < 4; i++) {
-                    const uint16_t* h = A.atlas + uint64_t(home_col) * tile_texels + (b + cr0 + q + i) * T + b;
-                    if (va[i] & 0x10000u) va[i] = h[rxa];
-                    if (vb[i] & 0x10000u) vb[i] = h[rxb];
+                    if constexpr (!kGeneric) {
+                        if (va[i] & 0x10000u) va[i] = prev_a[i];
+                        if (vb[i] & 0x10000u) vb[i] = prev_b[i];
+                    } else {
+                        const uint16_t* h = A.atlas + uint64_t(home_col) * tile_texels + (b + cr0 + q + i) * T + b;
+                        if (va[i] & 0x10000u) va[i] = h[rxa];
+                        if (vb[i] & 0x10000u) vb[i] = h[rxb];
+                    }
                 }
             }
             const uint32_t py = b + cr0 + q;
@@ -1146,7 +1162,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                 // a wave whose lanes all read clean texels stored its columns of this chunk (finest rows, parents, pushes) in the fast
                 // pass — every reduction of the pyramid stays inside a lane pair — and has nothing to redo
                 const uint32_t waves = uint32_t(__builtin_amdgcn_readfirstlane(int(S.redo_waves[(k - k_begin) >> 3]))) >> (((k - k_begin) & 7u) * 4u);
-                if ((waves >> uint32_t(__builtin_amdgcn_readfirstlane(int(tid >> 6)))) & 1u) {
+                if (((waves >> uint32_t(__builtin_amdgcn_readfirstlane(int(tid >> 6)))) & 1u) && !BT_ABLATE(A, 131072u)) {  // (131072: the redo stages but computes nothing — timing experiment)
                     apron_rows(k, std::true_type{});
                     generic_rows(k);
                 }
