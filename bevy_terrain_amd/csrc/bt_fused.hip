@@ -57,6 +57,11 @@ struct FusedArgs {
     const MainItem* items;
     const uint32_t* grids;         // per (side, lod): n x n atlas indices, x-major (x * n + y), INVALID = absent
     uint32_t grid_lod_lo, grid_lod_hi, grid_sides;  // the grids of (side, lod), lod_lo <= lod <= lod_hi, follow each other side-major, LODs ascending
+    // A job queued onto a fresh atlas holds its tiles in the reference's allocation order (preprocessor.rs:234-343: per side the finest
+    // LOD first, x-major, then each coarser LOD), i.e. atlas index = arithmetic on the coordinate.  regular != 0: the host checked every
+    // grid entry against that closed form, and a lookup is a handful of scalar operations instead of a dependent load from the grids
+    // (fused_tail was a chain of five dependent round trips, three of them lookups).
+    uint32_t regular, reg_first;
     float tlx, tly, brx, bry;
     uint32_t lod;         // finest LOD of this launch (fused_main) / input LOD (fused_tail)
     uint32_t levels;      // LODs produced by this launch: main 1..3 (lod, lod-1, lod-2); tail 1..3 below lod
@@ -114,6 +119,10 @@ __device__ __forceinline__ uint32_t grid_lookup(const FusedArgs& A, uint32_t sid
     const int n = int(1u << lod);
     if (x < 0 || y < 0 || x >= n || y >= n) return kInvalid;
     if (lod < A.grid_lod_lo || lod > A.grid_lod_hi || side >= A.grid_sides) return kInvalid;
+    if (A.regular) {  // sum of 4^l for lod < l <= lod_hi tiles precede the LOD's on its side, lod_lo .. lod_hi make a side
+        const uint32_t hi4 = 4u << (2u * A.grid_lod_hi);
+        return A.reg_first + side * ((hi4 - (1u << (2u * A.grid_lod_lo))) / 3u) + (hi4 - (4u << (2u * lod))) / 3u + uint32_t(x) * uint32_t(n) + uint32_t(y);
+    }
     // offset of the (side, lod) grid: computed, not looked up (one dependent load less in every lookup chain):
     // sum of 4^l for lod_lo <= l < lod = (4^lod - 4^lod_lo) / 3
     const uint32_t lo4 = 1u << (2u * A.grid_lod_lo), per_side = ((4u << (2u * A.grid_lod_hi)) - lo4) / 3u;
@@ -620,8 +629,6 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                                  (__attribute__((address_space(3))) void*)(dst + slot * (kP * 2u) + 1024u), 16, 0, 0);
         }
     };
-    // exchange inside the lane pair (2m, 2m+1): quad_perm [1, 0, 3, 2]
-    auto pair_min = [](uint32_t v) -> uint32_t { return min(v, uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0xB1, 0xf, 0xf, true))); };
 
     uint16_t* tile5 = A.atlas + uint64_t(t5.self) * tile_texels;
     uint32_t* tile5_u32 = reinterpret_cast<uint32_t*>(tile5);
@@ -706,7 +713,6 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     // ---- per-chunk pieces shared by the loop and by the redo of flagged chunks behind it
     uint16_t* s_src = s_buf;  // staged rows of the chunk being shaded ...
     int cur_ymin = 0;         // ... and the source row of its first slot
-    uint32_t dirty = 0;       // kDma: this thread skipped stores in the current chunk
     auto fetch_row = [&](int y) -> Texel4 {
         if constexpr (kStaged) {
             const uint16_t* row = s_src + uint32_t(y - cur_ymin) * P;
@@ -740,10 +746,6 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                 const uint16_t* h = A.atlas + uint64_t(nrow == kInvalid ? t5.self : nrow) * tile_texels + (b + S.apron[r].pad) * T + b;
                 if (min(t0.za, t1.za) == 0) va = h[rxa];
                 if (min(t0.zb, t1.zb) == 0) vb = h[rxb];
-            }
-            if (!kKeep && kDma && min(min(t0.za, t1.za), min(t0.zb, t1.zb)) == 0) {
-                dirty = 1;
-                continue;
             }
             tile5_u32[(py * T + px0) >> 1] = va | (vb << 16);
         }
@@ -853,7 +855,6 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             }
             else if (kStaged && wide && !BT_ABLATE(A, 8u)) stage_issue(next_ymin, next_slots, pre);
         }
-        dirty = 0;
 
         // Wave priority rotating with the chunk index, offset by the workgroup's dispatch rank on its CU.  The CU's arbiters serve
         // the highest-priority wave first and, among equals, the OLDEST — strictly: without this the four resident workgroups
@@ -878,7 +879,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         const bool skip_chunk = !kGeneric && has_nodata;
         if (skip_chunk && tid == 0) flag_chunk(k);
 
-        if (!skip_chunk) apron_rows(k, std::integral_constant<bool, kGeneric>{});
+        if (!skip_chunk) apron_rows(k, std::integral_constant<bool, kGeneric || kDma>{});  // (kDma: no-data is handled where it is met, inside the loop)
 
 #ifdef BT_DEBUG_HOOKS
 #define BT_FUSED_DEBUG_SKELETON_STORES
@@ -929,7 +930,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                     uint32_t q[4];
                     // kDma: smallest raw texel this thread read for the rows of a quad (source rows 4 * quad .. 4 * quad + 4), per column pair half
                     u16x2 zmin[2] = {__builtin_elementwise_min(ta, tb), u16x2{0xFFFFu, 0xFFFFu}};
-                    uint32_t zq[2] = {1u, 1u}, zp[2] = {1u, 1u};
+                    uint32_t zq[2] = {1u, 1u};
                     uint32_t* dst5 = tile5_u32 + (((b + cr0) * T + px0) >> 1);
 #pragma unroll
                     for (uint32_t quad = 0; quad < 2; quad++) {
@@ -960,10 +961,23 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         }
                         if constexpr (kDma) {
                             zq[quad] = min(uint32_t(zmin[quad].x), uint32_t(zmin[quad].y));
-                            zp[quad] = pair_min(zq[quad]);
-                            dirty |= zp[quad] == 0 ? 1u : 0u;
+                            if (zq[quad] == 0) {
+                                // (rare) this thread read a no-data texel for the quad: per-pixel validity from the rows that are still
+                                // staged, the previous atlas value where a footprint has no data (split.wgsl:34-42) — in place, no redo
+                                u16x2 z[5];
+#pragma unroll
+                                for (uint32_t j = 0; j < 5; j++)
+                                    z[j] = __builtin_elementwise_min(u16x2{pa0[(4 * quad + j) * P], pb0[(4 * quad + j) * P]},
+                                                                     u16x2{pa1[(4 * quad + j) * P], pb1[(4 * quad + j) * P]});
+                                const uint16_t* h = A.atlas + uint64_t(home_col) * tile_texels + (b + cr0 + 4 * quad) * T + b;
+#pragma unroll
+                                for (uint32_t i = 0; i < 4; i++) {
+                                    if (min(z[i].x, z[i + 1].x) == 0) ua[i] = h[i * T + rxa];
+                                    if (min(z[i].y, z[i + 1].y) == 0) ub[i] = h[i * T + rxb];
+                                }
+                            }
                         }
-                        if (!is_idle && !BT_ABLATE(A, 2u) && (!kDma || zq[quad] != 0)) {
+                        if (!is_idle && !BT_ABLATE(A, 2u)) {
 #pragma unroll
                             for (uint32_t i = 0; i < 4; i++) {
                                 if (BT_ABLATE(A, 8192u)) __builtin_nontemporal_store(ua[i] | (ub[i] << 16), &dst5[(4 * quad + i) * (T / 2)]);  // (8192: streaming stores)
@@ -976,37 +990,36 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             const f2 wq = quantise_quarter(sum);
                             q[2 * quad] = uint32_t(wq.x);
                             q[2 * quad + 1] = uint32_t(wq.y);
+                            if (kDma && zq[quad] == 0) {  // kept texels may be 0 (no data): the valid-average (downsample.wgsl:25-39)
+                                q[2 * quad] = downsample4(ua[0], ua[1], ub[0], ub[1]);  // OFFSETS order
+                                q[2 * quad + 1] = downsample4(ua[2], ua[3], ub[2], ub[3]);
+                            }
                         }
                     }
                     if (do4) {
                         // centre + (edge columns) the x neighbour's apron column; apron rows come from the stitch launch.
                         // The lane pair (2m, 2m+1) holds two adjacent pixels: the even lane stores both as one aligned dword
                         // (b, c / 2 even) — 2-byte stores cost the memory pipeline about as much as 4-byte ones.
-                        {
-                            uint32_t both[4];
+                        uint32_t both[4];
 #pragma unroll
-                            for (uint32_t j = 0; j < 4; j++)
-                                both[j] = q[j] | (uint32_t(__builtin_amdgcn_update_dpp(0, int(q[j]), 0xB1, 0xf, 0xf, true)) << 16);
-                            if (is_centre && (tid & 1u) == 0 && !BT_ABLATE(A, 4u)) {
-                                uint32_t* dst = reinterpret_cast<uint32_t*>(tile4 + (b + cy4_first) * T + b + cx4);
+                        for (uint32_t j = 0; j < 4; j++)
+                            both[j] = q[j] | (uint32_t(__builtin_amdgcn_update_dpp(0, int(q[j]), 0xB1, 0xf, 0xf, true)) << 16);
+                        if (is_centre && (tid & 1u) == 0 && !BT_ABLATE(A, 4u)) {
+                            uint32_t* dst = reinterpret_cast<uint32_t*>(tile4 + (b + cy4_first) * T + b + cx4);
 #pragma unroll
-                                for (uint32_t j = 0; j < 4; j++) {
-                                    if (kDma && zp[j >> 1] == 0) continue;  // the pair read a no-data texel in this quad's rows
-                                    if (BT_ABLATE(A, 16384u)) __builtin_nontemporal_store(both[j], &dst[j * (T / 2)]);  // (16384: streaming parent stores)
-                                    else dst[j * (T / 2)] = both[j];
-                                }
+                            for (uint32_t j = 0; j < 4; j++) {
+                                if (BT_ABLATE(A, 16384u)) __builtin_nontemporal_store(both[j], &dst[j * (T / 2)]);  // (16384: streaming parent stores)
+                                else dst[j * (T / 2)] = both[j];
                             }
                         }
                         if (x4_count && !BT_ABLATE(A, 4u)) {  // a few lanes of a tile; one texel each unless the x neighbour is absent
                             uint16_t* t = A.atlas + x4_off + cy4_first * T;
 #pragma unroll
-                            for (uint32_t j = 0; j < 4; j++)
-                                if (!kDma || zq[j >> 1] != 0) t[j * T] = uint16_t(q[j]);
+                            for (uint32_t j = 0; j < 4; j++) t[j * T] = uint16_t(q[j]);
                             if (x4_count > 1)
                                 for (uint32_t e = 1; e < x4_count; e++)
 #pragma unroll
-                                    for (uint32_t j = 0; j < 4; j++)
-                                        if (!kDma || zq[j >> 1] != 0) t[j * T + e] = uint16_t(q[j]);
+                                    for (uint32_t j = 0; j < 4; j++) t[j * T + e] = uint16_t(q[j]);
                         }
                         if (do3) {
                             // the lane pair (2m, 2m+1) owns two level-2 pixels (quads 0 and 1): the even lane finishes
@@ -1022,11 +1035,16 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             const float recv1 = swap_pair(even ? colsum.y : c02.x), recv2 = swap_pair(c13.x);
                             const float sa = even ? colsum.x : recv1, sb = even ? recv1 : c02.y, sc = even ? recv2 : c13.y;
                             const float s3 = (sa + sb) + sc;
-                            const uint32_t w3 = uint32_t(0.5f + (0.25f * (65535.0f / 65536.0f)) * s3);  // scaled domain, see quantise_quarter; the clamp is a no-op here
+                            uint32_t w3 = uint32_t(0.5f + (0.25f * (65535.0f / 65536.0f)) * s3);  // scaled domain, see quantise_quarter; the clamp is a no-op here
+                            if constexpr (kDma) {
+                                // a LOD-1 texel of the 2 x 2 block without data (0: only ever the result of a no-data quad): the valid-average
+                                const uint32_t m0 = even ? q[0] : q[2], m1 = even ? q[1] : q[3];                         // this lane's column
+                                const uint32_t p0 = (even ? both[0] : both[2]) >> 16, p1 = (even ? both[1] : both[3]) >> 16;  // the partner's
+                                if (min(min(m0, m1), min(p0, p1)) == 0) w3 = even ? downsample4(m0, m1, p0, p1) : downsample4(p0, p1, m0, m1);
+                            }
                             const uint32_t row3 = (b + cy3_first + (even ? 0u : 1u)) * T;
-                            const bool clean3 = !kDma || (even ? zp[0] : zp[1]) != 0;
-                            if (is_centre && clean3 && !BT_ABLATE(A, 64u)) tile3[row3 + b + cx3] = uint16_t(w3);
-                            if (x3_count && clean3 && !BT_ABLATE(A, 64u)) {
+                            if (is_centre && !BT_ABLATE(A, 64u)) tile3[row3 + b + cx3] = uint16_t(w3);
+                            if (x3_count && !BT_ABLATE(A, 64u)) {
                                 uint16_t* t = A.atlas + x3_off + (cy3_first + (even ? 0u : 1u)) * T;
                                 t[0] = uint16_t(w3);
                                 if (x3_count > 1)
@@ -1048,7 +1066,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                 uint32_t zcur = 1;  // ... and of the row hcur came from
                 for (uint32_t q = 0; q < nrows; q += 4) {
                     uint32_t ua[4], ub[4];
-                    uint32_t zq = 1, zp = 1;
+                    uint32_t zq = 1;
 #pragma unroll
                     for (uint32_t i = 0; i < 4; i++) {
                         const int yy = __builtin_amdgcn_readfirstlane(row_y0[q + i]);
@@ -1075,12 +1093,22 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         ua[i] = uint32_t(w.x);
                         ub[i] = uint32_t(w.y);
                     }
-                    if constexpr (kDma) {
-                        zp = pair_min(zq);
-                        dirty |= zp == 0 ? 1u : 0u;
+                    const bool fix = kDma && zq == 0;
+                    if (fix) {
+                        // (rare) this thread read a no-data texel for the quad: per-pixel validity from the staged rows, the previous
+                        // atlas value where a footprint has no data (split.wgsl:34-42) — in place, like the static path above
+                        const uint16_t* h = A.atlas + uint64_t(home_col) * tile_texels + (b + cr0 + q) * T + b;
+#pragma unroll
+                        for (uint32_t i = 0; i < 4; i++) {
+                            const int yy = row_y0[q + i];
+                            const uint16_t* r0 = s_src + uint32_t((yy & 0x7fffffff) - cur_ymin) * P;
+                            const uint16_t* r1 = r0 + (yy < 0 ? 0u : P);
+                            if (min(min(r0[la0], r0[la1]), min(r1[la0], r1[la1])) == 0) ua[i] = h[i * T + rxa];
+                            if (min(min(r0[lb0], r0[lb1]), min(r1[lb0], r1[lb1])) == 0) ub[i] = h[i * T + rxb];
+                        }
                     }
                     const uint32_t py = b + cr0 + q;
-                    if (!is_idle && !BT_ABLATE(A, 2u) && (!kDma || zq != 0)) {
+                    if (!is_idle && !BT_ABLATE(A, 2u)) {
 #pragma unroll
                         for (uint32_t i = 0; i < 4; i++) tile5_u32[((py + i) * T + px0) >> 1] = ua[i] | (ub[i] << 16);
                     }
@@ -1088,23 +1116,29 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         // two level-1 pixels (row pairs 0-1 and 2-3) in the two packed lanes: ((a0 + a1) + b0) + b1, then / 4
                         const f2 s = ((conv2(ua[0], ua[2]) + conv2(ua[1], ua[3])) + conv2(ub[0], ub[2])) + conv2(ub[1], ub[3]);
                         const f2 wq = quantise_quarter(s);
-                        const uint32_t q0 = uint32_t(wq.x), q1 = uint32_t(wq.y);
+                        uint32_t q0 = uint32_t(wq.x), q1 = uint32_t(wq.y);
+                        if (fix) {  // kept texels may be 0 (no data): the valid-average (downsample.wgsl:25-39), OFFSETS order
+                            q0 = downsample4(ua[0], ua[1], ub[0], ub[1]);
+                            q1 = downsample4(ua[2], ua[3], ub[2], ub[3]);
+                        }
                         const uint32_t cy = cr0 + q, cy4 = cy4_base + (cy >> 1);
-                        if (is_centre && (!kDma || zq != 0)) {
+                        if (is_centre) {
                             uint16_t* dst = tile4 + (b + cy4) * T + b + cx4;
                             dst[0] = uint16_t(q0);
                             dst[T] = uint16_t(q1);
                         }
-                        if (x4_count && (!kDma || zq != 0)) {
+                        if (x4_count) {
                             xpush4(cy4, uint16_t(q0));
                             xpush4(cy4 + 1, uint16_t(q1));
                         }
                         if (do3) {
                             const uint32_t other0 = __shfl_xor(q0, 1), other1 = __shfl_xor(q1, 1);
-                            if (is_centre && (tid & 1u) == 0 && (!kDma || zp != 0)) {
+                            if (is_centre && (tid & 1u) == 0) {
                                 const f2 mine = conv2(q0, q1), theirs = conv2(other0, other1);
                                 const float s3 = ((mine.x + mine.y) + theirs.x) + theirs.y;
-                                const uint32_t w3 = uint32_t(0.5f + (0.25f * (65535.0f / 65536.0f)) * s3);  // scaled domain (conv2)
+                                uint32_t w3 = uint32_t(0.5f + (0.25f * (65535.0f / 65536.0f)) * s3);  // scaled domain (conv2)
+                                // a LOD-1 texel of the block without data (0: only ever the result of a no-data quad): the valid-average
+                                if (kDma && min(min(q0, q1), min(other0, other1)) == 0) w3 = downsample4(q0, q1, other0, other1);
                                 const uint32_t cy3 = cy3_base + (cy >> 2);
                                 tile3[(b + cy3) * T + b + cx3] = uint16_t(w3);
                                 if (x3_count) xpush3(cy3, uint16_t(w3));
@@ -1118,12 +1152,6 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             }
         }
 
-        if constexpr (kDma) {
-            if (dirty) {  // (rare: straight into the masks the redo reads behind the loop)
-                atomicOr(&S.redo[(k - k_begin) >> 5], 1u << ((k - k_begin) & 31u));
-                atomicOr(&S.redo_waves[(k - k_begin) >> 3], 1u << (((k - k_begin) & 7u) * 4u + (tid >> 6)));
-            }
-        }
         if (!more) break;
         // chunk k + 1 goes into the other staging buffer (nobody reads it any more: its last readers passed the
         // previous barrier), the row table of chunk k + 3 replaces the one of chunk k after the barrier
@@ -1137,7 +1165,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         has_nodata = any_nodata(nodata, (k + 1) & 1u);
     }
     wg_stamp(2);
-    if constexpr (kStaged && !kGeneric) {
+    if constexpr (kStaged && !kGeneric && !kDma) {  // (kDma handles no-data where it meets it, inside the loop: fix)
         // ---- redo of the flagged chunks with the generic rows: stage the window once more (nobody reads LDS any more), run the
         // apron rows and the rows with validity.  Clean inputs pay one barrier and one LDS read per tile.
         __syncthreads();
@@ -1147,10 +1175,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             for (uint32_t k = k_begin; k < k_end; k++) {
                 if (!(((k - k_begin) < 32u ? redo0 >> (k - k_begin) : redo1 >> (k - k_begin - 32u)) & 1u)) continue;
                 window(k, ymin, slots);
-                if constexpr (kDma) {
-                    dma_issue(s_buf, ymin, slots);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                } else if (wide) {
+                if (wide) {
                     stage_issue(ymin, slots, pre);
                     stage_commit(s_buf, slots, pre);
                 } else {
@@ -1274,8 +1299,12 @@ __device__ __forceinline__ void tail_aprons_rgba8(const FusedArgs& A, uint32_t s
     }
 }
 
-template <uint32_t kFormat>
-__global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A) {
+// kRegular: the atlas indices follow the closed form (FusedArgs::regular) — as a compile-time fact the table lookups and their
+// registers fall away (64 VGPRs: eight waves per SIMD)
+template <uint32_t kFormat, bool kRegular>
+__global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A_in) {
+    FusedArgs A = A_in;
+    A.regular = kRegular ? 1u : 0u;
     constexpr bool kR16 = kFormat == BT_FORMAT_R16;
     using TT = typename std::conditional<kR16, uint16_t, uint32_t>::type;  // texel
     {
@@ -2162,6 +2191,21 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         args.grid_lod_lo = lod_lo;
         args.grid_lod_hi = lod_hi;
         args.grid_sides = sides;
+        {   // the closed form of grid_lookup: does every entry follow it?
+            const uint32_t hi4 = 4u << (2u * lod_hi), per_side = (hi4 - (1u << (2u * lod_lo))) / 3u, first = grids.empty() ? 0u : grids[grid_offsets[lod_hi]];
+            bool regular = first != kInvalid;
+            for (uint32_t side = 0; side < sides && regular; side++)
+                for (uint32_t lod = lod_lo; lod <= lod_hi && regular; lod++) {
+                    const uint32_t off = grid_offsets[side * 32 + lod], base = first + side * per_side + (hi4 - (4u << (2u * lod))) / 3u;
+                    for (size_t i = 0; i < (size_t(1) << (2 * lod)); i++)
+                        if (grids[off + i] != base + uint32_t(i)) { regular = false; break; }
+                }
+            args.regular = regular ? 1u : 0u;
+            args.reg_first = first;
+#ifdef BT_DEBUG_HOOKS
+            if (getenv("BT_FUSED_NO_REGULAR")) args.regular = 0;
+#endif
+        }
         if (upload_vector(p, items, &args.items) || upload_vector(p, grids, &args.grids))
             return false;
 
@@ -2575,8 +2619,13 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
             for (uint32_t k = 0; k < job.args.apron_lods; k++) extra += (1ull << (2 * (job.args.lod + k))) * blocks_per_tile;
             grid.y += uint32_t((extra + grid.x - 1) / grid.x);
         }
-        if (job.args.m.format == BT_FORMAT_R16) fused_tail_kernel<BT_FORMAT_R16><<<grid, 256, 0, p->ctx->stream>>>(job.args);
-        else fused_tail_kernel<BT_FORMAT_RGBA8><<<grid, 256, 0, p->ctx->stream>>>(job.args);
+        if (job.args.m.format == BT_FORMAT_R16) {
+            if (job.args.regular) fused_tail_kernel<BT_FORMAT_R16, true><<<grid, 256, 0, p->ctx->stream>>>(job.args);
+            else fused_tail_kernel<BT_FORMAT_R16, false><<<grid, 256, 0, p->ctx->stream>>>(job.args);
+        } else {
+            if (job.args.regular) fused_tail_kernel<BT_FORMAT_RGBA8, true><<<grid, 256, 0, p->ctx->stream>>>(job.args);
+            else fused_tail_kernel<BT_FORMAT_RGBA8, false><<<grid, 256, 0, p->ctx->stream>>>(job.args);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "fused kernel launch");
