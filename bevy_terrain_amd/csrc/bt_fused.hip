@@ -746,6 +746,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                 const uint16_t* h = A.atlas + uint64_t(nrow == kInvalid ? t5.self : nrow) * tile_texels + (b + S.apron[r].pad) * T + b;
                 if (min(t0.za, t1.za) == 0) va = h[rxa];
                 if (min(t0.zb, t1.zb) == 0) vb = h[rxb];
+                asm volatile("" : "+v"(va), "+v"(vb));  // (the values arrive inside the rare branch: no wait for everything in flight behind it)
             }
             tile5_u32[(py * T + px0) >> 1] = va | (vb << 16);
         }
@@ -975,6 +976,11 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                     if (min(z[i].x, z[i + 1].x) == 0) ua[i] = h[i * T + rxa];
                                     if (min(z[i].y, z[i + 1].y) == 0) ub[i] = h[i * T + rxb];
                                 }
+                                // the fetched values arrive HERE, inside the rare branch: left pending, the compiler guards the stores behind the
+                                // branch — on the fast path too — with s_waitcnt vmcnt(0), a wait for the next chunk's DMA rows and every store
+                                // in flight (first version of this fix: the clean 16k job 267 -> 312 us)
+#pragma unroll
+                                for (uint32_t i = 0; i < 4; i++) asm volatile("" : "+v"(ua[i]), "+v"(ub[i]));
                             }
                         }
                         if (!is_idle && !BT_ABLATE(A, 2u)) {
@@ -1106,6 +1112,8 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             if (min(min(r0[la0], r0[la1]), min(r1[la0], r1[la1])) == 0) ua[i] = h[i * T + rxa];
                             if (min(min(r0[lb0], r0[lb1]), min(r1[lb0], r1[lb1])) == 0) ub[i] = h[i * T + rxb];
                         }
+#pragma unroll
+                        for (uint32_t i = 0; i < 4; i++) asm volatile("" : "+v"(ua[i]), "+v"(ub[i]));  // (the values arrive inside the rare branch, see the static path)
                     }
                     const uint32_t py = b + cr0 + q;
                     if (!is_idle && !BT_ABLATE(A, 2u)) {
@@ -1965,7 +1973,8 @@ struct FusedJobDev {  // one fused launch of a compiled queue
     uint32_t attachment;
     uint32_t lds_pad = 0;    // profiling build only (BT_FUSED_LDS_PAD at plan time): extra dynamic LDS per workgroup
     bool dma = false;        // fused_main stages through LDS-DMA (every raster of the job 16-byte aligned in base and pitch)
-    std::vector<MainItem> host_items;  // fused_main's items as uploaded (tile-row order): streamed runs cut them into bands
+    std::vector<MainItem> host_items;  // fused_main's / fused_direct's items as uploaded (tile-row order): streamed runs cut fused_main's into bands, fused_source_window reads both
+    bool direct = false;     // a fused_direct launch (reads the source texel by texel: no staged window)
     float tly = 0.0f, bry = 1.0f;
 };
 
@@ -1973,6 +1982,7 @@ struct FusedJobDev {  // one fused launch of a compiled queue
 struct FusedState {
     std::vector<FusedJobDev> jobs;
     std::vector<void*> allocs;  // device buffers of the jobs (grids, item lists)
+    std::vector<uint8_t> whole_raster;  // [raster]: a launch without an item list (the hybrid plan's batched split) reads it: no window is known
 };
 
 }  // namespace bt
@@ -2012,6 +2022,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
     state.allocs.clear();
     std::vector<FusedJobDev>& jobs = state.jobs;
     jobs.clear();
+    state.whole_raster.assign(p->rasters.size(), 0);
     if (p->queue.empty()) return false;
 
     const std::vector<Task>& q = p->queue;
@@ -2254,7 +2265,10 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             ls.kind = kLaunchSplit;
             ls.attachment = ai;
             ls.first_task = uint32_t(tasks.size());
-            for (const Task* t : splits) tasks.push_back(device_task(*t));
+            for (const Task* t : splits) {
+                tasks.push_back(device_task(*t));
+                if (t->raster >= 0 && size_t(t->raster) < state.whole_raster.size()) state.whole_raster[size_t(t->raster)] = 1;  // (every rank splits every tile)
+            }
             ls.task_count = uint32_t(splits.size());
             ls.algorithmic_bytes = source_bytes + uint64_t(splits.size()) * Tt * Tt * bpp;
             plan.push_back(ls);
@@ -2272,6 +2286,10 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             job.args.lod = lod_hi;
             job.args.levels = main_levels;
             job.args.item_count = uint32_t(items.size());
+            job.host_items = items;
+            job.direct = true;
+            job.tly = args.tly;
+            job.bry = args.bry;
             {   // row blocks per workgroup: as many as keep at least one resident generation (1024 workgroups) busy
                 const uint64_t blocks = uint64_t(items.size()) * ((m.center_size + kDirectRows - 1) / kDirectRows);
                 job.args.groups = uint32_t(std::min<uint64_t>(kDirectMaxBlocks, std::max<uint64_t>(1, (blocks + 1023) / 1024)));
@@ -2494,12 +2512,15 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) { retur
 
 // Bands of whole tile rows of a fused main launch, with the last source row each band's kernels read (the bottom apron rows
 // of its last tile row are evaluated with the next tile row's formula: same f32 operations as the kernel's row tables).
-// The source texels [x0, x1) x [y0, y1) of raster `raster` that the fused main launches of the compiled plan read — for a sharded
-// preprocessor: this rank's column strips + their halo (finest aprons are evaluated from the source, staged windows start on an
-// 8-texel boundary and are lds_pitch wide).  Conservative (a missing neighbour tile only shrinks what the kernel reads).
-// false: no fused main launch reads this raster (or the plan is not fused): the caller assumes the whole raster.
+// The source texels [x0, x1) x [y0, y1) of raster `raster` that the launches of the compiled plan read — for a sharded
+// preprocessor: this rank's column strips + their halo (finest aprons are evaluated from the source; fused_main's staged windows
+// start on an 8-texel boundary and are lds_pitch wide; fused_direct reads texel by texel).  Conservative (a missing neighbour tile
+// only shrinks what the kernel reads).  Decided PER RASTER: false — the caller assumes the whole raster — unless every launch that
+// reads it is a fused_main / fused_direct launch with an item list (a height raster read by fused_main and an albedo raster read by
+// fused_direct in one queue get a window each; a raster the hybrid plan's batched split reads has none).
 bool fused_source_window(const bt_preprocessor* p, uint32_t raster, uint32_t out[4]) {
     if (!p->fused || raster >= p->rasters.size()) return false;
+    if (raster < p->fused->whole_raster.size() && p->fused->whole_raster[raster]) return false;
     const RasterDev& r = p->rasters[raster].dev;
     uint32_t x0 = r.width, y0 = r.height, x1 = 0, y1 = 0;
     bool any = false, known = false;
@@ -2518,10 +2539,12 @@ bool fused_source_window(const bt_preprocessor* p, uint32_t raster, uint32_t out
             const int hi_x = std::max(it.x + 1 < n ? ax(it.x + 1, b - 1).i1 : ax(it.x, c - 1).i1, ax(it.x, c - 1).i1);
             const int lo_y = std::min(it.y > 0 ? ay(it.y - 1, c - b).i0 : ay(it.y, 0).i0, ay(it.y, 0).i0);
             const int hi_y = std::max(it.y + 1 < n ? ay(it.y + 1, b - 1).i1 : ay(it.y, c - 1).i1, ay(it.y, c - 1).i1);
-            const uint32_t xa = uint32_t(std::max(lo_x, 0)) & ~7u;
-            uint32_t xe = uint32_t(hi_x) + 1u;
-            if (A.lds_rows) xe = std::max(xe, xa + A.lds_pitch);  // the staged window: lds_pitch texels from the aligned start
-            if (xe + 8u > r.width) xe = r.width;                   // (pieces past the row's end re-read its last 16 bytes)
+            uint32_t xa = uint32_t(std::max(lo_x, 0)), xe = uint32_t(hi_x) + 1u;
+            if (!job.direct) {
+                xa &= ~7u;
+                if (A.lds_rows) xe = std::max(xe, xa + A.lds_pitch);  // the staged window: lds_pitch texels from the aligned start
+                if (xe + 8u > r.width) xe = r.width;                   // (pieces past the row's end re-read its last 16 bytes)
+            }
             x0 = std::min(x0, xa);
             x1 = std::max(x1, std::min(xe, r.width));
             y0 = std::min(y0, uint32_t(std::max(lo_y, 0)));

@@ -1429,26 +1429,40 @@ namespace bt {
 bool fused_source_window(const bt_preprocessor* p, uint32_t raster, uint32_t out[4]);
 
 // Deferred host rasters travel when the queue runs.  A SHARDED preprocessor (compiled plan known) uploads only the texels its
-// own launches read — its column strips + halo (a rank never touches the rest of the source).
+// own launches read — its column strips + halo (a rank never touches the rest of the source).  What has travelled is
+// remembered per raster (Raster::uploaded): when a kept queue is compiled again — another rank / world (bt_preprocessor_set_shard),
+// BT_RUN_GENERIC or BT_RUN_REFERENCE_DISPATCH, whose launches read the whole raster — and its launches read texels outside that
+// window, the missing part travels before the run (the caller keeps the rows of a deferred raster alive until the queue is released).
 bt_status upload_pending_rasters(bt_preprocessor* p) {
     for (size_t i = 0; i < p->rasters.size(); i++) {
         Raster& r = p->rasters[i];
-        if (!r.pending) continue;
-        uint32_t w[4];
+        if (!r.host) continue;  // not a deferred raster
+        uint32_t w[4] = {0u, 0u, r.dev.width, r.dev.height};
         const uint64_t px = r.format == BT_FORMAT_R16 ? 2 : 4;
-        if (p->shard_world > 1 && p->compiled && fused_source_window(p, uint32_t(i), w)) {
-            p->uploaded_source_bytes = 0;
-            if (w[2] > w[0] && w[3] > w[1]) {
+        const bool window = p->shard_world > 1 && p->compiled && fused_source_window(p, uint32_t(i), w);
+        if (!window) {
+            w[0] = w[1] = 0;
+            w[2] = r.dev.width;
+            w[3] = r.dev.height;
+        }
+        const bool empty = !(w[2] > w[0] && w[3] > w[1]);
+        const bool covered = empty || (r.uploaded[2] > r.uploaded[0] && w[0] >= r.uploaded[0] && w[1] >= r.uploaded[1] && w[2] <= r.uploaded[2] && w[3] <= r.uploaded[3]);
+        if (!r.pending && covered) continue;
+        p->uploaded_source_bytes = 0;
+        if (!empty && !covered) {
+            if (w[0] == 0 && w[1] == 0 && w[2] == r.dev.width && w[3] == r.dev.height) {
+                BT_HIP(hipMemcpyAsync((void*)r.dev.data, r.host, r.host_bytes, hipMemcpyHostToDevice, p->ctx->stream));
+                p->uploaded_source_bytes = r.host_bytes;
+            } else {
                 const uint64_t off = uint64_t(w[1]) * r.dev.pitch + uint64_t(w[0]) * px;
                 BT_HIP(hipMemcpy2DAsync((uint8_t*)r.dev.data + off, r.dev.pitch, (const uint8_t*)r.host + off, r.dev.pitch, (w[2] - w[0]) * px, w[3] - w[1],
                                         hipMemcpyHostToDevice, p->ctx->stream));
                 p->uploaded_source_bytes = uint64_t(w[2] - w[0]) * px * (w[3] - w[1]);
             }
-        } else {
-            BT_HIP(hipMemcpyAsync((void*)r.dev.data, r.host, r.host_bytes, hipMemcpyHostToDevice, p->ctx->stream));
-            p->uploaded_source_bytes = r.host_bytes;
+            BT_HIP(hipStreamSynchronize(p->ctx->stream));
+            // (a window that does not contain the previous one replaces it in the record: the device still holds both, the record stays conservative)
+            for (int k = 0; k < 4; k++) r.uploaded[k] = w[k];
         }
-        BT_HIP(hipStreamSynchronize(p->ctx->stream));
         r.pending = false;
     }
     return BT_OK;
@@ -1602,7 +1616,12 @@ bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* a, const ch
         if (rc == BT_OK) publish(k + 1);
     }
     // the raster counts as uploaded only when every band went out; after a failure a later run of the kept queue uploads it whole
-    if (rc == BT_OK) r.pending = false;
+    if (rc == BT_OK) {
+        r.pending = false;
+        r.uploaded[0] = r.uploaded[1] = 0;  // every band has travelled: the whole raster
+        r.uploaded[2] = r.dev.width;
+        r.uploaded[3] = r.dev.height;
+    }
     for (size_t i = 1; i < p->plan.size() && rc == BT_OK; i++) rc = run_plan_entry(p, a, p->plan[i]);
     if (rc == BT_OK && hipEventRecord(computed[nb], p->ctx->stream) != hipSuccess) rc = BT_ERR_DEVICE;
     if (rc == BT_OK) publish(nb + 1);

@@ -121,6 +121,7 @@ bt_status ensure_compiled(bt_preprocessor* p, bt_atlas* a, uint32_t mode) {
         bool fused = false;
         if (!mode) fused = fused_plan(p, a, tasks, p->plan);
         if (!fused) {
+            fused_release(p);  // (a plan that was refused half way, or the fused plan of an earlier mode: bt_preprocessor_source_window must not see its jobs)
             tasks.clear();
             p->plan.clear();
             generic_plan(p, a, tasks, p->plan);

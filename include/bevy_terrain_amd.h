@@ -101,7 +101,10 @@ typedef struct bt_raster {
     uint32_t on_device;  /* 0: host memory (copied to the GPU by the call), 1: device pointer (borrowed
                             until the preprocessor has run), BT_RASTER_HOST_DEFERRED: host memory that stays the
                             caller's until the queue has run — copied by bt_preprocessor_run (all at once) or by
-                            bt_preprocessor_run_streamed (band by band, beside the kernels and the downloads) */
+                            bt_preprocessor_run_streamed (band by band, beside the kernels and the downloads).  A queue kept
+                            with BT_RUN_KEEP_QUEUE may read the rows again (only the window a sharded rank needs travels;
+                            a later bt_preprocessor_set_shard / other run flags fetch what is missing): keep them alive
+                            until the queue is released */
 } bt_raster;
 #define BT_RASTER_HOST_DEFERRED 2u
 
