@@ -17,8 +17,13 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bevy_terrain_amd.
 def header_abi_version() -> int:
     """BT_ABI_VERSION as include/bevy_terrain_amd.h declares it: the one place the number is written."""
     import re
-    with open(HEADER_PATH) as f:
-        m = re.search(r"^#define\s+BT_ABI_VERSION\s+(\d+)u?\s*$", f.read(), flags=re.M)
+    try:
+        with open(HEADER_PATH) as f:
+            text = f.read()
+    except OSError as e:  # a deployment without the sibling include/ directory: a load failure like any other
+        raise ImportError(f"bevy_terrain_amd: {HEADER_PATH} (the C ABI's header, which names the ABI version this binding checks the "
+                          f"library against) cannot be read: {e}") from e
+    m = re.search(r"^#define\s+BT_ABI_VERSION\s+(\d+)u?\s*$", text, flags=re.M)
     if not m:
         raise ImportError(f"{HEADER_PATH}: BT_ABI_VERSION not found")
     return int(m.group(1))

@@ -1431,6 +1431,190 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A_in) {
 }
 
 
+// ---- fused_tail, R16 (round 5): ONE dependent round trip, a quarter of the waves -------------------------------------
+// The kernel above is a latency chain over 21 k short waves: with every load, store and lookup compiled out it still takes 11.6 of its
+// 27 us (profiles/r05_tail_ablation.txt) — wave dispatch — and the rest is lookups -> loads -> stores -> lookups one after the other.
+// Here a thread owns 8 x 8 pixels of the input LOD's mosaic = four 4 x 4 blocks (c % 4 == 0: each inside one tile; the 8 x 8 block
+// may straddle two): all its 16 loads are issued at once, the 4 x 4 / 2 x 2 / 1 pixels of the three LODs below come out of registers
+// with no shuffle, tile indices are arithmetic where the atlas is in allocation order (FusedArgs::regular), and everything a thread
+// stores follows its one round of loads.  Workgroup = 16 x 16 threads = 128 x 128 input pixels (16k job: 1024 workgroups instead of
+// 4096).  The all-valid case of downsample.wgsl:25-39 runs two pixels at a time in the 2^16-scaled domain of fused_main's fast loop
+// (same operations, same order: bit-identical); a 2 x 2 block with a no-data texel takes downsample4.
+// Apron rows of the LODs fused_main produced: one workgroup per tile, four texel pairs per thread, loads before stores.
+__device__ __forceinline__ void tail2_apron_rows(const FusedArgs& A, uint32_t side, uint32_t e) {
+    const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
+    const uint32_t pairs = b * T;  // texel pairs of the 2b apron rows of a tile
+    for (uint32_t k = 0; k < A.apron_lods; k++) {
+        const uint32_t lod = A.lod + k, n = 1u << lod, blocks = n * n;
+        if (e >= blocks) {
+            e -= blocks;
+            continue;
+        }
+        const uint32_t tx = e / n, ty = e % n;
+        const uint32_t self = grid_lookup(A, side, lod, int(tx), int(ty));
+        if (self == kInvalid) return;
+        const uint32_t north = grid_lookup(A, side, lod, int(tx), int(ty) - 1), south = grid_lookup(A, side, lod, int(tx), int(ty) + 1);
+        uint32_t* dst_tile = reinterpret_cast<uint32_t*>(A.atlas + uint64_t(self) * T * T);
+        for (uint32_t base = 0; base < pairs; base += 1024u) {
+            uint32_t v[4], where[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                // branch-free (selects only): the eight loads of a thread leave back to back
+                const uint32_t i = base + j * 256u + threadIdx.x;
+                const bool in = i < pairs;
+                const uint32_t ii = in ? i : 0u;
+                const uint32_t r = ii / (T / 2u), px = 2u * (ii % (T / 2u)), py = r < b ? r : c + r;
+                const int rx = px < b ? -1 : (px >= o ? 1 : 0), ry = r < b ? -1 : 1;
+                // the neighbour that governs this pair (stitch.wgsl:57-66: rows first, corners by the diagonal one): the x neighbours only at the corners
+                const uint32_t nb = rx == 0 ? (ry < 0 ? north : south) : grid_lookup(A, side, lod, int(tx) + rx, int(ty) + ry);
+                const bool have = nb != kInvalid;
+                // the neighbour's centre texels — or, neighbour absent, the own centre clamped (a corner pair clamps to ONE texel)
+                const uint32_t sy = have ? uint32_t(int(py) - ry * int(c)) : min(max(py, b), o - 1u);
+                const uint32_t sx0 = have ? uint32_t(int(px) - rx * int(c)) : min(max(px, b), o - 1u);
+                const uint32_t sx1 = have ? sx0 + 1u : min(max(px + 1u, b), o - 1u);
+                const uint16_t* row = A.atlas + uint64_t(have ? nb : self) * T * T + sy * T;
+                where[j] = in ? (py * T + px) >> 1 : kInvalid;
+                v[j] = uint32_t(row[sx0]) | (uint32_t(row[sx1]) << 16);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++)
+                if (where[j] != kInvalid) dst_tile[where[j]] = v[j];
+        }
+        return;
+    }
+}
+
+template <bool kRegular>
+__global__ __launch_bounds__(256) void fused_tail2_kernel(FusedArgs A_in) {
+    FusedArgs A = A_in;
+    A.regular = kRegular ? 1u : 0u;  // (a compile-time fact: the table lookups and their registers fall away)
+    const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
+    const uint32_t size = (1u << A.lod) * c;  // mosaic extent of the input LOD (a multiple of 4)
+    {
+        const uint32_t ny = (size + 127u) / 128u;
+        if (blockIdx.y >= ny) {  // workgroups past the mosaic: the apron rows
+            if (BT_ABLATE(A, 268435456u)) return;  // (268435456: no apron workgroups — timing experiment)
+            tail2_apron_rows(A, blockIdx.z, (blockIdx.y - ny) * gridDim.x + blockIdx.x);
+            return;
+        }
+    }
+    const uint32_t tile_texels = T * T, side = blockIdx.z;
+    const uint32_t gx = blockIdx.x * 128u + 8u * (threadIdx.x & 15u), gy = blockIdx.y * 128u + 8u * (threadIdx.x >> 4);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+
+    // ---- the 16 loads: sub-block (sx, sy) = pixels [gx + 4 sx, +4) x [gy + 4 sy, +4), rows as two aligned dwords (b even)
+    uint32_t t[8][4];  // [row][dword]: dword d of row r holds pixels 2d, 2d + 1 of the thread's 8
+    bool live[2][2];
+#pragma unroll
+    for (uint32_t sy = 0; sy < 2; sy++)
+#pragma unroll
+        for (uint32_t sx = 0; sx < 2; sx++) {
+            const uint32_t x = gx + 4u * sx, y = gy + 4u * sy;
+            live[sy][sx] = x < size && y < size;
+            const uint32_t tile_x = x / c, tile_y = y / c;
+            const uint32_t idx = live[sy][sx] ? grid_lookup(A, side, A.lod, int(tile_x), int(tile_y)) : kInvalid;
+            const bool have = idx != kInvalid && !BT_ABLATE(A, 33554432u);  // an absent tile reads as no data  (33554432: no texel loads — timing experiment)
+            const uint16_t* p = A.atlas + uint64_t(have ? idx : 0u) * tile_texels + (b + (y - tile_y * c)) * T + b + (x - tile_x * c);
+#pragma unroll
+            for (uint32_t r = 0; r < 4; r++) {
+                // unconditional (an absent tile reads layer 0 and is zeroed afterwards): sixteen loads back to back, no branch around any
+                const uint2 w = *reinterpret_cast<const uint2 __attribute__((aligned(4)))*>(p + r * T);
+                t[4 * sy + r][2 * sx] = have ? w.x : 0u;
+                t[4 * sy + r][2 * sx + 1] = have ? w.y : 0u;
+            }
+        }
+
+    const f2 kr = {1.0f / 65535.0f, 1.0f / 65535.0f}, khalf = {0.5f, 0.5f}, knq = {0.25f * (65535.0f / 65536.0f), 0.25f * (65535.0f / 65536.0f)};
+    auto conv2 = [&](uint32_t a, uint32_t bq) -> f2 {  // (F(a), F(b)), F(t) = 65536 * RN(t / 65535): see fused_main's fast loop
+        const f2 x = {float(a), float(bq)};
+        return __builtin_elementwise_fma(x, kr, x);
+    };
+    // two 2 x 2 averages at once: block A = (a0 | a1) over (a2 | a3) as packed texel pairs (low half = x0), block B likewise.
+    // OFFSETS order (0,0),(0,1),(1,0),(1,1) of (dx, dy): ((x0y0 + x0y1) + x1y0) + x1y1
+    auto down_pair = [&](uint32_t a_top, uint32_t a_bot, uint32_t b_top, uint32_t b_bot, uint32_t& qa, uint32_t& qb) {
+        const u16x2 m = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_bit_cast(u16x2, a_top), __builtin_bit_cast(u16x2, a_bot)),
+                                                  __builtin_elementwise_min(__builtin_bit_cast(u16x2, b_top), __builtin_bit_cast(u16x2, b_bot)));
+        if (m.x != 0 && m.y != 0) {
+            const f2 sum = ((conv2(a_top & 0xFFFFu, b_top & 0xFFFFu) + conv2(a_bot & 0xFFFFu, b_bot & 0xFFFFu)) + conv2(a_top >> 16, b_top >> 16)) + conv2(a_bot >> 16, b_bot >> 16);
+            const f2 w = khalf + knq * sum;
+            qa = uint32_t(w.x);
+            qb = uint32_t(w.y);
+        } else {
+            qa = downsample4(a_top & 0xFFFFu, a_bot & 0xFFFFu, a_top >> 16, a_bot >> 16);
+            qb = downsample4(b_top & 0xFFFFu, b_bot & 0xFFFFu, b_top >> 16, b_bot >> 16);
+        }
+    };
+    // the same for values held one per register (the LODs further down)
+    auto down_pair4 = [&](uint32_t a00, uint32_t a01, uint32_t a10, uint32_t a11, uint32_t b00, uint32_t b01, uint32_t b10, uint32_t b11, uint32_t& qa, uint32_t& qb) {
+        if (min(min(min(a00, a01), min(a10, a11)), min(min(b00, b01), min(b10, b11))) != 0) {
+            const f2 sum = ((conv2(a00, b00) + conv2(a01, b01)) + conv2(a10, b10)) + conv2(a11, b11);
+            const f2 w = khalf + knq * sum;
+            qa = uint32_t(w.x);
+            qb = uint32_t(w.y);
+        } else {
+            qa = downsample4(a00, a01, a10, a11);
+            qb = downsample4(b00, b01, b10, b11);
+        }
+    };
+
+    // ---- lod-1: 4 x 4 pixels, q[row][col]; pixel (i, j) from rows 2i, 2i + 1 of dword j
+    uint32_t q[4][4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++)
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j += 2) down_pair(t[2 * i][j], t[2 * i + 1][j], t[2 * i][j + 1], t[2 * i + 1][j + 1], q[i][j], q[i][j + 1]);
+    const bool pre = true;  // b even (the fused plan's condition for R16): a 2 x 2 block with even coordinates shares its push targets
+    (void)pre;
+#pragma unroll
+    for (uint32_t sy = 0; sy < 2; sy++)
+#pragma unroll
+        for (uint32_t sx = 0; sx < 2; sx++) {
+            if (!live[sy][sx] || BT_ABLATE(A, 1073741824u)) continue;  // (1073741824: no lod-1 stores — timing experiment)
+            const uint32_t X = (gx >> 1) + 2u * sx, Y = (gy >> 1) + 2u * sy;  // first lod-1 mosaic pixel of the sub-block
+            const uint32_t tx1 = X / c, ty1 = Y / c, rx1 = X - tx1 * c, ry1 = Y - ty1 * c;
+            const uint32_t self = grid_lookup(A, side, A.lod - 1, int(tx1), int(ty1));
+            if (self == kInvalid) continue;
+            const PushNb nb1 = push_targets(A, side, A.lod - 1, tx1, ty1, rx1, ry1, !BT_ABLATE(A, 536870912u));  // (536870912: no apron pushes of lod-1)
+            uint16_t* centre = A.atlas + uint64_t(self) * tile_texels + (b + ry1) * T + b + rx1;
+#pragma unroll
+            for (uint32_t r = 0; r < 2; r++) {
+                *reinterpret_cast<uint32_t*>(centre + r * T) = q[2 * sy + r][2 * sx] | (q[2 * sy + r][2 * sx + 1] << 16);
+#pragma unroll
+                for (uint32_t k = 0; k < 2; k++) push_store<uint16_t>(A, nb1, self, rx1 + k, ry1 + r, uint16_t(q[2 * sy + r][2 * sx + k]));
+            }
+        }
+    if (A.levels < 2 || BT_ABLATE(A, 67108864u)) return;  // (67108864: lod-1 only — timing experiment)
+
+    // ---- lod-2: 2 x 2 pixels, one per sub-block
+    uint32_t p2[2][2];
+#pragma unroll
+    for (uint32_t i = 0; i < 2; i++)
+        down_pair4(q[2 * i][0], q[2 * i + 1][0], q[2 * i][1], q[2 * i + 1][1], q[2 * i][2], q[2 * i + 1][2], q[2 * i][3], q[2 * i + 1][3], p2[i][0], p2[i][1]);
+#pragma unroll
+    for (uint32_t sy = 0; sy < 2; sy++)
+#pragma unroll
+        for (uint32_t sx = 0; sx < 2; sx++) {
+            if (!live[sy][sx]) continue;
+            const uint32_t X = (gx >> 2) + sx, Y = (gy >> 2) + sy;
+            const uint32_t tx2 = X / c, ty2 = Y / c;
+            const uint32_t self = grid_lookup(A, side, A.lod - 2, int(tx2), int(ty2));
+            if (self != kInvalid) push_pixel<true, uint16_t>(A, side, A.lod - 2, tx2, ty2, self, X - tx2 * c, Y - ty2 * c, uint16_t(p2[sy][sx]));
+        }
+    if (A.levels < 3) return;
+
+    // ---- lod-3: one pixel (levels == 3 implies lod >= 3: the mosaic is a multiple of 8 wide, the 8 x 8 block is whole)
+    if (!live[0][0]) return;
+    const uint32_t v3 = downsample4(p2[0][0], p2[1][0], p2[0][1], p2[1][1]);
+    {
+        const uint32_t X = gx >> 3, Y = gy >> 3;
+        const uint32_t tx3 = X / c, ty3 = Y / c;
+        const uint32_t self = grid_lookup(A, side, A.lod - 3, int(tx3), int(ty3));
+        if (self != kInvalid) push_pixel<true, uint16_t>(A, side, A.lod - 3, tx3, ty3, self, X - tx3 * c, Y - ty3 * c, uint16_t(v3));
+    }
+}
+
+
 // ---- fused_direct (Rgba8): split + the two parent LODs WITHOUT LDS staging ------------------------------------------
 // Workgroup = several 4-row blocks of one finest tile (c = 508 = 127 x 4: no partial block), thread = one centre column (two
 // sweeps of 256).  The 5 source rows x 2 texels a column needs per block are requested ONE BLOCK AHEAD straight from global
@@ -2633,6 +2817,17 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
         }
     } else {
         const uint32_t size = (1u << job.args.lod) * job.args.m.center_size;
+        if (job.args.m.format == BT_FORMAT_R16 && (job.args.m.border_size & 1u) == 0) {  // (R16 in a fused plan: always)
+            dim3 grid((size + 127) / 128, (size + 127) / 128, job.args.sides);
+            uint64_t extra = 0;  // apron rows of the LODs fused_main produced: one workgroup per tile
+            for (uint32_t k = 0; k < job.args.apron_lods; k++) extra += 1ull << (2 * (job.args.lod + k));
+            grid.y += uint32_t((extra + grid.x - 1) / grid.x);
+            if (job.args.regular) fused_tail2_kernel<true><<<grid, 256, 0, p->ctx->stream>>>(job.args);
+            else fused_tail2_kernel<false><<<grid, 256, 0, p->ctx->stream>>>(job.args);
+            hipError_t e2 = hipGetLastError();
+            if (e2 != hipSuccess) return hip_fail(e2, "fused kernel launch");
+            return BT_OK;
+        }
         dim3 grid((size + 63) / 64, (size + 63) / 64, job.args.sides);
         if (job.args.apron_lods) {
             const uint32_t blocks_per_tile = job.args.m.format == BT_FORMAT_R16

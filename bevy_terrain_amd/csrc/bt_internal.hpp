@@ -244,6 +244,7 @@ struct bt_preprocessor {
     std::vector<hipEvent_t> events;
     std::vector<hipEvent_t> event_pool;  // events read by bt_preprocessor_profile, kept for the next profiled runs (no hipEventCreate inside a timed step)
     uint32_t profiled_runs = 0;
+    std::vector<uint32_t> profiled_phases;  // per profiled run: BT_RUN_SHARD_LOCAL | BT_RUN_SHARD_FINISH bits of the plan halves it executed
 };
 
 namespace bt {
@@ -269,4 +270,5 @@ namespace bt {
 // the three forms of the tiling prepass with the view's approximate_height optionally taken from device memory (bt_frame_update);
 // form: 0 = bt_tiling_prepass_run, 1 = _run_unordered, 2 = _run_plain
 bt_status tiling_prepass_enqueue(bt_tiling_prepass* t, const bt_view_state* view, const float* device_height, uint32_t form);
+bt_ctx* tiling_prepass_ctx(const bt_tiling_prepass* t);  // the context (stream) its kernels run on
 }  // namespace bt

@@ -458,6 +458,10 @@ __global__ __launch_bounds__(kThreads) void tiling_prepass_kernel(bt_view_state 
 
 using namespace bt;
 
+namespace bt {
+bt_ctx* tiling_prepass_ctx(const bt_tiling_prepass* t) { return t ? t->ctx : nullptr; }
+}  // namespace bt
+
 extern "C" {
 
 bt_status bt_tiling_prepass_create(bt_ctx* ctx, uint32_t geometry_tile_count, bt_tiling_prepass** out) {

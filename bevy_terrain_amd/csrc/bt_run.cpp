@@ -20,7 +20,7 @@ bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l);
 
 namespace {
 
-constexpr uint32_t kMaxProfiledRuns = 256;  // events kept until bt_preprocessor_profile reads them
+constexpr uint32_t kMaxProfiledRuns = 512;  // events kept until bt_preprocessor_profile reads them
 
 TaskDev to_device_task(const Task& t) {
     TaskDev d{};
@@ -158,6 +158,7 @@ bt_status ensure_compiled(bt_preprocessor* p, bt_atlas* a, uint32_t mode) {
         p->event_pool.insert(p->event_pool.end(), p->events.begin(), p->events.end());
         p->events.clear();
         p->profiled_runs = 0;
+        p->profiled_phases.clear();
     }
     return BT_OK;
 }
@@ -235,7 +236,12 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
         if (profile)
             if (bt_status s2 = record()) return s2;
     }
-    if (profile) p->profiled_runs++;
+    if (profile) {
+        // which halves of the plan this run executed: a sharded step is two profiled runs (local, finish) that each leave a whole event row;
+        // bt_preprocessor_profile averages a launch over the rows that ran it
+        p->profiled_phases.push_back(sharded ? (flags & (BT_RUN_SHARD_LOCAL | BT_RUN_SHARD_FINISH)) : uint32_t(BT_RUN_SHARD_LOCAL | BT_RUN_SHARD_FINISH));
+        p->profiled_runs++;
+    }
 
     // Save tasks: remembered until bt_preprocessor_save (the reference starts them as tasks drain)
     if (!p->saves_recorded) {  // (re-runs of a kept queue produce the same tiles: recorded once per queue and save)
@@ -279,20 +285,26 @@ extern "C" bt_status bt_preprocessor_profile(bt_preprocessor* p, bt_launch_profi
     for (uint32_t i = 0; i < n && i < cap; i++) {
         const Launch& l = p->plan[i];
         double total = 0.0;
+        uint32_t samples = 0;
         for (uint32_t r = 0; r < p->profiled_runs; r++) {
+            // a run that skipped this launch (the other half of a sharded step) is not a sample of it
+            const uint32_t ran = r < p->profiled_phases.size() ? p->profiled_phases[r] : uint32_t(BT_RUN_SHARD_LOCAL | BT_RUN_SHARD_FINISH);
+            if (!(ran & (l.phase == 2 ? BT_RUN_SHARD_FINISH : BT_RUN_SHARD_LOCAL))) continue;
             float ms = 0.0f;
             BT_HIP(hipEventElapsedTime(&ms, p->events[size_t(r) * (n + 1) + i], p->events[size_t(r) * (n + 1) + i + 1]));
             total += ms;
+            samples++;
         }
         out[i].kind = uint32_t(l.kind);
         out[i].tasks = l.task_count;
         out[i].algorithmic_bytes = l.algorithmic_bytes;
-        out[i].samples = p->profiled_runs;
-        out[i].avg_ms = p->profiled_runs ? float(total / p->profiled_runs) : 0.0f;
+        out[i].samples = samples;
+        out[i].avg_ms = samples ? float(total / samples) : 0.0f;
     }
     p->event_pool.insert(p->event_pool.end(), p->events.begin(), p->events.end());
     p->events.clear();
     p->profiled_runs = 0;
+    p->profiled_phases.clear();
     return BT_OK;
 }
 

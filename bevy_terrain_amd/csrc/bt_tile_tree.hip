@@ -253,7 +253,7 @@ __device__ __forceinline__ void sample_lookup(const AttachmentMeta& m, const voi
 // sample_attachment / sample_height (terrain_data/mod.rs:265-307), one world position per thread
 __global__ __launch_bounds__(128) void tile_tree_sample_kernel(TreeParams P, const bt_tile_tree_entry* __restrict__ entries, AttachmentMeta m,
                                                                const void* __restrict__ atlas, const double* __restrict__ positions, uint32_t count,
-                                                               float4* __restrict__ out, float* __restrict__ heights, const float* __restrict__ height) {
+                                                               float4* __restrict__ out, float* heights, const float* height) {  // (heights / height may be ONE buffer — enqueue_height reads the old height, then overwrites it: no __restrict__)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const float approximate_height = height ? *height : P.approximate_height;
@@ -650,6 +650,11 @@ bt_status bt_frame_update(bt_tile_tree* t, bt_atlas* a, bt_tiling_prepass* prepa
     if (!t || !a || !view_world_position) return BT_ERR_INVALID_ARGUMENT;
     if (t->ctx != a->ctx) {
         set_error("tile tree and atlas belong to different contexts");
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    if (prepass && bt::tiling_prepass_ctx(prepass) != t->ctx) {
+        // the prepass kernels read the height the sample kernel of THIS call leaves on the device: ordered only on one stream
+        set_error("tile tree and tiling prepass belong to different contexts");
         return BT_ERR_INVALID_ARGUMENT;
     }
     BT_HIP(hipSetDevice(t->ctx->device));
