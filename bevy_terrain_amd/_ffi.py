@@ -160,6 +160,8 @@ PROTOTYPES = {
     "bt_ctx_stream": (_vp, [_vp]),
     "bt_ctx_synchronize": (_i32, [_vp]),
     "bt_ctx_trim": (_i32, [_vp, C.POINTER(C.c_uint64)]),
+    "bt_ctx_set_io_threads": (_i32, [_vp, C.c_uint32]),
+    "bt_ctx_io_threads": (C.c_uint32, [_vp]),
     "bt_ctx_timer_begin": (_i32, [_vp]),
     "bt_ctx_timer_end": (_i32, [_vp, _P(C.c_float)]),
     "bt_device_malloc": (_i32, [_vp, C.c_size_t, _P(_vp)]),
@@ -213,6 +215,7 @@ PROTOTYPES = {
     "bt_comm_adopt": (_i32, [_vp, _vp, _u32, _u32, _P(_vp)]),
     "bt_comm_destroy": (None, [_vp]),
     "bt_comm_check": (_i32, [_vp]),
+    "bt_comm_preflight": (_i32, [_vp, C.c_uint64, C.POINTER(C.c_float)]),
     "bt_preprocessor_run_sharded": (_i32, [_vp, _vp, _vp, _u32]),
     "bt_preprocessor_finish_sharded": (_i32, [_vp, _vp, _vp, _u32]),
     "bt_preprocessor_source_window": (_i32, [_vp, _vp, _u32, _u32, _P(C.c_uint32), _P(C.c_uint64)]),

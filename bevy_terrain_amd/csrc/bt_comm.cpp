@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <vector>
 
 #include "bt_internal.hpp"
 
@@ -141,43 +142,56 @@ void bt_comm_destroy(bt_comm* comm) {
     delete comm;
 }
 
-// A health check of the communicator on the context's stream: every rank fills its slot of a small device buffer
-// with a rank pattern, ONE grouped collective (in-place all-gather + in-place broadcast from the last rank) moves
-// them, and the result is verified on the host.
-bt_status bt_comm_check(bt_comm* comm) {
-    if (!comm) return BT_ERR_INVALID_ARGUMENT;
+// A health check of the communicator on the context's stream: every rank fills its slot of a device buffer with a rank pattern,
+// ONE grouped collective (in-place all-gather + in-place broadcast from the last rank — the two shapes a sharded step issues) moves
+// them, and every byte is verified on the host.  bt_comm_check: 4 KB slots; bt_comm_preflight: the caller's slot size (an atlas tile).
+bt_status bt_comm_preflight(bt_comm* comm, uint64_t slot_bytes, float* elapsed_ms) {
+    if (!comm || slot_bytes == 0 || slot_bytes > (1ull << 30)) return BT_ERR_INVALID_ARGUMENT;
     if (bt_status s = need_rccl()) return s;
     bt_ctx* ctx = comm->ctx;
     BT_HIP(hipSetDevice(ctx->device));
-    const size_t slot = 4096, total = slot * (comm->world + 1);
+    const size_t slot = size_t(slot_bytes), total = slot * (comm->world + 1);
     uint8_t* dev = nullptr;
     BT_HIP(hipMalloc((void**)&dev, total));
     std::vector<uint8_t> host(total, 0);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     bt_status rc = BT_OK;
-    hipError_t e = hipMemsetAsync(dev, 0, total, ctx->stream);
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipMemsetAsync(dev, 0, total, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(dev + slot * comm->rank, int(0x40 + comm->rank), slot, ctx->stream);
     if (e == hipSuccess && comm->rank == comm->world - 1) e = hipMemsetAsync(dev + slot * comm->world, 0x7E, slot, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
     if (e == hipSuccess) {
         const Rccl& R = rccl();
         int r0 = R.GroupStart();
         int r1 = R.AllGather(dev + slot * comm->rank, dev, slot, kNcclUint8, comm->comm, ctx->stream);
         int r2 = R.Broadcast(dev + slot * comm->world, dev + slot * comm->world, slot, kNcclUint8, int(comm->world - 1), comm->comm, ctx->stream);
         int r3 = R.GroupEnd();
-        if (r0 || r1 || r2 || r3) rc = nccl_fail(r0 ? r0 : r1 ? r1 : r2 ? r2 : r3, "bt_comm_check collective");
+        if (r0 || r1 || r2 || r3) rc = nccl_fail(r0 ? r0 : r1 ? r1 : r2 ? r2 : r3, "bt_comm_preflight collective");
     }
+    if (e == hipSuccess && rc == BT_OK) e = hipEventRecord(e1, ctx->stream);
     if (e == hipSuccess && rc == BT_OK) e = hipMemcpyAsync(host.data(), dev, total, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && rc == BT_OK) e = hipStreamSynchronize(ctx->stream);
+    float ms = 0.0f;
+    if (e == hipSuccess && rc == BT_OK) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
     hipFree(dev);
-    if (e != hipSuccess) return hip_fail(e, "bt_comm_check");
+    if (e != hipSuccess) return hip_fail(e, "bt_comm_preflight");
     if (rc) return rc;
     for (uint32_t r = 0; r <= comm->world; r++)
         for (size_t i = 0; i < slot; i++)
             if (host[slot * r + i] != (r == comm->world ? 0x7E : uint8_t(0x40 + r))) {
-                set_error("bt_comm_check: slot %u byte %zu holds 0x%02x", r, i, host[slot * r + i]);
+                set_error("bt_comm_preflight: rank %u of %u: slot %u byte %zu holds 0x%02x after the grouped all-gather + broadcast", comm->rank, comm->world, r, i,
+                          host[slot * r + i]);
                 return BT_ERR_DEVICE;
             }
+    if (elapsed_ms) *elapsed_ms = ms;
     return BT_OK;
 }
+
+bt_status bt_comm_check(bt_comm* comm) { return bt_comm_preflight(comm, 4096, nullptr); }
 
 bt_status bt_preprocessor_shard_pieces(const bt_preprocessor* p, bt_shard_piece* out, uint32_t cap, uint32_t* count) {
     if (!p || !count) return BT_ERR_INVALID_ARGUMENT;

@@ -1503,19 +1503,23 @@ __global__ __launch_bounds__(256) void fused_tail2_kernel(FusedArgs A_in) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 
-    // ---- the 16 loads: sub-block (sx, sy) = pixels [gx + 4 sx, +4) x [gy + 4 sy, +4), rows as two aligned dwords (b even)
+    // ---- the 16 loads: sub-block (sx, sy) = pixels [gx + 4 sx, +4) x [gy + 4 sy, +4), rows as two aligned dwords (b even).
+    // ONE division per axis: the second sub-block is the next tile's first one or 4 pixels on; the tile / in-tile coordinates of a
+    // pixel k LODs down follow by shifts: floor(floor(x / 2^k) / c) = floor(x / c) >> k (as in the kernel above)
+    const uint32_t tile_x0 = gx / c, rem_x0 = gx - tile_x0 * c, tile_y0 = gy / c, rem_y0 = gy - tile_y0 * c;
+    const bool wrap_x = rem_x0 + 4u >= c, wrap_y = rem_y0 + 4u >= c;
+    const uint32_t tile_xs[2] = {tile_x0, wrap_x ? tile_x0 + 1u : tile_x0}, rem_xs[2] = {rem_x0, wrap_x ? rem_x0 + 4u - c : rem_x0 + 4u};
+    const uint32_t tile_ys[2] = {tile_y0, wrap_y ? tile_y0 + 1u : tile_y0}, rem_ys[2] = {rem_y0, wrap_y ? rem_y0 + 4u - c : rem_y0 + 4u};
     uint32_t t[8][4];  // [row][dword]: dword d of row r holds pixels 2d, 2d + 1 of the thread's 8
     bool live[2][2];
 #pragma unroll
     for (uint32_t sy = 0; sy < 2; sy++)
 #pragma unroll
         for (uint32_t sx = 0; sx < 2; sx++) {
-            const uint32_t x = gx + 4u * sx, y = gy + 4u * sy;
-            live[sy][sx] = x < size && y < size;
-            const uint32_t tile_x = x / c, tile_y = y / c;
-            const uint32_t idx = live[sy][sx] ? grid_lookup(A, side, A.lod, int(tile_x), int(tile_y)) : kInvalid;
+            live[sy][sx] = gx + 4u * sx < size && gy + 4u * sy < size;
+            const uint32_t idx = live[sy][sx] ? grid_lookup(A, side, A.lod, int(tile_xs[sx]), int(tile_ys[sy])) : kInvalid;
             const bool have = idx != kInvalid && !BT_ABLATE(A, 33554432u);  // an absent tile reads as no data  (33554432: no texel loads — timing experiment)
-            const uint16_t* p = A.atlas + uint64_t(have ? idx : 0u) * tile_texels + (b + (y - tile_y * c)) * T + b + (x - tile_x * c);
+            const uint16_t* p = A.atlas + uint64_t(have ? idx : 0u) * tile_texels + (b + rem_ys[sy]) * T + b + rem_xs[sx];
 #pragma unroll
             for (uint32_t r = 0; r < 4; r++) {
                 // unconditional (an absent tile reads layer 0 and is zeroed afterwards): sixteen loads back to back, no branch around any
@@ -1525,37 +1529,53 @@ __global__ __launch_bounds__(256) void fused_tail2_kernel(FusedArgs A_in) {
             }
         }
 
-    const f2 kr = {1.0f / 65535.0f, 1.0f / 65535.0f}, khalf = {0.5f, 0.5f}, knq = {0.25f * (65535.0f / 65536.0f), 0.25f * (65535.0f / 65536.0f)};
-    auto conv2 = [&](uint32_t a, uint32_t bq) -> f2 {  // (F(a), F(b)), F(t) = 65536 * RN(t / 65535): see fused_main's fast loop
+    // downsample.wgsl:25-39 in the 2^16-scaled domain of fused_main's fast loop, two pixels per packed operation.  F(t) = fma(x, r, x) =
+    // 65536 * RN(t / 65535) and F(0) = 0: a no-data texel adds an exact 0 to the running sum, so ((F00 + F01) + F10) + F11 IS the sum over
+    // the valid texels in OFFSETS order, rounding for rounding; what differs is the divisor.  All four valid (the common case):
+    // 0.5 + (0.25 * k) * sum with k = 65535 / 65536 (sum * 0.25 is exact).  Otherwise one IEEE division by the count — scaling by a power of
+    // two commutes with it, and an average of values <= 1 needs no clamp — and count 0 gives 0.5 + k * (0 / 1) -> 0, the defined "no data".
+    const f2 kr = {1.0f / 65535.0f, 1.0f / 65535.0f}, khalf = {0.5f, 0.5f}, kn = {65535.0f / 65536.0f, 65535.0f / 65536.0f};
+    const f2 knq = {0.25f * (65535.0f / 65536.0f), 0.25f * (65535.0f / 65536.0f)};
+    auto conv2 = [&](uint32_t a, uint32_t bq) -> f2 {
         const f2 x = {float(a), float(bq)};
         return __builtin_elementwise_fma(x, kr, x);
     };
-    // two 2 x 2 averages at once: block A = (a0 | a1) over (a2 | a3) as packed texel pairs (low half = x0), block B likewise.
-    // OFFSETS order (0,0),(0,1),(1,0),(1,1) of (dx, dy): ((x0y0 + x0y1) + x1y0) + x1y1
-    auto down_pair = [&](uint32_t a_top, uint32_t a_bot, uint32_t b_top, uint32_t b_bot, uint32_t& qa, uint32_t& qb) {
-        const u16x2 m = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_bit_cast(u16x2, a_top), __builtin_bit_cast(u16x2, a_bot)),
-                                                  __builtin_elementwise_min(__builtin_bit_cast(u16x2, b_top), __builtin_bit_cast(u16x2, b_bot)));
-        if (m.x != 0 && m.y != 0) {
-            const f2 sum = ((conv2(a_top & 0xFFFFu, b_top & 0xFFFFu) + conv2(a_bot & 0xFFFFu, b_bot & 0xFFFFu)) + conv2(a_top >> 16, b_top >> 16)) + conv2(a_bot >> 16, b_bot >> 16);
-            const f2 w = khalf + knq * sum;
-            qa = uint32_t(w.x);
-            qb = uint32_t(w.y);
-        } else {
-            qa = downsample4(a_top & 0xFFFFu, a_bot & 0xFFFFu, a_top >> 16, a_bot >> 16);
-            qb = downsample4(b_top & 0xFFFFu, b_bot & 0xFFFFu, b_top >> 16, b_bot >> 16);
+    auto finish = [&](f2 sum, bool all_valid, uint32_t cnt_a, uint32_t cnt_b, uint32_t& qa, uint32_t& qb) {
+        f2 w = khalf + knq * sum;
+        if (!all_valid) {  // (rare) some texel has no data: the valid-average
+            const f2 d = {sum.x / float(max(cnt_a, 1u)), sum.y / float(max(cnt_b, 1u))};
+            w = khalf + kn * d;
         }
+        qa = uint32_t(w.x);
+        qb = uint32_t(w.y);
+    };
+    // block A = (a_top | a_bot), block B likewise: packed texel pairs (low half = x0).  OFFSETS order (0,0),(0,1),(1,0),(1,1) of (dx, dy)
+    auto down_pair = [&](uint32_t a_top, uint32_t a_bot, uint32_t b_top, uint32_t b_bot, uint32_t& qa, uint32_t& qb) {
+        const u16x2 one = {1, 1};
+        const u16x2 ma = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a_top), __builtin_bit_cast(u16x2, a_bot));
+        const u16x2 mb = __builtin_elementwise_min(__builtin_bit_cast(u16x2, b_top), __builtin_bit_cast(u16x2, b_bot));
+        const u16x2 m = __builtin_elementwise_min(ma, mb);
+        const f2 sum = ((conv2(a_top & 0xFFFFu, b_top & 0xFFFFu) + conv2(a_bot & 0xFFFFu, b_bot & 0xFFFFu)) + conv2(a_top >> 16, b_top >> 16)) + conv2(a_bot >> 16, b_bot >> 16);
+        const bool all_valid = m.x != 0 && m.y != 0;
+        uint32_t cnt_a = 4, cnt_b = 4;
+        if (!all_valid) {
+            const u16x2 ca = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a_top), one) + __builtin_elementwise_min(__builtin_bit_cast(u16x2, a_bot), one);
+            const u16x2 cb = __builtin_elementwise_min(__builtin_bit_cast(u16x2, b_top), one) + __builtin_elementwise_min(__builtin_bit_cast(u16x2, b_bot), one);
+            cnt_a = uint32_t(ca.x) + uint32_t(ca.y);
+            cnt_b = uint32_t(cb.x) + uint32_t(cb.y);
+        }
+        finish(sum, all_valid, cnt_a, cnt_b, qa, qb);
     };
     // the same for values held one per register (the LODs further down)
     auto down_pair4 = [&](uint32_t a00, uint32_t a01, uint32_t a10, uint32_t a11, uint32_t b00, uint32_t b01, uint32_t b10, uint32_t b11, uint32_t& qa, uint32_t& qb) {
-        if (min(min(min(a00, a01), min(a10, a11)), min(min(b00, b01), min(b10, b11))) != 0) {
-            const f2 sum = ((conv2(a00, b00) + conv2(a01, b01)) + conv2(a10, b10)) + conv2(a11, b11);
-            const f2 w = khalf + knq * sum;
-            qa = uint32_t(w.x);
-            qb = uint32_t(w.y);
-        } else {
-            qa = downsample4(a00, a01, a10, a11);
-            qb = downsample4(b00, b01, b10, b11);
+        const bool all_valid = min(min(min(a00, a01), min(a10, a11)), min(min(b00, b01), min(b10, b11))) != 0;
+        const f2 sum = ((conv2(a00, b00) + conv2(a01, b01)) + conv2(a10, b10)) + conv2(a11, b11);
+        uint32_t cnt_a = 4, cnt_b = 4;
+        if (!all_valid) {
+            cnt_a = min(a00, 1u) + min(a01, 1u) + min(a10, 1u) + min(a11, 1u);
+            cnt_b = min(b00, 1u) + min(b01, 1u) + min(b10, 1u) + min(b11, 1u);
         }
+        finish(sum, all_valid, cnt_a, cnt_b, qa, qb);
     };
 
     // ---- lod-1: 4 x 4 pixels, q[row][col]; pixel (i, j) from rows 2i, 2i + 1 of dword j
@@ -1564,26 +1584,39 @@ __global__ __launch_bounds__(256) void fused_tail2_kernel(FusedArgs A_in) {
     for (uint32_t i = 0; i < 4; i++)
 #pragma unroll
         for (uint32_t j = 0; j < 4; j += 2) down_pair(t[2 * i][j], t[2 * i + 1][j], t[2 * i][j + 1], t[2 * i + 1][j + 1], q[i][j], q[i][j + 1]);
-    const bool pre = true;  // b even (the fused plan's condition for R16): a 2 x 2 block with even coordinates shares its push targets
-    (void)pre;
-#pragma unroll
-    for (uint32_t sy = 0; sy < 2; sy++)
-#pragma unroll
-        for (uint32_t sx = 0; sx < 2; sx++) {
-            if (!live[sy][sx] || BT_ABLATE(A, 1073741824u)) continue;  // (1073741824: no lod-1 stores — timing experiment)
-            const uint32_t X = (gx >> 1) + 2u * sx, Y = (gy >> 1) + 2u * sy;  // first lod-1 mosaic pixel of the sub-block
-            const uint32_t tx1 = X / c, ty1 = Y / c, rx1 = X - tx1 * c, ry1 = Y - ty1 * c;
+    // The stores of a level go through ONE rolled loop over the four sub-blocks (values picked by selects): unrolled, the apron pushes —
+    // executed by the few threads within b of a tile edge — were 7 of the kernel's 9 thousand instructions.
+    auto sel4 = [](uint32_t i, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) -> uint32_t { return i == 0 ? v0 : (i == 1 ? v1 : (i == 2 ? v2 : v3)); };
+    const uint32_t live_mask = (live[0][0] ? 1u : 0u) | (live[0][1] ? 2u : 0u) | (live[1][0] ? 4u : 0u) | (live[1][1] ? 8u : 0u);
+    if (!BT_ABLATE(A, 1073741824u)) {  // (1073741824: no lod-1 stores — timing experiment)
+        // packed rows of the sub-blocks' 2 x 2 lod-1 pixels: [sub-block][row]
+        const uint32_t r00 = q[0][0] | (q[0][1] << 16), r01 = q[1][0] | (q[1][1] << 16), r10 = q[0][2] | (q[0][3] << 16), r11 = q[1][2] | (q[1][3] << 16);
+        const uint32_t r20 = q[2][0] | (q[2][1] << 16), r21 = q[3][0] | (q[3][1] << 16), r30 = q[2][2] | (q[2][3] << 16), r31 = q[3][2] | (q[3][3] << 16);
+#pragma nounroll
+        for (uint32_t sb = 0; sb < 4; sb++) {
+            if (!((live_mask >> sb) & 1u)) continue;
+            const uint32_t sx = sb & 1u, sy = sb >> 1;
+            const uint32_t tile_x = sx ? tile_xs[1] : tile_xs[0], tile_y = sy ? tile_ys[1] : tile_ys[0];
+            const uint32_t rem_x = sx ? rem_xs[1] : rem_xs[0], rem_y = sy ? rem_ys[1] : rem_ys[0];
+            // the sub-block's 2 x 2 lod-1 pixels lie in one lod-1 tile (4 x 4 block inside one input tile)
+            const uint32_t tx1 = tile_x >> 1, ty1 = tile_y >> 1, rx1 = ((tile_x & 1u) * c + rem_x) >> 1, ry1 = ((tile_y & 1u) * c + rem_y) >> 1;
             const uint32_t self = grid_lookup(A, side, A.lod - 1, int(tx1), int(ty1));
             if (self == kInvalid) continue;
-            const PushNb nb1 = push_targets(A, side, A.lod - 1, tx1, ty1, rx1, ry1, !BT_ABLATE(A, 536870912u));  // (536870912: no apron pushes of lod-1)
+            const uint32_t row0 = sel4(sb, r00, r10, r20, r30), row1 = sel4(sb, r01, r11, r21, r31);
             uint16_t* centre = A.atlas + uint64_t(self) * tile_texels + (b + ry1) * T + b + rx1;
-#pragma unroll
-            for (uint32_t r = 0; r < 2; r++) {
-                *reinterpret_cast<uint32_t*>(centre + r * T) = q[2 * sy + r][2 * sx] | (q[2 * sy + r][2 * sx + 1] << 16);
-#pragma unroll
-                for (uint32_t k = 0; k < 2; k++) push_store<uint16_t>(A, nb1, self, rx1 + k, ry1 + r, uint16_t(q[2 * sy + r][2 * sx + k]));
+            *reinterpret_cast<uint32_t*>(centre) = row0;
+            *reinterpret_cast<uint32_t*>(centre + T) = row1;
+            // aprons: only a block within b of its tile's edge pushes (b even: the 2 x 2 block with even coordinates shares its targets)
+            if ((rx1 < b || rx1 + 2u > c - b || ry1 < b || ry1 + 2u > c - b) && !BT_ABLATE(A, 536870912u)) {  // (536870912: no apron pushes of lod-1)
+                const PushNb nb1 = push_targets(A, side, A.lod - 1, tx1, ty1, rx1, ry1, true);
+#pragma nounroll
+                for (uint32_t e = 0; e < 4; e++) {
+                    const uint32_t row = (e & 2u) ? row1 : row0;
+                    push_store<uint16_t>(A, nb1, self, rx1 + (e & 1u), ry1 + (e >> 1), uint16_t((e & 1u) ? row >> 16 : row & 0xFFFFu));
+                }
             }
         }
+    }
     if (A.levels < 2 || BT_ABLATE(A, 67108864u)) return;  // (67108864: lod-1 only — timing experiment)
 
     // ---- lod-2: 2 x 2 pixels, one per sub-block
@@ -1591,29 +1624,35 @@ __global__ __launch_bounds__(256) void fused_tail2_kernel(FusedArgs A_in) {
 #pragma unroll
     for (uint32_t i = 0; i < 2; i++)
         down_pair4(q[2 * i][0], q[2 * i + 1][0], q[2 * i][1], q[2 * i + 1][1], q[2 * i][2], q[2 * i + 1][2], q[2 * i][3], q[2 * i + 1][3], p2[i][0], p2[i][1]);
-#pragma unroll
-    for (uint32_t sy = 0; sy < 2; sy++)
-#pragma unroll
-        for (uint32_t sx = 0; sx < 2; sx++) {
-            if (!live[sy][sx]) continue;
-            const uint32_t X = (gx >> 2) + sx, Y = (gy >> 2) + sy;
-            const uint32_t tx2 = X / c, ty2 = Y / c;
-            const uint32_t self = grid_lookup(A, side, A.lod - 2, int(tx2), int(ty2));
-            if (self != kInvalid) push_pixel<true, uint16_t>(A, side, A.lod - 2, tx2, ty2, self, X - tx2 * c, Y - ty2 * c, uint16_t(p2[sy][sx]));
-        }
+#pragma nounroll
+    for (uint32_t sb = 0; sb < 4; sb++) {
+        if (!((live_mask >> sb) & 1u)) continue;
+        const uint32_t sx = sb & 1u, sy = sb >> 1;
+        const uint32_t tile_x = sx ? tile_xs[1] : tile_xs[0], tile_y = sy ? tile_ys[1] : tile_ys[0];
+        const uint32_t rem_x = sx ? rem_xs[1] : rem_xs[0], rem_y = sy ? rem_ys[1] : rem_ys[0];
+        const uint32_t tx2 = tile_x >> 2, ty2 = tile_y >> 2, rx2 = ((tile_x & 3u) * c + rem_x) >> 2, ry2 = ((tile_y & 3u) * c + rem_y) >> 2;
+        const uint32_t self = grid_lookup(A, side, A.lod - 2, int(tx2), int(ty2));
+        if (self == kInvalid) continue;
+        const uint32_t v = sel4(sb, p2[0][0], p2[0][1], p2[1][0], p2[1][1]);
+        A.atlas[uint64_t(self) * tile_texels + (b + ry2) * T + b + rx2] = uint16_t(v);
+        if (rx2 < b || rx2 >= c - b || ry2 < b || ry2 >= c - b) push_pixel<false, uint16_t>(A, side, A.lod - 2, tx2, ty2, self, rx2, ry2, uint16_t(v));
+    }
     if (A.levels < 3) return;
 
-    // ---- lod-3: one pixel (levels == 3 implies lod >= 3: the mosaic is a multiple of 8 wide, the 8 x 8 block is whole)
+    // ---- lod-3: one pixel (levels == 3 implies lod >= 3: the mosaic is a multiple of 8 wide, the 8 x 8 block is whole and — 8 | 8c — in one lod-3 tile's share)
     if (!live[0][0]) return;
-    const uint32_t v3 = downsample4(p2[0][0], p2[1][0], p2[0][1], p2[1][1]);
+    uint32_t v3, unused;
+    down_pair4(p2[0][0], p2[1][0], p2[0][1], p2[1][1], p2[0][0], p2[1][0], p2[0][1], p2[1][1], v3, unused);
     {
-        const uint32_t X = gx >> 3, Y = gy >> 3;
-        const uint32_t tx3 = X / c, ty3 = Y / c;
+        const uint32_t tx3 = tile_x0 >> 3, ty3 = tile_y0 >> 3;
+        const uint32_t rx3 = ((tile_x0 & 7u) * c + rem_x0) >> 3, ry3 = ((tile_y0 & 7u) * c + rem_y0) >> 3;
         const uint32_t self = grid_lookup(A, side, A.lod - 3, int(tx3), int(ty3));
-        if (self != kInvalid) push_pixel<true, uint16_t>(A, side, A.lod - 3, tx3, ty3, self, X - tx3 * c, Y - ty3 * c, uint16_t(v3));
+        if (self != kInvalid) {
+            A.atlas[uint64_t(self) * tile_texels + (b + ry3) * T + b + rx3] = uint16_t(v3);
+            if (rx3 < b || rx3 >= c - b || ry3 < b || ry3 >= c - b) push_pixel<false, uint16_t>(A, side, A.lod - 3, tx3, ty3, self, rx3, ry3, uint16_t(v3));
+        }
     }
 }
-
 
 // ---- fused_direct (Rgba8): split + the two parent LODs WITHOUT LDS staging ------------------------------------------
 // Workgroup = several 4-row blocks of one finest tile (c = 508 = 127 x 4: no partial block), thread = one centre column (two

@@ -4,6 +4,7 @@
 // the arithmetic on texels lives in bt_kernels.hip and bt_fused.hip.
 #include <dirent.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -156,6 +157,45 @@ static bt_status make_dirs(const std::string& dir) {
     return BT_OK;
 }
 
+// CPUs this process may use: the scheduler's affinity mask, capped by the cgroup's CPU quota (cgroup v2 cpu.max, v1 cfs quota) — a
+// container on a 256-thread host may own 16 of them, and std::thread::hardware_concurrency() reports the host's
+uint32_t usable_cpus() {
+    uint32_t n = 0;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = uint32_t(CPU_COUNT(&set));
+    if (n == 0) n = std::max(1u, std::thread::hardware_concurrency());
+    auto quota_from = [](const char* path, const char* period_path) -> double {
+        FILE* f = fopen(path, "r");
+        if (!f) return 0.0;
+        char a[64] = "", b2[64] = "";
+        const int got = fscanf(f, "%63s %63s", a, b2);
+        fclose(f);
+        if (got < 1 || !strcmp(a, "max")) return 0.0;
+        double quota = atof(a), period = got >= 2 ? atof(b2) : 0.0;
+        if (period_path) {
+            FILE* g = fopen(period_path, "r");
+            if (g) {
+                if (fscanf(g, "%63s", b2) == 1) period = atof(b2);
+                fclose(g);
+            }
+        }
+        return quota > 0.0 && period > 0.0 ? quota / period : 0.0;
+    };
+    double q = quota_from("/sys/fs/cgroup/cpu.max", nullptr);
+    if (q <= 0.0) q = quota_from("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+    if (q > 0.0) n = std::min(n, std::max(1u, uint32_t(q + 0.999)));
+    return n;
+}
+
+// Writer / reader threads of the save and load paths.  Automatic: min(16, usable CPUs) — on tmpfs and the overlay disk 6 / 8 / 12 / 16 /
+// 24 / 32 / 64 threads write at 29 / 34 / 42 / 46-49 / 46 / 35 / 4 GB/s on a 16-CPU quota (beyond ~24 the page-cache allocation lock
+// dominates): the threads mostly sleep in the kernel's copy, so the quota itself, not quota - 2, is the optimum there.
+uint32_t ctx_io_threads(const bt_ctx* ctx) {
+    if (ctx->io_threads) return ctx->io_threads;
+    return std::max(1u, std::min(16u, usable_cpus()));
+}
+
 bt_status ctx_staging(bt_ctx* ctx, size_t bytes) {
     if (ctx->staging_bytes >= bytes && ctx->staging[0]) return BT_OK;
     for (void*& p : ctx->staging) {
@@ -261,6 +301,14 @@ bt_status bt_ctx_trim(bt_ctx* ctx, uint64_t* freed_bytes) {
     if (freed_bytes) *freed_bytes = freed;
     return BT_OK;
 }
+
+bt_status bt_ctx_set_io_threads(bt_ctx* ctx, uint32_t threads) {
+    if (!ctx || threads > 256u) return BT_ERR_INVALID_ARGUMENT;
+    ctx->io_threads = threads;
+    return BT_OK;
+}
+
+uint32_t bt_ctx_io_threads(const bt_ctx* ctx) { return ctx ? bt::ctx_io_threads(ctx) : 0u; }
 
 bt_status bt_ctx_timer_begin(bt_ctx* ctx) {
     if (!ctx) return BT_ERR_INVALID_ARGUMENT;
@@ -662,7 +710,8 @@ class TileSaver {
         }
         // 16 writers: measured on tmpfs and the overlay disk, 6 / 8 / 12 / 16 / 24 / 32 / 64 / 128 threads write at 29 / 34 / 42 /
         // 46-49 / 46 / 35 / 4 / 5 GB/s — beyond ~24 the page-cache allocation lock dominates
-        uint32_t threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        // (the count follows the CPUs the process may use, not the machine's hardware threads: bt_ctx_set_io_threads)
+        uint32_t threads = ctx_io_threads(a_->ctx);
 #ifdef BT_DEBUG_HOOKS
         if (const char* e = getenv("BT_SAVE_THREADS")) threads = std::max(1, atoi(e));  // tools build only: writer-count experiments
 #endif
@@ -926,7 +975,7 @@ bt_status bt_atlas_load_tiles(bt_atlas* a, uint32_t ai, const char* directory, c
         if (e != hipSuccess) rc = hip_fail(e, "load events");
     }
     if (rc == BT_OK) {
-        FileWriters readers(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), kBuffers);
+        FileWriters readers(ctx_io_threads(a->ctx), kBuffers);
         const uint32_t chunks = (count + chunk - 1) / chunk;
         std::vector<std::vector<uint32_t>> index(kBuffers);
         auto upload = [&](uint32_t c) -> bt_status {  // chunk c has been queued for reading: wait for its files, enqueue its copies

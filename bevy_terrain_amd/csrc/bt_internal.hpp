@@ -144,10 +144,13 @@ struct bt_ctx {
     // end-to-end span; a host that preprocesses dataset after dataset pays them once)
     void* spare_raster = nullptr;
     uint64_t spare_raster_bytes = 0;
+    uint32_t io_threads = 0;  // writer / reader threads of the save and load paths; 0 = automatic (bt_ctx_set_io_threads)
 };
 
 namespace bt {
 bt_status ctx_staging(bt_ctx* ctx, size_t bytes_per_buffer);  // ensures ctx->staging[*] hold at least that much
+uint32_t usable_cpus();                  // CPUs this process may use: affinity mask capped by the cgroup CPU quota
+uint32_t ctx_io_threads(const bt_ctx* ctx);  // the resolved thread count of the save / load paths
 }
 
 struct bt_atlas {

@@ -38,6 +38,15 @@ class Device:
     def synchronize(self):
         _ffi.check(_ffi.lib().bt_ctx_synchronize(self._h))
 
+    def set_io_threads(self, threads: int = 0) -> int:
+        """bt_ctx_set_io_threads: writer / reader threads of this context's save and load paths (0 = automatic: min(16, CPUs the
+        process may use)); returns the count the next save / load uses"""
+        _ffi.check(_ffi.lib().bt_ctx_set_io_threads(self._h, threads))
+        return int(_ffi.lib().bt_ctx_io_threads(self._h))
+
+    def io_threads(self) -> int:
+        return int(_ffi.lib().bt_ctx_io_threads(self._h))
+
     def trim(self) -> int:
         """bt_ctx_trim: give back the raster buffer kept for the next queue and the pinned staging buffers; bytes released"""
         freed = C.c_uint64()

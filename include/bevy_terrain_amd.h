@@ -29,12 +29,14 @@
 extern "C" {
 #endif
 
-/* 4 (round 4): + bt_frame_update / bt_frame_info, BT_RUN_SHARD_OVERLAP + bt_preprocessor_finish_sharded, bt_preprocessor_source_window, BT_RUN_REFERENCE_DISPATCH, bt_ctx_trim; the fused plan no longer has a fused_todo launch (kind 6 of bt_launch_profile
+/* 5 (round 5): + bt_ctx_set_io_threads / bt_ctx_io_threads (writer / reader threads of the save and load paths follow the CPUs the
+ * process may use), bt_comm_preflight (tile-sized health check of the communicator before the first sharded step) — additions only.
+ * 4 (round 4): + bt_frame_update / bt_frame_info, BT_RUN_SHARD_OVERLAP + bt_preprocessor_finish_sharded, bt_preprocessor_source_window, BT_RUN_REFERENCE_DISPATCH, bt_ctx_trim; the fused plan no longer has a fused_todo launch (kind 6 of bt_launch_profile
  * does not occur any more) — additions only.
  * 3 (round 3): + bt_preprocessor_run_streamed, BT_RASTER_HOST_DEFERRED, BT_RUN_SHARD_EXCHANGE, bt_tiling_prepass_run_plain /
  * _run_unordered / _set_window, launch kind 6 (fused todo) in bt_launch_profile — additions only, every version-2 call keeps its
  * meaning. */
-#define BT_ABI_VERSION 4u
+#define BT_ABI_VERSION 5u
 
 typedef int32_t bt_status;
 enum {
@@ -157,6 +159,12 @@ bt_status bt_ctx_synchronize(bt_ctx* ctx);
  * source need not be allocated again: 0.5 GB for a 16k R16 raster) and the pinned staging buffers of the save / load paths.
  * Synchronises the context's stream first.  `freed_bytes` (may be NULL): device + pinned bytes released. */
 bt_status bt_ctx_trim(bt_ctx* ctx, uint64_t* freed_bytes);
+/* Host threads that write (bt_preprocessor_save / _run_streamed) and read (bt_atlas_load_tiles) tile files for this context.
+ * 0 = automatic: min(16, CPUs this process may use) — the affinity mask capped by the cgroup's CPU quota, not the machine's
+ * hardware threads (the reference spawns one AsyncComputeTaskPool task per tile, tile_atlas.rs:77-116).  bt_ctx_io_threads returns
+ * the number the next save / load will use. */
+bt_status bt_ctx_set_io_threads(bt_ctx* ctx, uint32_t threads);
+uint32_t bt_ctx_io_threads(const bt_ctx* ctx);
 /* hipEvent pair on the context's stream: begin .. end -> elapsed milliseconds (end synchronises) */
 bt_status bt_ctx_timer_begin(bt_ctx* ctx);
 bt_status bt_ctx_timer_end(bt_ctx* ctx, float* elapsed_ms);
@@ -366,6 +374,11 @@ bt_status bt_comm_adopt(bt_ctx* ctx, void* nccl_comm, uint32_t world, uint32_t r
 void bt_comm_destroy(bt_comm* comm);
 /* health check: a small grouped in-place all-gather + broadcast through the communicator, verified on the host */
 bt_status bt_comm_check(bt_comm* comm);
+/* The same with slots of `slot_bytes` each (one atlas tile, say): ONE grouped collective — an in-place all-gather of one slot per rank
+ * and an in-place broadcast from the last rank — on the context's stream, every byte verified on the host.  Meant to run once before the
+ * first sharded step: a communicator that cannot move a tile fails HERE with RCCL's error string (or, if the collective hangs, under
+ * the caller's watchdog) instead of inside a timed step.  `elapsed_ms` (may be NULL): device time of the collective. */
+bt_status bt_comm_preflight(bt_comm* comm, uint64_t slot_bytes, float* elapsed_ms);
 /* One step of a sharded job, entirely on the context's stream and without host synchronisation: this rank's strip
  * (BT_RUN_SHARD_LOCAL), ONE grouped collective (in-place ncclAllGather per LOD for the regular planar layout, in-place
  * ncclBroadcast per piece otherwise, between ncclGroupStart and ncclGroupEnd), the finishing kernels
