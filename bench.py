@@ -281,6 +281,7 @@ def main():
                     help="N = 1: independent jobs in flight in the HEADLINE pass — P contexts (HIP streams) with an atlas each over "
                          "the same resident source, steps issued round-robin (default 1: one job on one stream, the definition "
                          "that also holds at N > 1, which always uses 1)")
+    ap.add_argument("--preflight-timeout", type=int, default=120, help="N > 1: seconds the one-tile-per-rank collective before the timed steps may take")
     ap.add_argument("--extras-timeout", type=int, default=180, help="N > 1: seconds the extra passes may take before the line is printed without them")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra passes (N = 1: two jobs in flight; N > 1: kernels only, collective only, the other result mode)")
@@ -361,14 +362,33 @@ def main():
     if world > 1:
         from bevy_terrain_amd.shard import ShardedPreprocess
 
+        # PREFLIGHT, before anything is timed: one grouped in-place all-gather (+ broadcast) of ONE TILE PER RANK through the communicator the
+        # steps will use, every byte checked on the host.  A communicator that cannot move a tile fails here, loudly, with RCCL's error
+        # string — and a collective that hangs is ended by this watchdog, not by the driver's timeout around the whole run.
+        import ctypes
+        import threading
+
+        tile_bytes = TEXTURE_SIZE * TEXTURE_SIZE * 2
+
+        def preflight_hung():
+            print(f"[rank {rank}] bench.py: the RCCL preflight (one {tile_bytes}-byte tile per rank, {world} ranks) did not complete within "
+                  f"{args.preflight_timeout} s — the communicator hangs; no step was timed", file=sys.stderr, flush=True)
+            os._exit(3)
+
+        preflight_watchdog = threading.Timer(args.preflight_timeout, preflight_hung)
+        preflight_watchdog.daemon = True
+        preflight_watchdog.start()
         if collective == "library":
             # every rank must end up on the same path: agree on whether the library's communicator came up everywhere
             ok = 1
             try:
                 job = ShardedPreprocess(pre, atlas, server, paths, range(0, lod_count), rank, world, generic=args.generic, collective="library", result=result)
-                bt._ffi.check(bt._ffi.lib().bt_comm_check(job._comm))
+                ms_pre = ctypes.c_float()
+                bt._ffi.check(bt._ffi.lib().bt_comm_preflight(job._comm, tile_bytes, ctypes.byref(ms_pre)))
+                preflight = {"through": "the library's RCCL communicator (bt_comm_preflight)", "slot_bytes": tile_bytes, "ranks": world,
+                             "collective_ms_rank0": ms_pre.value, "verified": "every byte of every rank's slot, on the host"}
             except Exception as e:
-                print(f"[rank {rank}] library-issued collective unavailable ({e!r}); falling back to torch.distributed", file=sys.stderr)
+                print(f"[rank {rank}] library-issued collective unavailable or failed its preflight ({e!r}); falling back to torch.distributed", file=sys.stderr, flush=True)
                 ok = 0
             flag = torch.tensor([ok], device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -377,6 +397,19 @@ def main():
                 pre = bt.Preprocessor.new().clear_attachment(0, atlas)
         if collective == "torch":
             job = ShardedPreprocess(pre, atlas, server, paths, range(0, lod_count), rank, world, generic=args.generic, collective="torch", result=result)
+            # the same preflight through torch.distributed (backend nccl = RCCL, or gloo in the tests): an exception here ends the run
+            slots = torch.zeros(world * tile_bytes, dtype=torch.uint8, device="cuda")
+            slots[rank * tile_bytes:(rank + 1) * tile_bytes] = 0x40 + rank
+            t_pre = time.perf_counter()
+            dist.all_gather_into_tensor(slots, slots[rank * tile_bytes:(rank + 1) * tile_bytes].clone())
+            torch.cuda.synchronize()
+            got = slots.view(world, tile_bytes).cpu()
+            for r in range(world):
+                assert bool((got[r] == 0x40 + r).all()), f"[rank {rank}] preflight: slot {r} of the all-gather does not hold rank {r}'s tile"
+            preflight = {"through": f"torch.distributed ({backend})", "slot_bytes": tile_bytes, "ranks": world,
+                         "collective_ms_rank0": (time.perf_counter() - t_pre) * 1e3, "verified": "every byte of every rank's slot, on the host"}
+            del slots
+        preflight_watchdog.cancel()
     else:
         if cube:
             pre.preprocess_spherical(bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lod_count)), server, atlas)
@@ -462,6 +495,36 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = float(t.item())
     ms_per_step = ms / args.steps
+
+    # N > 1: the N = 1 step of the SAME invocation — rank 0 runs the whole, unsharded job once more on its GPU (its own context, atlas and a
+    # complete source) while the other ranks wait at a barrier, so that a SCALE record carries its own baseline: same box, same clocks, same build
+    n1_reference = None
+    if world > 1 and not cube and not args.no_extras:
+        if rank == 0:
+            try:
+                d1 = bt.Device(local_rank)
+                full = d1.synth_fbm_r16(SIZE, SIZE, SEED)
+                a1 = bt.TileAtlas.new(cfg, d1)
+                q1 = bt.Preprocessor.new().clear_attachment(0, a1).preprocess_tile(
+                    bt.PreprocessDataset(attachment_index=0, path="n1", lod_range=range(0, lod_count)), bt.AssetServer().insert("n1", (full, SIZE, SIZE)), a1)
+                for _ in range(max(10, args.warmup)):
+                    q1.run(a1, generic=args.generic, keep_queue=True, sync=False)
+                d1.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(d1.torch_stream)
+                for _ in range(args.steps):
+                    q1.run(a1, generic=args.generic, keep_queue=True, sync=False)
+                e1.record(d1.torch_stream)
+                d1.synchronize()
+                t1 = e0.elapsed_time(e1) / args.steps
+                n1_reference = {"ms_per_step": t1, "tiles_per_s": q1.stats()["tiles"] / (t1 / 1e3),
+                                "note": "the unsharded job on rank 0's GPU, one stream, K steps between HIP events, measured in this invocation while the other ranks wait"}
+                q1.close()
+                d1.free(full)
+                del a1
+            except Exception as e:  # never lose the headline over the reference
+                n1_reference = {"error": repr(e)}
+        fence()
 
     def timed_pass(fn, on_stream=None):
         """K calls of fn between two events on `on_stream`, fenced on both sides, max over ranks; ms per call"""
@@ -552,6 +615,8 @@ def main():
                    "collective_only_ms_per_step": exchange_only_ms,  # N > 1: the grouped collective alone
                    "other_result_mode": other_result,  # N > 1: the same job with the other --result, timed in the same run
                    "all_gather_bytes_per_rank": (job.gather_bytes if job is not None else 0),
+                   "rccl_preflight": preflight if world > 1 else None,  # N > 1: the one-tile-per-rank collective that ran before anything was timed
+                   "n1_same_invocation": n1_reference,  # N > 1: the unsharded step on rank 0's GPU, this invocation
                    "source_window_rank0": source_window,  # N > 1: the part of the source rank 0 generated (its strips + halo); the rest stays zero
                    "result": (None if job is None else
                               "replicated: every rank ends with the full atlas" if job.held is None else
@@ -636,6 +701,20 @@ def main():
         line["config"]["collective_only_ms_per_step"] = exchange_only_ms
         line["config"]["other_result_mode"] = other_result
         line["config"][f"{result}_overlapped"] = overlapped
+    if n1_reference and "ms_per_step" in n1_reference:
+        # strong scaling against the N = 1 step of this invocation: speedup = t1 / tN, efficiency = speedup / N (informational: the driver
+        # computes its own from the per-N lines)
+        def ratio(t):
+            return {"speedup": n1_reference["ms_per_step"] / t, "efficiency": n1_reference["ms_per_step"] / t / world} if t else None
+
+        sc = {"headline": ratio(ms_per_step)}
+        if overlapped:
+            sc[f"{result}_overlapped"] = ratio(overlapped["ms_per_step"])
+        if other_result:
+            sc[other_result["result"]] = ratio(other_result["ms_per_step"])
+        if compute_only_ms:
+            sc["kernels_only"] = ratio(compute_only_ms)
+        line["config"]["scaling_vs_n1_same_invocation"] = sc
     if dominant:
         achieved = dominant["algorithmic_bytes"] / (dominant["avg_ms"] / 1e3) / 1e9
         # HBM bytes per launch from the PMC passes of the same command (rocprofv3 cannot run inside this

@@ -1484,14 +1484,18 @@ __device__ __forceinline__ void tail2_apron_rows(const FusedArgs& A, uint32_t si
     }
 }
 
-template <bool kRegular>
+// kBlocks: 8 x 8 blocks per thread, 128 rows apart (workgroup = 128 x 128 kBlocks input pixels).  With two, both blocks' loads are issued
+// up front and the second block's texels are made to arrive BEFORE the first block's stores are issued (one in-order memory counter: a
+// wait for loads issued behind stores waits for the stores' acknowledges too), so the first block's stores travel while the second
+// block is computed.
+template <bool kRegular, uint32_t kBlocks>
 __global__ __launch_bounds__(256) void fused_tail2_kernel(FusedArgs A_in) {
     FusedArgs A = A_in;
     A.regular = kRegular ? 1u : 0u;  // (a compile-time fact: the table lookups and their registers fall away)
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
     const uint32_t size = (1u << A.lod) * c;  // mosaic extent of the input LOD (a multiple of 4)
     {
-        const uint32_t ny = (size + 127u) / 128u;
+        const uint32_t ny = (size + 128u * kBlocks - 1u) / (128u * kBlocks);
         if (blockIdx.y >= ny) {  // workgroups past the mosaic: the apron rows
             if (BT_ABLATE(A, 268435456u)) return;  // (268435456: no apron workgroups — timing experiment)
             tail2_apron_rows(A, blockIdx.z, (blockIdx.y - ny) * gridDim.x + blockIdx.x);
@@ -1499,35 +1503,61 @@ __global__ __launch_bounds__(256) void fused_tail2_kernel(FusedArgs A_in) {
         }
     }
     const uint32_t tile_texels = T * T, side = blockIdx.z;
-    const uint32_t gx = blockIdx.x * 128u + 8u * (threadIdx.x & 15u), gy = blockIdx.y * 128u + 8u * (threadIdx.x >> 4);
+    const uint32_t gx = blockIdx.x * 128u + 8u * (threadIdx.x & 15u), gy_first = blockIdx.y * (128u * kBlocks) + 8u * (threadIdx.x >> 4);
+#ifdef BT_DEBUG_HOOKS
+    // (134217728: real-time (100 MHz) stamps per workgroup — entry, lod-1 computed (its loads have landed), lod-1 stored, lod-2 stored, end —
+    // into the atlas's last layer behind fused_main's; tools/tail_probe.py)
+    auto stamp = [&](uint32_t slot) {
+        if (BT_ABLATE(A, 134217728u) && threadIdx.x == 0)
+            reinterpret_cast<unsigned long long*>(A.atlas + uint64_t(A.m.atlas_size - 1u) * T * T)[32768u + (blockIdx.y * gridDim.x + blockIdx.x) * 8u + slot] = __builtin_amdgcn_s_memrealtime();
+    };
+#else
+    auto stamp = [&](uint32_t) {};
+#endif
+    stamp(0);
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 
-    // ---- the 16 loads: sub-block (sx, sy) = pixels [gx + 4 sx, +4) x [gy + 4 sy, +4), rows as two aligned dwords (b even).
+    // ---- the 16 loads of a block: sub-block (sx, sy) = pixels [gx + 4 sx, +4) x [gy + 4 sy, +4), rows as two aligned dwords (b even).
     // ONE division per axis: the second sub-block is the next tile's first one or 4 pixels on; the tile / in-tile coordinates of a
     // pixel k LODs down follow by shifts: floor(floor(x / 2^k) / c) = floor(x / c) >> k (as in the kernel above)
-    const uint32_t tile_x0 = gx / c, rem_x0 = gx - tile_x0 * c, tile_y0 = gy / c, rem_y0 = gy - tile_y0 * c;
-    const bool wrap_x = rem_x0 + 4u >= c, wrap_y = rem_y0 + 4u >= c;
-    const uint32_t tile_xs[2] = {tile_x0, wrap_x ? tile_x0 + 1u : tile_x0}, rem_xs[2] = {rem_x0, wrap_x ? rem_x0 + 4u - c : rem_x0 + 4u};
-    const uint32_t tile_ys[2] = {tile_y0, wrap_y ? tile_y0 + 1u : tile_y0}, rem_ys[2] = {rem_y0, wrap_y ? rem_y0 + 4u - c : rem_y0 + 4u};
-    uint32_t t[8][4];  // [row][dword]: dword d of row r holds pixels 2d, 2d + 1 of the thread's 8
-    bool live[2][2];
+    struct Block {
+        uint32_t tile_xs[2], rem_xs[2], tile_ys[2], rem_ys[2];
+        uint32_t live_mask, have_mask;  // bit sy * 2 + sx: the sub-block lies inside the mosaic / its input tile exists
+    };
+    const uint32_t tile_x0 = gx / c, rem_x0 = gx - tile_x0 * c;
+    const bool wrap_x = rem_x0 + 4u >= c;
+    auto locate_and_load = [&](uint32_t gy, Block& B, uint32_t (&t)[8][4]) {
+        const uint32_t tile_y0 = gy / c, rem_y0 = gy - tile_y0 * c;
+        const bool wrap_y = rem_y0 + 4u >= c;
+        B.tile_xs[0] = tile_x0;
+        B.tile_xs[1] = wrap_x ? tile_x0 + 1u : tile_x0;
+        B.rem_xs[0] = rem_x0;
+        B.rem_xs[1] = wrap_x ? rem_x0 + 4u - c : rem_x0 + 4u;
+        B.tile_ys[0] = tile_y0;
+        B.tile_ys[1] = wrap_y ? tile_y0 + 1u : tile_y0;
+        B.rem_ys[0] = rem_y0;
+        B.rem_ys[1] = wrap_y ? rem_y0 + 4u - c : rem_y0 + 4u;
+        B.live_mask = B.have_mask = 0;
 #pragma unroll
-    for (uint32_t sy = 0; sy < 2; sy++)
+        for (uint32_t sy = 0; sy < 2; sy++)
 #pragma unroll
-        for (uint32_t sx = 0; sx < 2; sx++) {
-            live[sy][sx] = gx + 4u * sx < size && gy + 4u * sy < size;
-            const uint32_t idx = live[sy][sx] ? grid_lookup(A, side, A.lod, int(tile_xs[sx]), int(tile_ys[sy])) : kInvalid;
-            const bool have = idx != kInvalid && !BT_ABLATE(A, 33554432u);  // an absent tile reads as no data  (33554432: no texel loads — timing experiment)
-            const uint16_t* p = A.atlas + uint64_t(have ? idx : 0u) * tile_texels + (b + rem_ys[sy]) * T + b + rem_xs[sx];
+            for (uint32_t sx = 0; sx < 2; sx++) {
+                const bool live = gx + 4u * sx < size && gy + 4u * sy < size;
+                const uint32_t idx = live ? grid_lookup(A, side, A.lod, int(B.tile_xs[sx]), int(B.tile_ys[sy])) : kInvalid;
+                const bool have = idx != kInvalid && !BT_ABLATE(A, 33554432u);  // an absent tile reads as no data  (33554432: no texel loads — timing experiment)
+                B.live_mask |= live ? 1u << (2u * sy + sx) : 0u;
+                B.have_mask |= have ? 1u << (2u * sy + sx) : 0u;
+                const uint16_t* p = A.atlas + uint64_t(have ? idx : 0u) * tile_texels + (b + B.rem_ys[sy]) * T + b + B.rem_xs[sx];
 #pragma unroll
-            for (uint32_t r = 0; r < 4; r++) {
-                // unconditional (an absent tile reads layer 0 and is zeroed afterwards): sixteen loads back to back, no branch around any
-                const uint2 w = *reinterpret_cast<const uint2 __attribute__((aligned(4)))*>(p + r * T);
-                t[4 * sy + r][2 * sx] = have ? w.x : 0u;
-                t[4 * sy + r][2 * sx + 1] = have ? w.y : 0u;
+                for (uint32_t r = 0; r < 4; r++) {
+                    // unconditional (an absent tile reads layer 0 and is zeroed when the texels are used): sixteen loads back to back
+                    const uint2 w = *reinterpret_cast<const uint2 __attribute__((aligned(4)))*>(p + r * T);
+                    t[4 * sy + r][2 * sx] = w.x;
+                    t[4 * sy + r][2 * sx + 1] = w.y;
+                }
             }
-        }
+    };
 
     // downsample.wgsl:25-39 in the 2^16-scaled domain of fused_main's fast loop, two pixels per packed operation.  F(t) = fma(x, r, x) =
     // 65536 * RN(t / 65535) and F(0) = 0: a no-data texel adds an exact 0 to the running sum, so ((F00 + F01) + F10) + F11 IS the sum over
@@ -1542,7 +1572,7 @@ __global__ __launch_bounds__(256) void fused_tail2_kernel(FusedArgs A_in) {
     };
     auto finish = [&](f2 sum, bool all_valid, uint32_t cnt_a, uint32_t cnt_b, uint32_t& qa, uint32_t& qb) {
         f2 w = khalf + knq * sum;
-        if (!all_valid) {  // (rare) some texel has no data: the valid-average
+        if (__builtin_expect(!all_valid, 0)) {  // (rare) some texel has no data: the valid-average
             const f2 d = {sum.x / float(max(cnt_a, 1u)), sum.y / float(max(cnt_b, 1u))};
             w = khalf + kn * d;
         }
@@ -1558,7 +1588,7 @@ __global__ __launch_bounds__(256) void fused_tail2_kernel(FusedArgs A_in) {
         const f2 sum = ((conv2(a_top & 0xFFFFu, b_top & 0xFFFFu) + conv2(a_bot & 0xFFFFu, b_bot & 0xFFFFu)) + conv2(a_top >> 16, b_top >> 16)) + conv2(a_bot >> 16, b_bot >> 16);
         const bool all_valid = m.x != 0 && m.y != 0;
         uint32_t cnt_a = 4, cnt_b = 4;
-        if (!all_valid) {
+        if (__builtin_expect(!all_valid, 0)) {
             const u16x2 ca = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a_top), one) + __builtin_elementwise_min(__builtin_bit_cast(u16x2, a_bot), one);
             const u16x2 cb = __builtin_elementwise_min(__builtin_bit_cast(u16x2, b_top), one) + __builtin_elementwise_min(__builtin_bit_cast(u16x2, b_bot), one);
             cnt_a = uint32_t(ca.x) + uint32_t(ca.y);
@@ -1571,87 +1601,112 @@ __global__ __launch_bounds__(256) void fused_tail2_kernel(FusedArgs A_in) {
         const bool all_valid = min(min(min(a00, a01), min(a10, a11)), min(min(b00, b01), min(b10, b11))) != 0;
         const f2 sum = ((conv2(a00, b00) + conv2(a01, b01)) + conv2(a10, b10)) + conv2(a11, b11);
         uint32_t cnt_a = 4, cnt_b = 4;
-        if (!all_valid) {
+        if (__builtin_expect(!all_valid, 0)) {
             cnt_a = min(a00, 1u) + min(a01, 1u) + min(a10, 1u) + min(a11, 1u);
             cnt_b = min(b00, 1u) + min(b01, 1u) + min(b10, 1u) + min(b11, 1u);
         }
         finish(sum, all_valid, cnt_a, cnt_b, qa, qb);
     };
 
-    // ---- lod-1: 4 x 4 pixels, q[row][col]; pixel (i, j) from rows 2i, 2i + 1 of dword j
-    uint32_t q[4][4];
-#pragma unroll
-    for (uint32_t i = 0; i < 4; i++)
-#pragma unroll
-        for (uint32_t j = 0; j < 4; j += 2) down_pair(t[2 * i][j], t[2 * i + 1][j], t[2 * i][j + 1], t[2 * i + 1][j + 1], q[i][j], q[i][j + 1]);
-    // The stores of a level go through ONE rolled loop over the four sub-blocks (values picked by selects): unrolled, the apron pushes —
-    // executed by the few threads within b of a tile edge — were 7 of the kernel's 9 thousand instructions.
-    auto sel4 = [](uint32_t i, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) -> uint32_t { return i == 0 ? v0 : (i == 1 ? v1 : (i == 2 ? v2 : v3)); };
-    const uint32_t live_mask = (live[0][0] ? 1u : 0u) | (live[0][1] ? 2u : 0u) | (live[1][0] ? 4u : 0u) | (live[1][1] ? 8u : 0u);
-    if (!BT_ABLATE(A, 1073741824u)) {  // (1073741824: no lod-1 stores — timing experiment)
-        // packed rows of the sub-blocks' 2 x 2 lod-1 pixels: [sub-block][row]
-        const uint32_t r00 = q[0][0] | (q[0][1] << 16), r01 = q[1][0] | (q[1][1] << 16), r10 = q[0][2] | (q[0][3] << 16), r11 = q[1][2] | (q[1][3] << 16);
-        const uint32_t r20 = q[2][0] | (q[2][1] << 16), r21 = q[3][0] | (q[3][1] << 16), r30 = q[2][2] | (q[2][3] << 16), r31 = q[3][2] | (q[3][3] << 16);
-#pragma nounroll
-        for (uint32_t sb = 0; sb < 4; sb++) {
-            if (!((live_mask >> sb) & 1u)) continue;
-            const uint32_t sx = sb & 1u, sy = sb >> 1;
-            const uint32_t tile_x = sx ? tile_xs[1] : tile_xs[0], tile_y = sy ? tile_ys[1] : tile_ys[0];
-            const uint32_t rem_x = sx ? rem_xs[1] : rem_xs[0], rem_y = sy ? rem_ys[1] : rem_ys[0];
-            // the sub-block's 2 x 2 lod-1 pixels lie in one lod-1 tile (4 x 4 block inside one input tile)
-            const uint32_t tx1 = tile_x >> 1, ty1 = tile_y >> 1, rx1 = ((tile_x & 1u) * c + rem_x) >> 1, ry1 = ((tile_y & 1u) * c + rem_y) >> 1;
-            const uint32_t self = grid_lookup(A, side, A.lod - 1, int(tx1), int(ty1));
-            if (self == kInvalid) continue;
-            const uint32_t row0 = sel4(sb, r00, r10, r20, r30), row1 = sel4(sb, r01, r11, r21, r31);
-            uint16_t* centre = A.atlas + uint64_t(self) * tile_texels + (b + ry1) * T + b + rx1;
-            *reinterpret_cast<uint32_t*>(centre) = row0;
-            *reinterpret_cast<uint32_t*>(centre + T) = row1;
-            // aprons: only a block within b of its tile's edge pushes (b even: the 2 x 2 block with even coordinates shares its targets)
-            if ((rx1 < b || rx1 + 2u > c - b || ry1 < b || ry1 + 2u > c - b) && !BT_ABLATE(A, 536870912u)) {  // (536870912: no apron pushes of lod-1)
-                const PushNb nb1 = push_targets(A, side, A.lod - 1, tx1, ty1, rx1, ry1, true);
-#pragma nounroll
-                for (uint32_t e = 0; e < 4; e++) {
-                    const uint32_t row = (e & 2u) ? row1 : row0;
-                    push_store<uint16_t>(A, nb1, self, rx1 + (e & 1u), ry1 + (e >> 1), uint16_t((e & 1u) ? row >> 16 : row & 0xFFFFu));
+    auto process = [&](const Block& B, uint32_t (&t)[8][4], bool first, auto arrive) {
+        // ---- lod-1: 4 x 4 pixels, q[row][col]; pixel (i, j) from rows 2i, 2i + 1 of dword j
+        uint32_t q[4][4];
+    #pragma unroll
+        for (uint32_t i = 0; i < 4; i++)
+    #pragma unroll
+            for (uint32_t j = 0; j < 4; j += 2) {
+                const bool have = (B.have_mask >> (2u * (i >> 1) + (j >> 1))) & 1u;  // sub-block (sx = j / 2, sy = i / 2)
+                down_pair(have ? t[2 * i][j] : 0u, have ? t[2 * i + 1][j] : 0u, have ? t[2 * i][j + 1] : 0u, have ? t[2 * i + 1][j + 1] : 0u, q[i][j], q[i][j + 1]);
+            }
+        if (first) stamp(1);
+        arrive();  // (two blocks: the other block's texels land before this block's first store is issued)
+        // The stores of a level go through ONE rolled loop over the four sub-blocks (values picked by selects): unrolled, the apron pushes —
+        // executed by the few threads within b of a tile edge — were 7 of the kernel's 9 thousand instructions.
+        auto sel4 = [](uint32_t i, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) -> uint32_t { return i == 0 ? v0 : (i == 1 ? v1 : (i == 2 ? v2 : v3)); };
+        const uint32_t live_mask = B.live_mask;
+        if (!BT_ABLATE(A, 1073741824u)) {  // (1073741824: no lod-1 stores — timing experiment)
+            // packed rows of the sub-blocks' 2 x 2 lod-1 pixels: [sub-block][row]
+            const uint32_t r00 = q[0][0] | (q[0][1] << 16), r01 = q[1][0] | (q[1][1] << 16), r10 = q[0][2] | (q[0][3] << 16), r11 = q[1][2] | (q[1][3] << 16);
+            const uint32_t r20 = q[2][0] | (q[2][1] << 16), r21 = q[3][0] | (q[3][1] << 16), r30 = q[2][2] | (q[2][3] << 16), r31 = q[3][2] | (q[3][3] << 16);
+    #pragma nounroll
+            for (uint32_t sb = 0; sb < 4; sb++) {
+                if (__builtin_expect(!((live_mask >> sb) & 1u), 0)) continue;
+                const uint32_t sx = sb & 1u, sy = sb >> 1;
+                const uint32_t tile_x = sx ? B.tile_xs[1] : B.tile_xs[0], tile_y = sy ? B.tile_ys[1] : B.tile_ys[0];
+                const uint32_t rem_x = sx ? B.rem_xs[1] : B.rem_xs[0], rem_y = sy ? B.rem_ys[1] : B.rem_ys[0];
+                // the sub-block's 2 x 2 lod-1 pixels lie in one lod-1 tile (4 x 4 block inside one input tile)
+                const uint32_t tx1 = tile_x >> 1, ty1 = tile_y >> 1, rx1 = ((tile_x & 1u) * c + rem_x) >> 1, ry1 = ((tile_y & 1u) * c + rem_y) >> 1;
+                const uint32_t self = grid_lookup(A, side, A.lod - 1, int(tx1), int(ty1));
+                if (__builtin_expect(self == kInvalid, 0)) continue;
+                const uint32_t row0 = sel4(sb, r00, r10, r20, r30), row1 = sel4(sb, r01, r11, r21, r31);
+                uint16_t* centre = A.atlas + uint64_t(self) * tile_texels + (b + ry1) * T + b + rx1;
+                *reinterpret_cast<uint32_t*>(centre) = row0;
+                *reinterpret_cast<uint32_t*>(centre + T) = row1;
+                // aprons: only a block within b of its tile's edge pushes (b even: the 2 x 2 block with even coordinates shares its targets)
+                if (__builtin_expect((rx1 < b || rx1 + 2u > c - b || ry1 < b || ry1 + 2u > c - b) && !BT_ABLATE(A, 536870912u), 0)) {  // (536870912: no apron pushes of lod-1)
+                    const PushNb nb1 = push_targets(A, side, A.lod - 1, tx1, ty1, rx1, ry1, true);
+    #pragma nounroll
+                    for (uint32_t e = 0; e < 4; e++) {
+                        const uint32_t row = (e & 2u) ? row1 : row0;
+                        push_store<uint16_t>(A, nb1, self, rx1 + (e & 1u), ry1 + (e >> 1), uint16_t((e & 1u) ? row >> 16 : row & 0xFFFFu));
+                    }
                 }
             }
         }
-    }
-    if (A.levels < 2 || BT_ABLATE(A, 67108864u)) return;  // (67108864: lod-1 only — timing experiment)
+        if (first) stamp(2);
+        if (A.levels < 2 || BT_ABLATE(A, 67108864u)) return;  // (67108864: lod-1 only — timing experiment)
 
-    // ---- lod-2: 2 x 2 pixels, one per sub-block
-    uint32_t p2[2][2];
-#pragma unroll
-    for (uint32_t i = 0; i < 2; i++)
-        down_pair4(q[2 * i][0], q[2 * i + 1][0], q[2 * i][1], q[2 * i + 1][1], q[2 * i][2], q[2 * i + 1][2], q[2 * i][3], q[2 * i + 1][3], p2[i][0], p2[i][1]);
-#pragma nounroll
-    for (uint32_t sb = 0; sb < 4; sb++) {
-        if (!((live_mask >> sb) & 1u)) continue;
-        const uint32_t sx = sb & 1u, sy = sb >> 1;
-        const uint32_t tile_x = sx ? tile_xs[1] : tile_xs[0], tile_y = sy ? tile_ys[1] : tile_ys[0];
-        const uint32_t rem_x = sx ? rem_xs[1] : rem_xs[0], rem_y = sy ? rem_ys[1] : rem_ys[0];
-        const uint32_t tx2 = tile_x >> 2, ty2 = tile_y >> 2, rx2 = ((tile_x & 3u) * c + rem_x) >> 2, ry2 = ((tile_y & 3u) * c + rem_y) >> 2;
-        const uint32_t self = grid_lookup(A, side, A.lod - 2, int(tx2), int(ty2));
-        if (self == kInvalid) continue;
-        const uint32_t v = sel4(sb, p2[0][0], p2[0][1], p2[1][0], p2[1][1]);
-        A.atlas[uint64_t(self) * tile_texels + (b + ry2) * T + b + rx2] = uint16_t(v);
-        if (rx2 < b || rx2 >= c - b || ry2 < b || ry2 >= c - b) push_pixel<false, uint16_t>(A, side, A.lod - 2, tx2, ty2, self, rx2, ry2, uint16_t(v));
-    }
-    if (A.levels < 3) return;
-
-    // ---- lod-3: one pixel (levels == 3 implies lod >= 3: the mosaic is a multiple of 8 wide, the 8 x 8 block is whole and — 8 | 8c — in one lod-3 tile's share)
-    if (!live[0][0]) return;
-    uint32_t v3, unused;
-    down_pair4(p2[0][0], p2[1][0], p2[0][1], p2[1][1], p2[0][0], p2[1][0], p2[0][1], p2[1][1], v3, unused);
-    {
-        const uint32_t tx3 = tile_x0 >> 3, ty3 = tile_y0 >> 3;
-        const uint32_t rx3 = ((tile_x0 & 7u) * c + rem_x0) >> 3, ry3 = ((tile_y0 & 7u) * c + rem_y0) >> 3;
-        const uint32_t self = grid_lookup(A, side, A.lod - 3, int(tx3), int(ty3));
-        if (self != kInvalid) {
-            A.atlas[uint64_t(self) * tile_texels + (b + ry3) * T + b + rx3] = uint16_t(v3);
-            if (rx3 < b || rx3 >= c - b || ry3 < b || ry3 >= c - b) push_pixel<false, uint16_t>(A, side, A.lod - 3, tx3, ty3, self, rx3, ry3, uint16_t(v3));
+        // ---- lod-2: 2 x 2 pixels, one per sub-block
+        uint32_t p2[2][2];
+    #pragma unroll
+        for (uint32_t i = 0; i < 2; i++)
+            down_pair4(q[2 * i][0], q[2 * i + 1][0], q[2 * i][1], q[2 * i + 1][1], q[2 * i][2], q[2 * i + 1][2], q[2 * i][3], q[2 * i + 1][3], p2[i][0], p2[i][1]);
+    #pragma nounroll
+        for (uint32_t sb = 0; sb < 4; sb++) {
+            if (__builtin_expect(!((live_mask >> sb) & 1u), 0)) continue;
+            const uint32_t sx = sb & 1u, sy = sb >> 1;
+            const uint32_t tile_x = sx ? B.tile_xs[1] : B.tile_xs[0], tile_y = sy ? B.tile_ys[1] : B.tile_ys[0];
+            const uint32_t rem_x = sx ? B.rem_xs[1] : B.rem_xs[0], rem_y = sy ? B.rem_ys[1] : B.rem_ys[0];
+            const uint32_t tx2 = tile_x >> 2, ty2 = tile_y >> 2, rx2 = ((tile_x & 3u) * c + rem_x) >> 2, ry2 = ((tile_y & 3u) * c + rem_y) >> 2;
+            const uint32_t self = grid_lookup(A, side, A.lod - 2, int(tx2), int(ty2));
+            if (__builtin_expect(self == kInvalid, 0)) continue;
+            const uint32_t v = sel4(sb, p2[0][0], p2[0][1], p2[1][0], p2[1][1]);
+            A.atlas[uint64_t(self) * tile_texels + (b + ry2) * T + b + rx2] = uint16_t(v);
+            if (__builtin_expect(rx2 < b || rx2 >= c - b || ry2 < b || ry2 >= c - b, 0)) push_pixel<false, uint16_t>(A, side, A.lod - 2, tx2, ty2, self, rx2, ry2, uint16_t(v));
         }
+        if (first) stamp(3);
+        if (A.levels < 3) return;
+
+        // ---- lod-3: one pixel (levels == 3 implies lod >= 3: the mosaic is a multiple of 8 wide, the 8 x 8 block is whole and — 8 | 8c — in one lod-3 tile's share)
+        if (!(B.live_mask & 1u)) return;
+        uint32_t v3, unused;
+        down_pair4(p2[0][0], p2[1][0], p2[0][1], p2[1][1], p2[0][0], p2[1][0], p2[0][1], p2[1][1], v3, unused);
+        {
+            const uint32_t tx3 = B.tile_xs[0] >> 3, ty3 = B.tile_ys[0] >> 3;
+            const uint32_t rx3 = ((B.tile_xs[0] & 7u) * c + B.rem_xs[0]) >> 3, ry3 = ((B.tile_ys[0] & 7u) * c + B.rem_ys[0]) >> 3;
+            const uint32_t self = grid_lookup(A, side, A.lod - 3, int(tx3), int(ty3));
+            if (self != kInvalid) {
+                A.atlas[uint64_t(self) * tile_texels + (b + ry3) * T + b + rx3] = uint16_t(v3);
+                if (__builtin_expect(rx3 < b || rx3 >= c - b || ry3 < b || ry3 >= c - b, 0)) push_pixel<false, uint16_t>(A, side, A.lod - 3, tx3, ty3, self, rx3, ry3, uint16_t(v3));
+            }
+        }
+    };
+    uint32_t ta[8][4];
+    Block ba;
+    locate_and_load(gy_first, ba, ta);
+    if constexpr (kBlocks == 2) {
+        uint32_t tb[8][4];
+        Block bb;
+        locate_and_load(gy_first + 128u, bb, tb);
+        process(ba, ta, true, [&] {
+#pragma unroll
+            for (uint32_t r = 0; r < 8; r++) asm volatile("" : "+v"(tb[r][0]), "+v"(tb[r][1]), "+v"(tb[r][2]), "+v"(tb[r][3]));
+        });
+        process(bb, tb, false, [] {});
+    } else {
+        process(ba, ta, true, [] {});
     }
+    stamp(4);
 }
 
 // ---- fused_direct (Rgba8): split + the two parent LODs WITHOUT LDS staging ------------------------------------------
@@ -2856,13 +2911,32 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
         }
     } else {
         const uint32_t size = (1u << job.args.lod) * job.args.m.center_size;
-        if (job.args.m.format == BT_FORMAT_R16 && (job.args.m.border_size & 1u) == 0) {  // (R16 in a fused plan: always)
-            dim3 grid((size + 127) / 128, (size + 127) / 128, job.args.sides);
+        // R16 (b even in a fused plan), enough input for one 128 x 128 workgroup per CU: the 8 x 8-per-thread kernel; smaller mosaics keep the
+        // kernel below, whose 64 x 64 workgroups spread them over more CUs (config 2's tail, 4 tiles in: 7.6 vs 10.8 us)
+        uint32_t tail2_min = 256;
+#ifdef BT_DEBUG_HOOKS
+        if (const char* e = getenv("BT_FUSED_TAIL2_MIN")) tail2_min = uint32_t(atoi(e));
+#endif
+        if (job.args.m.format == BT_FORMAT_R16 && (job.args.m.border_size & 1u) == 0 && uint64_t((size + 127) / 128) * ((size + 127) / 128) * job.args.sides >= tail2_min) {
+            // two 8 x 8 blocks per thread where that still leaves every CU several workgroups
+            uint32_t blocks = uint64_t((size + 127) / 128) * ((size + 255) / 256) * job.args.sides >= 512 ? 2u : 1u;
+#ifdef BT_DEBUG_HOOKS
+            if (const char* e = getenv("BT_FUSED_TAIL_BLOCKS")) blocks = atoi(e) == 2 ? 2u : 1u;
+#endif
+            dim3 grid((size + 127) / 128, (size + 128 * blocks - 1) / (128 * blocks), job.args.sides);
             uint64_t extra = 0;  // apron rows of the LODs fused_main produced: one workgroup per tile
             for (uint32_t k = 0; k < job.args.apron_lods; k++) extra += 1ull << (2 * (job.args.lod + k));
             grid.y += uint32_t((extra + grid.x - 1) / grid.x);
-            if (job.args.regular) fused_tail2_kernel<true><<<grid, 256, 0, p->ctx->stream>>>(job.args);
-            else fused_tail2_kernel<false><<<grid, 256, 0, p->ctx->stream>>>(job.args);
+            auto launch = [&] {
+                if (job.args.regular && blocks == 2) fused_tail2_kernel<true, 2><<<grid, 256, 0, p->ctx->stream>>>(job.args);
+                else if (job.args.regular) fused_tail2_kernel<true, 1><<<grid, 256, 0, p->ctx->stream>>>(job.args);
+                else if (blocks == 2) fused_tail2_kernel<false, 2><<<grid, 256, 0, p->ctx->stream>>>(job.args);
+                else fused_tail2_kernel<false, 1><<<grid, 256, 0, p->ctx->stream>>>(job.args);
+            };
+            launch();
+#ifdef BT_DEBUG_HOOKS
+            if (getenv("BT_FUSED_TAIL_TWICE")) launch();  // (timing experiment: what does a second, warm launch of the same kernel cost?)
+#endif
             hipError_t e2 = hipGetLastError();
             if (e2 != hipSuccess) return hip_fail(e2, "fused kernel launch");
             return BT_OK;

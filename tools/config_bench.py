@@ -15,8 +15,18 @@ import torch  # noqa: E402,F401
 import bevy_terrain_amd as bt  # noqa: E402
 
 
+STEPS = None  # --steps N: fewer steps per job (counter passes under rocprofv3)
+ONLY = None   # --only NAME: one workload (config2_height_4k / config2_albedo_4k / config5_cube_height_8k / config3_masked_16k)
+
+
+def launches_of(prof):
+    return [(l["kind"], round(l["avg_ms"] * 1e3, 1), l["algorithmic_bytes"]) for l in prof]
+
+
 def time_job(device, pre, atlas, steps=50):
-    for _ in range(10):
+    if STEPS:
+        steps = STEPS
+    for _ in range(10 if not STEPS else 2):
         pre.run(atlas, keep_queue=True, sync=False)
     device.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -48,13 +58,18 @@ def masked_16k(device):
     server = bt.AssetServer().insert("m", (ptr, size, size))
     pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="m", lod_range=range(0, lods)), server, atlas)
     ms, prof, st = time_job(device, pre, atlas, steps=20)
-    return {"ms": ms, "tiles": st["tiles"], "launches": [(l["kind"], round(l["avg_ms"] * 1e3, 1)) for l in prof]}
+    return {"ms": ms, "tiles": st["tiles"], "launches": launches_of(prof)}
 
 
 def main():
+    global STEPS, ONLY
+    if "--steps" in sys.argv:
+        STEPS = int(sys.argv[sys.argv.index("--steps") + 1])
+    if "--only" in sys.argv:
+        ONLY = sys.argv[sys.argv.index("--only") + 1]
     device = bt.Device(0)
     out = {}
-    if "--masked16k" in sys.argv:
+    if "--masked16k" in sys.argv or ONLY == "config3_masked_16k":
         print(json.dumps({"config3_masked_16k": masked_16k(device)}))
         return
     # config 2
@@ -67,11 +82,13 @@ def main():
     atlas = bt.TileAtlas.new(cfg, device)
     server = bt.AssetServer().insert("h", (h, 4096, 4096)).insert("a", albedo)
     for name, att, path in (("config2_height_4k", 0, "h"), ("config2_albedo_4k", 1, "a")):
+        if ONLY and ONLY != name:
+            continue
         pre = bt.Preprocessor.new().clear_attachment(att, atlas).preprocess_tile(
             bt.PreprocessDataset(attachment_index=att, path=path, lod_range=range(0, 4)), server, atlas)
         ms, prof, st = time_job(device, pre, atlas)
-        out[name] = {"ms": ms, "tiles": st["tiles"], "launches": [(l["kind"], round(l["avg_ms"] * 1e3, 1)) for l in prof]}
-    if "--config2" in sys.argv:
+        out[name] = {"ms": ms, "tiles": st["tiles"], "launches": launches_of(prof)}
+    if "--config2" in sys.argv or (ONLY and ONLY.startswith("config2")):
         print(json.dumps(out))
         return
     if "--cube-albedo" in sys.argv:  # config 5's second attachment: 6 faces of 8192^2 Rgba8 (1.6 GB of source), lod_count 5
@@ -87,7 +104,7 @@ def main():
         pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_spherical(
             bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, 5)), server, atlas)
         ms, prof, st = time_job(device, pre, atlas, steps=20)
-        print(json.dumps({"config5_cube_albedo_8k": {"ms": ms, "tiles": st["tiles"], "launches": [(l["kind"], round(l["avg_ms"] * 1e3, 1)) for l in prof]}}))
+        print(json.dumps({"config5_cube_albedo_8k": {"ms": ms, "tiles": st["tiles"], "launches": launches_of(prof)}}))
         return
     # config 5 (height)
     faces = [(device.synth_fbm_r16(8192, 8192, 7 + s), 8192, 8192) for s in range(6)]
@@ -101,7 +118,7 @@ def main():
     pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_spherical(
         bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, 5)), server, atlas)
     ms, prof, st = time_job(device, pre, atlas)
-    out["config5_cube_height_8k"] = {"ms": ms, "tiles": st["tiles"], "launches": [(l["kind"], round(l["avg_ms"] * 1e3, 1)) for l in prof]}
+    out["config5_cube_height_8k"] = {"ms": ms, "tiles": st["tiles"], "launches": launches_of(prof)}
     print(json.dumps(out))
 
 

@@ -334,6 +334,79 @@ template <int ARITH, uint32_t CH, uint32_t D, uint32_t R> __global__ __launch_bo
     }
 }
 
+// ------------------------------------------------------------------------------------------------ round 5: the DRAM side
+// every variant so far changed the CU side; loads-only + finest-stores-only = both, i.e. reads and writes do not
+// overlap in this access pattern.  V1 (LDS-DMA by all waves, ring two chunks ahead) with
+//   POLICY  the cache policy of the finest / parent stores from inline assembly: 0 plain, 1 sc0, 2 sc1, 3 sc0 sc1 (write-through at every
+//           level), 4 nt, 5 sc0 sc1 nt
+//   half    chip-wide read / write PHASE SEPARATION by the real-time clock (100 MHz ticks; 0 = off): a wave issues its DMA rows only
+//           while (clock / half) is even and its stores only while it is odd — every workgroup of the chip reads in the same window and
+//           writes in the same window, one chunk per period; `anti`: the odd XCDs run half a period late (4 XCDs read while 4 write)
+template <int POLICY> __device__ __forceinline__ void store_policy(uint32_t* p, uint32_t v) {
+    if (POLICY == 0) asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    if (POLICY == 1) asm volatile("global_store_dword %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");
+    if (POLICY == 2) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    if (POLICY == 3) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    if (POLICY == 4) asm volatile("global_store_dword %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    if (POLICY == 5) asm volatile("global_store_dword %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
+template <int ARITH, int POLICY> __global__ __launch_bounds__(256) void vdram(const uint8_t* src, uint8_t* tiles, uint8_t* parents, uint32_t half, uint32_t anti) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kRing * (kRowMain + kRowTail)];
+    uint32_t tx, ty;
+    tile_of(tx, ty);
+    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    const gbytes base = (gbytes)src + uint64_t(ty) * 512 * kPitch + uint64_t(tx) * 1024;
+    const lbytes ring = (lbytes)lds;
+    for (uint32_t y = wave; y < 18; y += 4) dma_row<false>(base, ring, y, lane);
+    if (wave == 0) {
+        dma_tails(base, ring, 0, lane);
+        dma_tails(base, ring, 8, lane);
+        dma_tails(base, ring, 16, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    uint32_t* d5 = reinterpret_cast<uint32_t*>(tiles + uint64_t(tx * 32 + ty) * 524288 + 4) + tid;
+    uint32_t* d4 = reinterpret_cast<uint32_t*>(parents + uint64_t((tx / 2) * 16 + ty / 2) * 524288 + uint64_t(ty & 1u) * 262144 + (tx & 1u) * 512 + 4) + (tid >> 1);
+    const uint32_t c0 = 2 * tid, c1 = 2 * tid + 2;
+    auto col = [&](uint32_t c, uint32_t& off, uint32_t& stride) {
+        if (c < 512) { off = c * 2; stride = kRowMain; } else { off = kTailBase + (c - 512) * 2; stride = kRowTail; }
+    };
+    uint32_t o00, s00, o01, s01, o10, s10, o11, s11;
+    col(c0, o00, s00); col(c0 + 1, o01, s01); col(c1, o10, s10); col(c1 + 1, o11, s11);
+    const uint32_t shift = anti ? (blockIdx.x & 1u) : 0u;  // blockIdx % 8 = the XCD
+    auto wait_phase = [&](uint32_t want) {  // (wave-uniform) spin until the chip-wide window is the wanted one
+        if (half == 0) return;
+        while ((((uint32_t(__builtin_amdgcn_s_memrealtime()) / half) + shift) & 1u) != want) __builtin_amdgcn_s_sleep(2);
+    };
+    for (uint32_t k = 0; k < 64; k++) {
+        wait_phase(0);
+        {
+            const uint32_t y0 = 8 * k + 18 + 2 * wave;
+            dma_row<false>(base, ring, y0, lane);
+            dma_row<false>(base, ring, y0 + 1, lane);
+            if (wave == 0) dma_tails(base, ring, 8 * k + 24, lane);
+        }
+        const uint32_t slot0 = (8 * k) & (kRing - 1);
+        auto tex = [&](uint32_t r, uint32_t off, uint32_t stride) -> uint32_t {
+            return *reinterpret_cast<const uint16_t*>(lds + off + ((slot0 + r) & (kRing - 1)) * stride);
+        };
+        f2 carry = {float(tex(0, o00, s00)), float(tex(0, o10, s10))};
+        uint32_t out[8];
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++) out[r] = shade<ARITH>(tex(r + 1, o00, s00), tex(r + 1, o01, s01), tex(r + 1, o10, s10), tex(r + 1, o11, s11), carry, 0.125f * float(r));
+        wait_phase(1);
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++) store_policy<POLICY>(&d5[(k * 8 + r) * 256], out[r]);
+        if ((tid & 1u) == 0) {
+#pragma unroll
+            for (uint32_t r = 0; r < 4; r++) store_policy<POLICY>(&d4[(k * 4 + r) * 256], out[2 * r] + out[2 * r + 1]);
+        }
+        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 template <typename F> static float timeit(F f) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -356,6 +429,30 @@ int main(int argc, char** argv) {
     hipMemset(src, 3, 16384ull * kPitch + (1 << 20));
     for (int i = 0; i < 200; i++) v0<0><<<1024, 256>>>(src, tiles, parents, 3);
     hipDeviceSynchronize();
+    if (argc > 1 && !strcmp(argv[1], "dram")) {  // round 5: store cache policies x chip-wide read / write phase separation (promotion gate: <= 225 us at arith 24)
+        const char* pol[6] = {"plain", "sc0", "sc1", "sc0 sc1", "nt", "sc0 sc1 nt"};
+        for (int rep = 0; rep < 2; rep++) {
+            printf("reference (compiler-issued stores): V1 arith 24 %6.1f us, arith 0 %6.1f us\n", timeit([&] { v12<24, false><<<1024, 256>>>(src, tiles, parents, 3); }),
+                   timeit([&] { v12<0, false><<<1024, 256>>>(src, tiles, parents, 3); }));
+            auto run = [&](int policy, uint32_t half, uint32_t anti) -> float {
+                switch (policy) {
+                    case 0: return timeit([&] { vdram<24, 0><<<1024, 256>>>(src, tiles, parents, half, anti); });
+                    case 1: return timeit([&] { vdram<24, 1><<<1024, 256>>>(src, tiles, parents, half, anti); });
+                    case 2: return timeit([&] { vdram<24, 2><<<1024, 256>>>(src, tiles, parents, half, anti); });
+                    case 3: return timeit([&] { vdram<24, 3><<<1024, 256>>>(src, tiles, parents, half, anti); });
+                    case 4: return timeit([&] { vdram<24, 4><<<1024, 256>>>(src, tiles, parents, half, anti); });
+                    default: return timeit([&] { vdram<24, 5><<<1024, 256>>>(src, tiles, parents, half, anti); });
+                }
+            };
+            for (int policy = 0; policy < 6; policy++) {
+                printf("arith 24, stores %-10s: no phases %6.1f us |", pol[policy], run(policy, 0, 0));
+                for (uint32_t half : {130u, 150u, 170u, 200u}) printf(" half %3.1f us: in phase %6.1f anti %6.1f |", half / 100.0, run(policy, half, 0), run(policy, half, 1));
+                printf("\n");
+                fflush(stdout);
+            }
+        }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "rows16")) {  // round 4: 16-row chunks against 8-row chunks (V1), same lease, alternating
         for (int rep = 0; rep < 3; rep++) {
             printf("arith  0: 8-row chunks %6.1f   16-row chunks %6.1f us\n", timeit([&] { v12<0, false><<<1024, 256>>>(src, tiles, parents, 3); }), timeit([&] { v16<0><<<1024, 256>>>(src, tiles, parents, 3); }));
