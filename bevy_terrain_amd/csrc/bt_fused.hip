@@ -1309,6 +1309,46 @@ __device__ __forceinline__ void tail_aprons_rgba8(const FusedArgs& A, uint32_t s
 
 // kRegular: the atlas indices follow the closed form (FusedArgs::regular) — as a compile-time fact the table lookups and their
 // registers fall away (64 VGPRs: eight waves per SIMD)
+// downsample.wgsl:25-39 for R16 in the 2^16-scaled domain of fused_main's fast loop (round 5; downsample4 above is the plain form).
+// F(t) = fma(x, r, x) = 65536 * RN(t / 65535) and F(0) = 0: a no-data texel adds an exact 0 to the running sum, so ((F00 + F01) + F10) + F11
+// IS the sum over the valid texels in OFFSETS order, rounding for rounding; what differs is the divisor.  All four valid (the common case):
+// 0.5 + (0.25 * k) * sum with k = 65535 / 65536 (sum * 0.25 is exact).  Otherwise ONE IEEE division by the count — scaling by a power of two
+// commutes with it, and an average of values <= 1 needs no clamp — and count 0 gives 0.5 + k * (0 / 1) -> 0, the defined "no data".
+typedef float tail_f2 __attribute__((ext_vector_type(2)));
+typedef uint16_t tail_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ tail_f2 tail_conv2(uint32_t a, uint32_t bq) {
+    const tail_f2 x = {float(a), float(bq)}, kr = {1.0f / 65535.0f, 1.0f / 65535.0f};
+    return __builtin_elementwise_fma(x, kr, x);
+}
+// two 2 x 2 averages at once: block A = a_top over a_bot, packed texel pairs (low half = x0), block B likewise
+__device__ __forceinline__ void down_pair_r16(uint32_t a_top, uint32_t a_bot, uint32_t b_top, uint32_t b_bot, uint32_t& qa, uint32_t& qb) {
+    const tail_f2 khalf = {0.5f, 0.5f}, kn = {65535.0f / 65536.0f, 65535.0f / 65536.0f}, knq = {0.25f * (65535.0f / 65536.0f), 0.25f * (65535.0f / 65536.0f)};
+    const tail_u16x2 one = {1, 1};
+    const tail_u16x2 at = __builtin_bit_cast(tail_u16x2, a_top), ab = __builtin_bit_cast(tail_u16x2, a_bot), bt2 = __builtin_bit_cast(tail_u16x2, b_top), bb = __builtin_bit_cast(tail_u16x2, b_bot);
+    const tail_u16x2 m = __builtin_elementwise_min(__builtin_elementwise_min(at, ab), __builtin_elementwise_min(bt2, bb));
+    // OFFSETS order (0,0),(0,1),(1,0),(1,1) of (dx, dy): ((x0y0 + x0y1) + x1y0) + x1y1
+    const tail_f2 sum = ((tail_conv2(a_top & 0xFFFFu, b_top & 0xFFFFu) + tail_conv2(a_bot & 0xFFFFu, b_bot & 0xFFFFu)) + tail_conv2(a_top >> 16, b_top >> 16)) + tail_conv2(a_bot >> 16, b_bot >> 16);
+    tail_f2 w = khalf + knq * sum;
+    if (__builtin_expect(m.x == 0 || m.y == 0, 0)) {  // (rare) some texel has no data: the valid-average
+        const tail_u16x2 ca = __builtin_elementwise_min(at, one) + __builtin_elementwise_min(ab, one), cb = __builtin_elementwise_min(bt2, one) + __builtin_elementwise_min(bb, one);
+        const tail_f2 d = {sum.x / float(max(uint32_t(ca.x) + uint32_t(ca.y), 1u)), sum.y / float(max(uint32_t(cb.x) + uint32_t(cb.y), 1u))};
+        w = khalf + kn * d;
+    }
+    qa = uint32_t(w.x);
+    qb = uint32_t(w.y);
+}
+__device__ __forceinline__ uint32_t down_one_r16(uint32_t t00, uint32_t t01, uint32_t t10, uint32_t t11) {
+    const float r = 1.0f / 65535.0f;
+    const float x00 = float(t00), x01 = float(t01), x10 = float(t10), x11 = float(t11);
+    const float sum = ((__builtin_fmaf(x00, r, x00) + __builtin_fmaf(x01, r, x01)) + __builtin_fmaf(x10, r, x10)) + __builtin_fmaf(x11, r, x11);
+    float w = 0.5f + (0.25f * (65535.0f / 65536.0f)) * sum;
+    if (__builtin_expect(min(min(t00, t01), min(t10, t11)) == 0, 0)) {
+        const uint32_t count = min(t00, 1u) + min(t01, 1u) + min(t10, 1u) + min(t11, 1u);
+        w = 0.5f + (65535.0f / 65536.0f) * (sum / float(max(count, 1u)));
+    }
+    return uint32_t(w);
+}
+
 template <uint32_t kFormat, bool kRegular>
 __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A_in) {
     FusedArgs A = A_in;
@@ -1337,11 +1377,11 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A_in) {
     const uint32_t rx1 = ((tile_x & 1u) * c + rem_x) >> 1, ry1 = ((tile_y & 1u) * c + rem_y) >> 1;
     TT* atlas = reinterpret_cast<TT*>(A.atlas);
     auto down = [](uint32_t t00, uint32_t t01, uint32_t t10, uint32_t t11) -> uint32_t {
-        if constexpr (kR16) return downsample4(t00, t01, t10, t11);
+        if constexpr (kR16) return down_one_r16(t00, t01, t10, t11);
         else return downsample4_rgba8(t00, t01, t10, t11);
     };
 
-    uint32_t t[4][4];  // [row][col]
+    uint32_t t[4][4];  // [row][col]  (R16: t[r][0], t[r][1] hold the row's two DWORDS — pixels 0 | 1 and 2 | 3 — as loaded)
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
@@ -1364,11 +1404,8 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A_in) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 if constexpr (kR16) {  // 4-byte aligned (b even)
-                    const uint32_t lo = *reinterpret_cast<const uint32_t*>(p + r * T), hi = *reinterpret_cast<const uint32_t*>(p + r * T + 2);
-                    t[r][0] = lo & 0xFFFFu;
-                    t[r][1] = lo >> 16;
-                    t[r][2] = hi & 0xFFFFu;
-                    t[r][3] = hi >> 16;
+                    t[r][0] = *reinterpret_cast<const uint32_t*>(p + r * T);
+                    t[r][1] = *reinterpret_cast<const uint32_t*>(p + r * T + 2);
                 } else {  // 8-byte aligned (b even or not: (b + 4k) texels of 4 bytes; pairs need b even) — two texels per load
                     if ((b & 1u) == 0) {
                         const uint2 lo = *reinterpret_cast<const uint2*>(p + r * T), hi = *reinterpret_cast<const uint2*>(p + r * T + 2);
@@ -1387,9 +1424,14 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A_in) {
     // lod-1: 2 x 2 pixels, each from a 2 x 2 block in OFFSETS order (0,0),(0,1),(1,0),(1,1) of (dx, dy)
     uint32_t q[2][2];  // [row][col]
 #pragma unroll
-    for (int r = 0; r < 2; r++)
+    for (int r = 0; r < 2; r++) {
+        if constexpr (kR16) {  // the row pair's two pixels at once, from the packed dwords
+            down_pair_r16(t[2 * r][0], t[2 * r + 1][0], t[2 * r][1], t[2 * r + 1][1], q[r][0], q[r][1]);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 2; k++) q[r][k] = down(t[2 * r][2 * k], t[2 * r + 1][2 * k], t[2 * r][2 * k + 1], t[2 * r + 1][2 * k + 1]);
+            for (int k = 0; k < 2; k++) q[r][k] = down(t[2 * r][2 * k], t[2 * r + 1][2 * k], t[2 * r][2 * k + 1], t[2 * r + 1][2 * k + 1]);
+        }
+    }
     if (active) {
         const uint32_t self = self1;
         if (self != kInvalid && !BT_ABLATE(A, 1073741824u)) {  // (1073741824: no lod-1 stores — timing experiment)
@@ -1431,283 +1473,6 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A_in) {
 }
 
 
-// ---- fused_tail, R16 (round 5): ONE dependent round trip, a quarter of the waves -------------------------------------
-// The kernel above is a latency chain over 21 k short waves: with every load, store and lookup compiled out it still takes 11.6 of its
-// 27 us (profiles/r05_tail_ablation.txt) — wave dispatch — and the rest is lookups -> loads -> stores -> lookups one after the other.
-// Here a thread owns 8 x 8 pixels of the input LOD's mosaic = four 4 x 4 blocks (c % 4 == 0: each inside one tile; the 8 x 8 block
-// may straddle two): all its 16 loads are issued at once, the 4 x 4 / 2 x 2 / 1 pixels of the three LODs below come out of registers
-// with no shuffle, tile indices are arithmetic where the atlas is in allocation order (FusedArgs::regular), and everything a thread
-// stores follows its one round of loads.  Workgroup = 16 x 16 threads = 128 x 128 input pixels (16k job: 1024 workgroups instead of
-// 4096).  The all-valid case of downsample.wgsl:25-39 runs two pixels at a time in the 2^16-scaled domain of fused_main's fast loop
-// (same operations, same order: bit-identical); a 2 x 2 block with a no-data texel takes downsample4.
-// Apron rows of the LODs fused_main produced: one workgroup per tile, four texel pairs per thread, loads before stores.
-__device__ __forceinline__ void tail2_apron_rows(const FusedArgs& A, uint32_t side, uint32_t e) {
-    const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
-    const uint32_t pairs = b * T;  // texel pairs of the 2b apron rows of a tile
-    for (uint32_t k = 0; k < A.apron_lods; k++) {
-        const uint32_t lod = A.lod + k, n = 1u << lod, blocks = n * n;
-        if (e >= blocks) {
-            e -= blocks;
-            continue;
-        }
-        const uint32_t tx = e / n, ty = e % n;
-        const uint32_t self = grid_lookup(A, side, lod, int(tx), int(ty));
-        if (self == kInvalid) return;
-        const uint32_t north = grid_lookup(A, side, lod, int(tx), int(ty) - 1), south = grid_lookup(A, side, lod, int(tx), int(ty) + 1);
-        uint32_t* dst_tile = reinterpret_cast<uint32_t*>(A.atlas + uint64_t(self) * T * T);
-        for (uint32_t base = 0; base < pairs; base += 1024u) {
-            uint32_t v[4], where[4];
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                // branch-free (selects only): the eight loads of a thread leave back to back
-                const uint32_t i = base + j * 256u + threadIdx.x;
-                const bool in = i < pairs;
-                const uint32_t ii = in ? i : 0u;
-                const uint32_t r = ii / (T / 2u), px = 2u * (ii % (T / 2u)), py = r < b ? r : c + r;
-                const int rx = px < b ? -1 : (px >= o ? 1 : 0), ry = r < b ? -1 : 1;
-                // the neighbour that governs this pair (stitch.wgsl:57-66: rows first, corners by the diagonal one): the x neighbours only at the corners
-                const uint32_t nb = rx == 0 ? (ry < 0 ? north : south) : grid_lookup(A, side, lod, int(tx) + rx, int(ty) + ry);
-                const bool have = nb != kInvalid;
-                // the neighbour's centre texels — or, neighbour absent, the own centre clamped (a corner pair clamps to ONE texel)
-                const uint32_t sy = have ? uint32_t(int(py) - ry * int(c)) : min(max(py, b), o - 1u);
-                const uint32_t sx0 = have ? uint32_t(int(px) - rx * int(c)) : min(max(px, b), o - 1u);
-                const uint32_t sx1 = have ? sx0 + 1u : min(max(px + 1u, b), o - 1u);
-                const uint16_t* row = A.atlas + uint64_t(have ? nb : self) * T * T + sy * T;
-                where[j] = in ? (py * T + px) >> 1 : kInvalid;
-                v[j] = uint32_t(row[sx0]) | (uint32_t(row[sx1]) << 16);
-            }
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++)
-                if (where[j] != kInvalid) dst_tile[where[j]] = v[j];
-        }
-        return;
-    }
-}
-
-// kBlocks: 8 x 8 blocks per thread, 128 rows apart (workgroup = 128 x 128 kBlocks input pixels).  With two, both blocks' loads are issued
-// up front and the second block's texels are made to arrive BEFORE the first block's stores are issued (one in-order memory counter: a
-// wait for loads issued behind stores waits for the stores' acknowledges too), so the first block's stores travel while the second
-// block is computed.
-template <bool kRegular, uint32_t kBlocks>
-__global__ __launch_bounds__(256) void fused_tail2_kernel(FusedArgs A_in) {
-    FusedArgs A = A_in;
-    A.regular = kRegular ? 1u : 0u;  // (a compile-time fact: the table lookups and their registers fall away)
-    const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
-    const uint32_t size = (1u << A.lod) * c;  // mosaic extent of the input LOD (a multiple of 4)
-    {
-        const uint32_t ny = (size + 128u * kBlocks - 1u) / (128u * kBlocks);
-        if (blockIdx.y >= ny) {  // workgroups past the mosaic: the apron rows
-            if (BT_ABLATE(A, 268435456u)) return;  // (268435456: no apron workgroups — timing experiment)
-            tail2_apron_rows(A, blockIdx.z, (blockIdx.y - ny) * gridDim.x + blockIdx.x);
-            return;
-        }
-    }
-    const uint32_t tile_texels = T * T, side = blockIdx.z;
-    const uint32_t gx = blockIdx.x * 128u + 8u * (threadIdx.x & 15u), gy_first = blockIdx.y * (128u * kBlocks) + 8u * (threadIdx.x >> 4);
-#ifdef BT_DEBUG_HOOKS
-    // (134217728: real-time (100 MHz) stamps per workgroup — entry, lod-1 computed (its loads have landed), lod-1 stored, lod-2 stored, end —
-    // into the atlas's last layer behind fused_main's; tools/tail_probe.py)
-    auto stamp = [&](uint32_t slot) {
-        if (BT_ABLATE(A, 134217728u) && threadIdx.x == 0)
-            reinterpret_cast<unsigned long long*>(A.atlas + uint64_t(A.m.atlas_size - 1u) * T * T)[32768u + (blockIdx.y * gridDim.x + blockIdx.x) * 8u + slot] = __builtin_amdgcn_s_memrealtime();
-    };
-#else
-    auto stamp = [&](uint32_t) {};
-#endif
-    stamp(0);
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-
-    // ---- the 16 loads of a block: sub-block (sx, sy) = pixels [gx + 4 sx, +4) x [gy + 4 sy, +4), rows as two aligned dwords (b even).
-    // ONE division per axis: the second sub-block is the next tile's first one or 4 pixels on; the tile / in-tile coordinates of a
-    // pixel k LODs down follow by shifts: floor(floor(x / 2^k) / c) = floor(x / c) >> k (as in the kernel above)
-    struct Block {
-        uint32_t tile_xs[2], rem_xs[2], tile_ys[2], rem_ys[2];
-        uint32_t live_mask, have_mask;  // bit sy * 2 + sx: the sub-block lies inside the mosaic / its input tile exists
-    };
-    const uint32_t tile_x0 = gx / c, rem_x0 = gx - tile_x0 * c;
-    const bool wrap_x = rem_x0 + 4u >= c;
-    auto locate_and_load = [&](uint32_t gy, Block& B, uint32_t (&t)[8][4]) {
-        const uint32_t tile_y0 = gy / c, rem_y0 = gy - tile_y0 * c;
-        const bool wrap_y = rem_y0 + 4u >= c;
-        B.tile_xs[0] = tile_x0;
-        B.tile_xs[1] = wrap_x ? tile_x0 + 1u : tile_x0;
-        B.rem_xs[0] = rem_x0;
-        B.rem_xs[1] = wrap_x ? rem_x0 + 4u - c : rem_x0 + 4u;
-        B.tile_ys[0] = tile_y0;
-        B.tile_ys[1] = wrap_y ? tile_y0 + 1u : tile_y0;
-        B.rem_ys[0] = rem_y0;
-        B.rem_ys[1] = wrap_y ? rem_y0 + 4u - c : rem_y0 + 4u;
-        B.live_mask = B.have_mask = 0;
-#pragma unroll
-        for (uint32_t sy = 0; sy < 2; sy++)
-#pragma unroll
-            for (uint32_t sx = 0; sx < 2; sx++) {
-                const bool live = gx + 4u * sx < size && gy + 4u * sy < size;
-                const uint32_t idx = live ? grid_lookup(A, side, A.lod, int(B.tile_xs[sx]), int(B.tile_ys[sy])) : kInvalid;
-                const bool have = idx != kInvalid && !BT_ABLATE(A, 33554432u);  // an absent tile reads as no data  (33554432: no texel loads — timing experiment)
-                B.live_mask |= live ? 1u << (2u * sy + sx) : 0u;
-                B.have_mask |= have ? 1u << (2u * sy + sx) : 0u;
-                const uint16_t* p = A.atlas + uint64_t(have ? idx : 0u) * tile_texels + (b + B.rem_ys[sy]) * T + b + B.rem_xs[sx];
-#pragma unroll
-                for (uint32_t r = 0; r < 4; r++) {
-                    // unconditional (an absent tile reads layer 0 and is zeroed when the texels are used): sixteen loads back to back
-                    const uint2 w = *reinterpret_cast<const uint2 __attribute__((aligned(4)))*>(p + r * T);
-                    t[4 * sy + r][2 * sx] = w.x;
-                    t[4 * sy + r][2 * sx + 1] = w.y;
-                }
-            }
-    };
-
-    // downsample.wgsl:25-39 in the 2^16-scaled domain of fused_main's fast loop, two pixels per packed operation.  F(t) = fma(x, r, x) =
-    // 65536 * RN(t / 65535) and F(0) = 0: a no-data texel adds an exact 0 to the running sum, so ((F00 + F01) + F10) + F11 IS the sum over
-    // the valid texels in OFFSETS order, rounding for rounding; what differs is the divisor.  All four valid (the common case):
-    // 0.5 + (0.25 * k) * sum with k = 65535 / 65536 (sum * 0.25 is exact).  Otherwise one IEEE division by the count — scaling by a power of
-    // two commutes with it, and an average of values <= 1 needs no clamp — and count 0 gives 0.5 + k * (0 / 1) -> 0, the defined "no data".
-    const f2 kr = {1.0f / 65535.0f, 1.0f / 65535.0f}, khalf = {0.5f, 0.5f}, kn = {65535.0f / 65536.0f, 65535.0f / 65536.0f};
-    const f2 knq = {0.25f * (65535.0f / 65536.0f), 0.25f * (65535.0f / 65536.0f)};
-    auto conv2 = [&](uint32_t a, uint32_t bq) -> f2 {
-        const f2 x = {float(a), float(bq)};
-        return __builtin_elementwise_fma(x, kr, x);
-    };
-    auto finish = [&](f2 sum, bool all_valid, uint32_t cnt_a, uint32_t cnt_b, uint32_t& qa, uint32_t& qb) {
-        f2 w = khalf + knq * sum;
-        if (__builtin_expect(!all_valid, 0)) {  // (rare) some texel has no data: the valid-average
-            const f2 d = {sum.x / float(max(cnt_a, 1u)), sum.y / float(max(cnt_b, 1u))};
-            w = khalf + kn * d;
-        }
-        qa = uint32_t(w.x);
-        qb = uint32_t(w.y);
-    };
-    // block A = (a_top | a_bot), block B likewise: packed texel pairs (low half = x0).  OFFSETS order (0,0),(0,1),(1,0),(1,1) of (dx, dy)
-    auto down_pair = [&](uint32_t a_top, uint32_t a_bot, uint32_t b_top, uint32_t b_bot, uint32_t& qa, uint32_t& qb) {
-        const u16x2 one = {1, 1};
-        const u16x2 ma = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a_top), __builtin_bit_cast(u16x2, a_bot));
-        const u16x2 mb = __builtin_elementwise_min(__builtin_bit_cast(u16x2, b_top), __builtin_bit_cast(u16x2, b_bot));
-        const u16x2 m = __builtin_elementwise_min(ma, mb);
-        const f2 sum = ((conv2(a_top & 0xFFFFu, b_top & 0xFFFFu) + conv2(a_bot & 0xFFFFu, b_bot & 0xFFFFu)) + conv2(a_top >> 16, b_top >> 16)) + conv2(a_bot >> 16, b_bot >> 16);
-        const bool all_valid = m.x != 0 && m.y != 0;
-        uint32_t cnt_a = 4, cnt_b = 4;
-        if (__builtin_expect(!all_valid, 0)) {
-            const u16x2 ca = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a_top), one) + __builtin_elementwise_min(__builtin_bit_cast(u16x2, a_bot), one);
-            const u16x2 cb = __builtin_elementwise_min(__builtin_bit_cast(u16x2, b_top), one) + __builtin_elementwise_min(__builtin_bit_cast(u16x2, b_bot), one);
-            cnt_a = uint32_t(ca.x) + uint32_t(ca.y);
-            cnt_b = uint32_t(cb.x) + uint32_t(cb.y);
-        }
-        finish(sum, all_valid, cnt_a, cnt_b, qa, qb);
-    };
-    // the same for values held one per register (the LODs further down)
-    auto down_pair4 = [&](uint32_t a00, uint32_t a01, uint32_t a10, uint32_t a11, uint32_t b00, uint32_t b01, uint32_t b10, uint32_t b11, uint32_t& qa, uint32_t& qb) {
-        const bool all_valid = min(min(min(a00, a01), min(a10, a11)), min(min(b00, b01), min(b10, b11))) != 0;
-        const f2 sum = ((conv2(a00, b00) + conv2(a01, b01)) + conv2(a10, b10)) + conv2(a11, b11);
-        uint32_t cnt_a = 4, cnt_b = 4;
-        if (__builtin_expect(!all_valid, 0)) {
-            cnt_a = min(a00, 1u) + min(a01, 1u) + min(a10, 1u) + min(a11, 1u);
-            cnt_b = min(b00, 1u) + min(b01, 1u) + min(b10, 1u) + min(b11, 1u);
-        }
-        finish(sum, all_valid, cnt_a, cnt_b, qa, qb);
-    };
-
-    auto process = [&](const Block& B, uint32_t (&t)[8][4], bool first, auto arrive) {
-        // ---- lod-1: 4 x 4 pixels, q[row][col]; pixel (i, j) from rows 2i, 2i + 1 of dword j
-        uint32_t q[4][4];
-    #pragma unroll
-        for (uint32_t i = 0; i < 4; i++)
-    #pragma unroll
-            for (uint32_t j = 0; j < 4; j += 2) {
-                const bool have = (B.have_mask >> (2u * (i >> 1) + (j >> 1))) & 1u;  // sub-block (sx = j / 2, sy = i / 2)
-                down_pair(have ? t[2 * i][j] : 0u, have ? t[2 * i + 1][j] : 0u, have ? t[2 * i][j + 1] : 0u, have ? t[2 * i + 1][j + 1] : 0u, q[i][j], q[i][j + 1]);
-            }
-        if (first) stamp(1);
-        arrive();  // (two blocks: the other block's texels land before this block's first store is issued)
-        // The stores of a level go through ONE rolled loop over the four sub-blocks (values picked by selects): unrolled, the apron pushes —
-        // executed by the few threads within b of a tile edge — were 7 of the kernel's 9 thousand instructions.
-        auto sel4 = [](uint32_t i, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) -> uint32_t { return i == 0 ? v0 : (i == 1 ? v1 : (i == 2 ? v2 : v3)); };
-        const uint32_t live_mask = B.live_mask;
-        if (!BT_ABLATE(A, 1073741824u)) {  // (1073741824: no lod-1 stores — timing experiment)
-            // packed rows of the sub-blocks' 2 x 2 lod-1 pixels: [sub-block][row]
-            const uint32_t r00 = q[0][0] | (q[0][1] << 16), r01 = q[1][0] | (q[1][1] << 16), r10 = q[0][2] | (q[0][3] << 16), r11 = q[1][2] | (q[1][3] << 16);
-            const uint32_t r20 = q[2][0] | (q[2][1] << 16), r21 = q[3][0] | (q[3][1] << 16), r30 = q[2][2] | (q[2][3] << 16), r31 = q[3][2] | (q[3][3] << 16);
-    #pragma nounroll
-            for (uint32_t sb = 0; sb < 4; sb++) {
-                if (__builtin_expect(!((live_mask >> sb) & 1u), 0)) continue;
-                const uint32_t sx = sb & 1u, sy = sb >> 1;
-                const uint32_t tile_x = sx ? B.tile_xs[1] : B.tile_xs[0], tile_y = sy ? B.tile_ys[1] : B.tile_ys[0];
-                const uint32_t rem_x = sx ? B.rem_xs[1] : B.rem_xs[0], rem_y = sy ? B.rem_ys[1] : B.rem_ys[0];
-                // the sub-block's 2 x 2 lod-1 pixels lie in one lod-1 tile (4 x 4 block inside one input tile)
-                const uint32_t tx1 = tile_x >> 1, ty1 = tile_y >> 1, rx1 = ((tile_x & 1u) * c + rem_x) >> 1, ry1 = ((tile_y & 1u) * c + rem_y) >> 1;
-                const uint32_t self = grid_lookup(A, side, A.lod - 1, int(tx1), int(ty1));
-                if (__builtin_expect(self == kInvalid, 0)) continue;
-                const uint32_t row0 = sel4(sb, r00, r10, r20, r30), row1 = sel4(sb, r01, r11, r21, r31);
-                uint16_t* centre = A.atlas + uint64_t(self) * tile_texels + (b + ry1) * T + b + rx1;
-                *reinterpret_cast<uint32_t*>(centre) = row0;
-                *reinterpret_cast<uint32_t*>(centre + T) = row1;
-                // aprons: only a block within b of its tile's edge pushes (b even: the 2 x 2 block with even coordinates shares its targets)
-                if (__builtin_expect((rx1 < b || rx1 + 2u > c - b || ry1 < b || ry1 + 2u > c - b) && !BT_ABLATE(A, 536870912u), 0)) {  // (536870912: no apron pushes of lod-1)
-                    const PushNb nb1 = push_targets(A, side, A.lod - 1, tx1, ty1, rx1, ry1, true);
-    #pragma nounroll
-                    for (uint32_t e = 0; e < 4; e++) {
-                        const uint32_t row = (e & 2u) ? row1 : row0;
-                        push_store<uint16_t>(A, nb1, self, rx1 + (e & 1u), ry1 + (e >> 1), uint16_t((e & 1u) ? row >> 16 : row & 0xFFFFu));
-                    }
-                }
-            }
-        }
-        if (first) stamp(2);
-        if (A.levels < 2 || BT_ABLATE(A, 67108864u)) return;  // (67108864: lod-1 only — timing experiment)
-
-        // ---- lod-2: 2 x 2 pixels, one per sub-block
-        uint32_t p2[2][2];
-    #pragma unroll
-        for (uint32_t i = 0; i < 2; i++)
-            down_pair4(q[2 * i][0], q[2 * i + 1][0], q[2 * i][1], q[2 * i + 1][1], q[2 * i][2], q[2 * i + 1][2], q[2 * i][3], q[2 * i + 1][3], p2[i][0], p2[i][1]);
-    #pragma nounroll
-        for (uint32_t sb = 0; sb < 4; sb++) {
-            if (__builtin_expect(!((live_mask >> sb) & 1u), 0)) continue;
-            const uint32_t sx = sb & 1u, sy = sb >> 1;
-            const uint32_t tile_x = sx ? B.tile_xs[1] : B.tile_xs[0], tile_y = sy ? B.tile_ys[1] : B.tile_ys[0];
-            const uint32_t rem_x = sx ? B.rem_xs[1] : B.rem_xs[0], rem_y = sy ? B.rem_ys[1] : B.rem_ys[0];
-            const uint32_t tx2 = tile_x >> 2, ty2 = tile_y >> 2, rx2 = ((tile_x & 3u) * c + rem_x) >> 2, ry2 = ((tile_y & 3u) * c + rem_y) >> 2;
-            const uint32_t self = grid_lookup(A, side, A.lod - 2, int(tx2), int(ty2));
-            if (__builtin_expect(self == kInvalid, 0)) continue;
-            const uint32_t v = sel4(sb, p2[0][0], p2[0][1], p2[1][0], p2[1][1]);
-            A.atlas[uint64_t(self) * tile_texels + (b + ry2) * T + b + rx2] = uint16_t(v);
-            if (__builtin_expect(rx2 < b || rx2 >= c - b || ry2 < b || ry2 >= c - b, 0)) push_pixel<false, uint16_t>(A, side, A.lod - 2, tx2, ty2, self, rx2, ry2, uint16_t(v));
-        }
-        if (first) stamp(3);
-        if (A.levels < 3) return;
-
-        // ---- lod-3: one pixel (levels == 3 implies lod >= 3: the mosaic is a multiple of 8 wide, the 8 x 8 block is whole and — 8 | 8c — in one lod-3 tile's share)
-        if (!(B.live_mask & 1u)) return;
-        uint32_t v3, unused;
-        down_pair4(p2[0][0], p2[1][0], p2[0][1], p2[1][1], p2[0][0], p2[1][0], p2[0][1], p2[1][1], v3, unused);
-        {
-            const uint32_t tx3 = B.tile_xs[0] >> 3, ty3 = B.tile_ys[0] >> 3;
-            const uint32_t rx3 = ((B.tile_xs[0] & 7u) * c + B.rem_xs[0]) >> 3, ry3 = ((B.tile_ys[0] & 7u) * c + B.rem_ys[0]) >> 3;
-            const uint32_t self = grid_lookup(A, side, A.lod - 3, int(tx3), int(ty3));
-            if (self != kInvalid) {
-                A.atlas[uint64_t(self) * tile_texels + (b + ry3) * T + b + rx3] = uint16_t(v3);
-                if (__builtin_expect(rx3 < b || rx3 >= c - b || ry3 < b || ry3 >= c - b, 0)) push_pixel<false, uint16_t>(A, side, A.lod - 3, tx3, ty3, self, rx3, ry3, uint16_t(v3));
-            }
-        }
-    };
-    uint32_t ta[8][4];
-    Block ba;
-    locate_and_load(gy_first, ba, ta);
-    if constexpr (kBlocks == 2) {
-        uint32_t tb[8][4];
-        Block bb;
-        locate_and_load(gy_first + 128u, bb, tb);
-        process(ba, ta, true, [&] {
-#pragma unroll
-            for (uint32_t r = 0; r < 8; r++) asm volatile("" : "+v"(tb[r][0]), "+v"(tb[r][1]), "+v"(tb[r][2]), "+v"(tb[r][3]));
-        });
-        process(bb, tb, false, [] {});
-    } else {
-        process(ba, ta, true, [] {});
-    }
-    stamp(4);
-}
 
 // ---- fused_direct (Rgba8): split + the two parent LODs WITHOUT LDS staging ------------------------------------------
 // Workgroup = several 4-row blocks of one finest tile (c = 508 = 127 x 4: no partial block), thread = one centre column (two
@@ -2911,36 +2676,6 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
         }
     } else {
         const uint32_t size = (1u << job.args.lod) * job.args.m.center_size;
-        // R16 (b even in a fused plan), enough input for one 128 x 128 workgroup per CU: the 8 x 8-per-thread kernel; smaller mosaics keep the
-        // kernel below, whose 64 x 64 workgroups spread them over more CUs (config 2's tail, 4 tiles in: 7.6 vs 10.8 us)
-        uint32_t tail2_min = 256;
-#ifdef BT_DEBUG_HOOKS
-        if (const char* e = getenv("BT_FUSED_TAIL2_MIN")) tail2_min = uint32_t(atoi(e));
-#endif
-        if (job.args.m.format == BT_FORMAT_R16 && (job.args.m.border_size & 1u) == 0 && uint64_t((size + 127) / 128) * ((size + 127) / 128) * job.args.sides >= tail2_min) {
-            // two 8 x 8 blocks per thread where that still leaves every CU several workgroups
-            uint32_t blocks = uint64_t((size + 127) / 128) * ((size + 255) / 256) * job.args.sides >= 512 ? 2u : 1u;
-#ifdef BT_DEBUG_HOOKS
-            if (const char* e = getenv("BT_FUSED_TAIL_BLOCKS")) blocks = atoi(e) == 2 ? 2u : 1u;
-#endif
-            dim3 grid((size + 127) / 128, (size + 128 * blocks - 1) / (128 * blocks), job.args.sides);
-            uint64_t extra = 0;  // apron rows of the LODs fused_main produced: one workgroup per tile
-            for (uint32_t k = 0; k < job.args.apron_lods; k++) extra += 1ull << (2 * (job.args.lod + k));
-            grid.y += uint32_t((extra + grid.x - 1) / grid.x);
-            auto launch = [&] {
-                if (job.args.regular && blocks == 2) fused_tail2_kernel<true, 2><<<grid, 256, 0, p->ctx->stream>>>(job.args);
-                else if (job.args.regular) fused_tail2_kernel<true, 1><<<grid, 256, 0, p->ctx->stream>>>(job.args);
-                else if (blocks == 2) fused_tail2_kernel<false, 2><<<grid, 256, 0, p->ctx->stream>>>(job.args);
-                else fused_tail2_kernel<false, 1><<<grid, 256, 0, p->ctx->stream>>>(job.args);
-            };
-            launch();
-#ifdef BT_DEBUG_HOOKS
-            if (getenv("BT_FUSED_TAIL_TWICE")) launch();  // (timing experiment: what does a second, warm launch of the same kernel cost?)
-#endif
-            hipError_t e2 = hipGetLastError();
-            if (e2 != hipSuccess) return hip_fail(e2, "fused kernel launch");
-            return BT_OK;
-        }
         dim3 grid((size + 63) / 64, (size + 63) / 64, job.args.sides);
         if (job.args.apron_lods) {
             const uint32_t blocks_per_tile = job.args.m.format == BT_FORMAT_R16
