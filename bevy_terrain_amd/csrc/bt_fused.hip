@@ -36,6 +36,8 @@ namespace {
 
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 
+#include "bt_stitch.hpp"  // project_to_side, stitch_source, stitch_region_body (the cube's cross-face seam regions)
+
 // Ablation switches of the profiling build (tools/, -DBT_DEBUG_HOOKS): compiled out of the product library, where
 // the branches they guard fold away and no environment variable is read.
 #ifdef BT_DEBUG_HOOKS
@@ -62,6 +64,11 @@ struct FusedArgs {
     // grid entry against that closed form, and a lookup is a handful of scalar operations instead of a dependent load from the grids
     // (fused_tail was a chain of five dependent round trips, three of them lookups).
     uint32_t regular, reg_first;
+    // fused_tail on a cube (round 5): the cross-face apron regions of the LODs fused_main produced — their sources, the neighbour faces'
+    // centres, are complete when the tail starts — ride in the tail launch as extra workgroups, one region each (stitch.wgsl:12-51, 79-118),
+    // instead of waiting for a launch of their own behind it.  seam_skip: the tail's own apron-row workgroups leave those regions alone.
+    const TaskDev* seam_tasks;
+    uint32_t seam_count, seam_skip;
     float tlx, tly, brx, bry;
     uint32_t lod;         // finest LOD of this launch (fused_main) / input LOD (fused_tail)
     uint32_t levels;      // LODs produced by this launch: main 1..3 (lod, lod-1, lod-2); tail 1..3 below lod
@@ -1253,6 +1260,12 @@ __device__ __forceinline__ void tail_apron_rows(const FusedArgs& A, uint32_t sid
         if (self == kInvalid) return;
         const uint32_t r = i / (T / 2u), px = 2u * (i % (T / 2u)), py = r < b ? r : c + r;
         const int rx = px < b ? -1 : (px >= o ? 1 : 0), ry = r < b ? -1 : 1;
+        if (A.seam_skip) {
+            // cube: a neighbour beyond ONE edge of the face lives on another face and a seam workgroup of this launch writes the region
+            // (beyond two edges — the cube's corner — there is none: clamped below like any absent neighbour)
+            const bool out_x = int(tx) + rx < 0 || int(tx) + rx >= int(n), out_y = int(ty) + ry < 0 || int(ty) + ry >= int(n);
+            if (out_x != out_y) return;
+        }
         const uint32_t nb = grid_lookup(A, side, lod, int(tx) + rx, int(ty) + ry);
         uint32_t v[2];
 #pragma unroll
@@ -1359,8 +1372,23 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A_in) {
         const uint32_t extent = (1u << A.lod) * A.m.center_size, ny = (extent + 63u) / 64u;
         if (blockIdx.y >= ny) {  // workgroups past the mosaic: apron rows (Rgba8: and columns)
             if (BT_ABLATE(A, 268435456u)) return;  // (268435456: no apron workgroups — timing experiment)
-            if constexpr (kR16) tail_apron_rows(A, blockIdx.z, (blockIdx.y - ny) * gridDim.x + blockIdx.x);
-            else tail_aprons_rgba8(A, blockIdx.z, (blockIdx.y - ny) * gridDim.x + blockIdx.x);
+            const uint32_t e = (blockIdx.y - ny) * gridDim.x + blockIdx.x;
+            if constexpr (kR16) {
+                if (A.seam_count) {  // the last ceil(seam_count / sides) extra workgroups of every side: one cross-face region each
+                    const uint32_t per_side = (A.seam_count + gridDim.z - 1u) / gridDim.z, extra = (gridDim.y - ny) * gridDim.x;
+                    if (e >= extra - per_side) {
+                        const uint32_t f = blockIdx.z * per_side + (e - (extra - per_side));
+                        if (f < A.seam_count) {
+                            if ((A.m.border_size & 1u) == 0 && (A.m.texture_size & 1u) == 0) stitch_region_body<uint16_t, 2>(A.m, A.atlas, A.seam_tasks[f]);
+                            else stitch_region_body<uint16_t, 1>(A.m, A.atlas, A.seam_tasks[f]);
+                        }
+                        return;
+                    }
+                }
+                tail_apron_rows(A, blockIdx.z, e);
+            } else {
+                tail_aprons_rgba8(A, blockIdx.z, e);
+            }
             return;
         }
     }
@@ -2018,6 +2046,7 @@ struct FusedJobDev {  // one fused launch of a compiled queue
     bool dma = false;        // fused_main stages through LDS-DMA (every raster of the job 16-byte aligned in base and pitch)
     std::vector<MainItem> host_items;  // fused_main's / fused_direct's items as uploaded (tile-row order): streamed runs cut fused_main's into bands, fused_source_window reads both
     bool direct = false;     // a fused_direct launch (reads the source texel by texel: no staged window)
+    uint32_t seam_first = 0;  // fused_tail with seam workgroups: its tasks are p->tasks_dev[seam_first ...] (args.seam_count of them)
     float tly = 0.0f, bry = 1.0f;
 };
 
@@ -2483,6 +2512,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
 
         // tail launches: three LODs at a time below the last fused one
         uint32_t in_lod = lod_hi - (main_levels - 1);
+        int first_tail_job = -1, first_tail_plan = -1;
         while (in_lod > lod_lo) {
             const uint32_t levels = std::min(3u, in_lod - lod_lo);
             uint64_t lt_extra = 0;
@@ -2504,19 +2534,22 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                 lt.algorithmic_bytes += tiles_at(in_lod - k) * Tt * Tt * bpp;
                 lt.task_count += uint32_t(tiles_at(in_lod - k));
             }
+            if (first_tail_job < 0) {
+                first_tail_job = int(jobs.size());
+                first_tail_plan = int(plan.size());
+            }
             jobs.push_back(tail);
             plan.push_back(lt);
             in_lod -= levels;
         }
 
-        // cube: aprons that cross a face edge come from the generic stitch kernel (after everything else)
+        // cube: aprons that cross a face edge (stitch.wgsl:12-51, 79-118), one task — one workgroup — per region: only the apron regions whose
+        // neighbour lives on another face (the fused kernels wrote the rest).  The regions of the LODs fused_main produced read centres that are
+        // complete when the tail launch starts: they ride in that launch as extra workgroups (round 5: the 16k-texel-wide job's seam launch was
+        // 33 of 500 us), and the tail's own apron-row workgroups leave those regions alone (FusedArgs::seam_skip).  What the tail itself
+        // produces (the few tiles of the top LODs) is stitched by the generic kernel behind it, as before.
         if (spherical) {
-            const uint32_t first = uint32_t(tasks.size());
-            uint64_t seam_pixels = 0;
-            for (const Task* t : stitches) {
-                const uint32_t n = 1u << t->coord.lod;
-                if (t->coord.x != 0 && t->coord.y != 0 && t->coord.x != n - 1 && t->coord.y != n - 1) continue;
-                if (hybrid && t->coord.lod == lod_hi) continue;  // stitched completely by the batched kernel above
+            auto seam_task = [&](const Task* t) {
                 TaskDev d{};
                 d.atlas_index = t->atlas_index;
                 d.side = t->coord.side;
@@ -2527,24 +2560,65 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                     d.rel_index[i] = t->rel[i].atlas_index;
                     d.rel_side[i] = t->rel[i].coordinate.side;
                 }
-                // only the apron regions whose neighbour lives on another face (the fused kernels already wrote the rest), one
-                // task — one workgroup of stitch_region_kernel — per region
-                for (int i = 0; i < 8; i++)
-                    if (d.rel_index[i] != BT_INVALID_ATLAS_INDEX && d.rel_side[i] != d.side) {
-                        d.regions = 1u << i;
-                        tasks.push_back(d);
-                        seam_pixels += uint64_t(m.border_size) * (i < 4 ? cc : m.border_size);
+                return d;
+            };
+            auto on_face_edge = [](const Task* t) {
+                const uint32_t n = 1u << t->coord.lod;
+                return t->coord.x == 0 || t->coord.y == 0 || t->coord.x == n - 1 || t->coord.y == n - 1;
+            };
+            // in the tail launch: R16 main plan, unsharded, a tail launch with apron-row workgroups exists, and EVERY region beyond exactly one
+            // face edge of the tiles whose apron rows the tail writes has its neighbour (then "skip" and "a seam workgroup writes it" coincide)
+            bool in_tail = !shard && !direct && !hybrid && first_tail_job >= 0 && jobs[size_t(first_tail_job)].args.apron_lods != 0;
+#ifdef BT_DEBUG_HOOKS
+            if (getenv("BT_FUSED_SEAMS_LATE")) in_tail = false;
+#endif
+            const uint32_t main_lo = lod_hi - (main_levels - 1);  // LODs main_lo .. lod_hi come out of the main launch
+            if (in_tail)
+                for (const Task* t : stitches) {
+                    if (!on_face_edge(t) || t->coord.lod < main_lo || t->coord.lod >= lod_hi) continue;
+                    const int n = int(1u << t->coord.lod);
+                    static const int off[8][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}, {-1, -1}, {1, -1}, {1, 1}, {-1, 1}};  // coordinate.rs:209-218
+                    for (int i = 0; i < 8; i++) {
+                        const int nx = int(t->coord.x) + off[i][0], ny = int(t->coord.y) + off[i][1];
+                        const bool out_x = nx < 0 || nx >= n, out_y = ny < 0 || ny >= n;
+                        if (out_x != out_y && !(t->rel[i].atlas_index != BT_INVALID_ATLAS_INDEX && t->rel[i].coordinate.side != t->coord.side)) in_tail = false;
                     }
+                }
+            uint64_t tail_pixels = 0, late_pixels = 0;
+            const uint32_t tail_first = uint32_t(tasks.size());
+            for (int pass = 0; pass < 2; pass++) {  // the tail launch's regions first, then the later launch's
+                if (pass == 1 && in_tail) {
+                    FusedJobDev& tj = jobs[size_t(first_tail_job)];
+                    tj.seam_first = tail_first;
+                    tj.args.seam_count = uint32_t(tasks.size()) - tail_first;
+                    tj.args.seam_skip = 1;
+                    plan[size_t(first_tail_plan)].algorithmic_bytes += 2 * tail_pixels * bpp;
+                }
+                const uint32_t first = uint32_t(tasks.size());
+                for (const Task* t : stitches) {
+                    if (!on_face_edge(t)) continue;
+                    if (hybrid && t->coord.lod == lod_hi) continue;  // stitched completely by the batched kernel above
+                    const bool rides = in_tail && t->coord.lod >= main_lo;
+                    if (rides != (pass == 0)) continue;
+                    TaskDev d = seam_task(t);
+                    for (int i = 0; i < 8; i++)
+                        if (d.rel_index[i] != BT_INVALID_ATLAS_INDEX && d.rel_side[i] != d.side) {
+                            d.regions = 1u << i;
+                            tasks.push_back(d);
+                            (pass == 0 ? tail_pixels : late_pixels) += uint64_t(m.border_size) * (i < 4 ? cc : m.border_size);
+                        }
+                }
+                if (pass == 0) continue;
+                Launch ls{};
+                ls.kind = kLaunchStitch;
+                ls.aux0 = 2u;  // one region per task
+                ls.attachment = ai;
+                ls.first_task = first;
+                ls.task_count = uint32_t(tasks.size()) - first;
+                ls.algorithmic_bytes = 2 * late_pixels * bpp;
+                ls.phase = shard ? 2u : 0u;
+                if (ls.task_count) plan.push_back(ls);
             }
-            Launch ls{};
-            ls.kind = kLaunchStitch;
-            ls.aux0 = 2u;  // one region per task
-            ls.attachment = ai;
-            ls.first_task = first;
-            ls.task_count = uint32_t(tasks.size()) - first;
-            ls.algorithmic_bytes = 2 * seam_pixels * bpp;
-            ls.phase = shard ? 2u : 0u;
-            if (ls.task_count) plan.push_back(ls);
         }
     }
     return true;
@@ -2677,12 +2751,16 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
     } else {
         const uint32_t size = (1u << job.args.lod) * job.args.m.center_size;
         dim3 grid((size + 63) / 64, (size + 63) / 64, job.args.sides);
+        job.args.seam_tasks = p->tasks_dev + job.seam_first;  // ((re)allocated with the plan: patched at launch like the rasters)
         if (job.args.apron_lods) {
             const uint32_t blocks_per_tile = job.args.m.format == BT_FORMAT_R16
                 ? (job.args.m.border_size * job.args.m.texture_size + 255u) / 256u  // texel pairs of the 2b apron rows
                 : (2u * job.args.m.border_size * (job.args.m.texture_size + (job.args.apron_cols ? job.args.m.center_size : 0u)) + 255u) / 256u;
             uint64_t extra = 0;
             for (uint32_t k = 0; k < job.args.apron_lods; k++) extra += (1ull << (2 * (job.args.lod + k))) * blocks_per_tile;
+            // + the cross-face seam regions: the LAST ceil(seam_count / sides) extra workgroups of every side (whole grid rows in front of
+            // them may idle: the kernel counts from the end)
+            extra += (job.args.seam_count + job.args.sides - 1) / job.args.sides;
             grid.y += uint32_t((extra + grid.x - 1) / grid.x);
         }
         if (job.args.m.format == BT_FORMAT_R16) {
