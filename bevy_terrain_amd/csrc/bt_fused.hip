@@ -1369,21 +1369,24 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A_in) {
     constexpr bool kR16 = kFormat == BT_FORMAT_R16;
     using TT = typename std::conditional<kR16, uint16_t, uint32_t>::type;  // texel
     {
-        const uint32_t extent = (1u << A.lod) * A.m.center_size, ny = (extent + 63u) / 64u;
-        if (blockIdx.y >= ny) {  // workgroups past the mosaic: apron rows (Rgba8: and columns)
+        // the grid's FIRST rows are the extra workgroups — apron rows (Rgba8: and columns) of the LODs above, on a cube the cross-face seam
+        // regions in front of them: short dependent chains that then run beside the mosaic workgroups instead of behind the last of them
+        const uint32_t extent = (1u << A.lod) * A.m.center_size, ny = (extent + 63u) / 64u, extra_rows = gridDim.y - ny;
+        if (blockIdx.y < extra_rows) {
             if (BT_ABLATE(A, 268435456u)) return;  // (268435456: no apron workgroups — timing experiment)
-            const uint32_t e = (blockIdx.y - ny) * gridDim.x + blockIdx.x;
+            uint32_t e = blockIdx.y * gridDim.x + blockIdx.x;
             if constexpr (kR16) {
-                if (A.seam_count) {  // the last ceil(seam_count / sides) extra workgroups of every side: one cross-face region each
-                    const uint32_t per_side = (A.seam_count + gridDim.z - 1u) / gridDim.z, extra = (gridDim.y - ny) * gridDim.x;
-                    if (e >= extra - per_side) {
-                        const uint32_t f = blockIdx.z * per_side + (e - (extra - per_side));
+                if (A.seam_count) {  // the first ceil(seam_count / sides) extra workgroups of every side: one cross-face region each
+                    const uint32_t per_side = (A.seam_count + gridDim.z - 1u) / gridDim.z;
+                    if (e < per_side) {
+                        const uint32_t f = blockIdx.z * per_side + e;
                         if (f < A.seam_count) {
                             if ((A.m.border_size & 1u) == 0 && (A.m.texture_size & 1u) == 0) stitch_region_body<uint16_t, 2>(A.m, A.atlas, A.seam_tasks[f]);
                             else stitch_region_body<uint16_t, 1>(A.m, A.atlas, A.seam_tasks[f]);
                         }
                         return;
                     }
+                    e -= per_side;
                 }
                 tail_apron_rows(A, blockIdx.z, e);
             } else {
@@ -1392,12 +1395,13 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A_in) {
             return;
         }
     }
+    const uint32_t mosaic_row = blockIdx.y - (gridDim.y - ((1u << A.lod) * A.m.center_size + 63u) / 64u);
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
     const uint32_t tile_texels = T * T;
     const uint32_t side = blockIdx.z;
     const uint32_t size = (1u << A.lod) * c;  // mosaic extent of the input LOD (a multiple of 4)
     const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
-    const uint32_t gx = blockIdx.x * 64u + 4u * tx, gy = blockIdx.y * 64u + 4u * ty;  // first input pixel
+    const uint32_t gx = blockIdx.x * 64u + 4u * tx, gy = mosaic_row * 64u + 4u * ty;  // first input pixel
     const bool active = gx < size && gy < size;
     // ONE division per axis: c is a multiple of 4, so the 4 x 4 block lies in one tile, and the tile / in-tile coordinates
     // of its pixel at LOD-k follow by shifts: tile >> k, ((tile & (2^k - 1)) * c + rem) >> k

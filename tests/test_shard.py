@@ -205,6 +205,13 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(result, held_tiles):
     assert line["verify_vs_oracle_overlapped_second_atlas"] == {"tiles": held_tiles, "identical": held_tiles, "index_contract": True}
     full, quarter = 1024 * 524288 + 256 * 524288 + 64 * 524288, 256 * 524288 + 64 * 524288
     assert cfg["all_gather_bytes_per_rank"] == (full if result == "replicated" else quarter)
+    # round 5: the one-tile-per-rank collective that ran before anything was timed, the N = 1 step of the same invocation, and the
+    # scaling of every mode against it
+    assert cfg["rccl_preflight"]["ranks"] == 2 and cfg["rccl_preflight"]["slot_bytes"] == 512 * 512 * 2 and "gloo" in cfg["rccl_preflight"]["through"]
+    assert cfg["n1_same_invocation"]["ms_per_step"] > 0
+    sc = cfg["scaling_vs_n1_same_invocation"]
+    assert sc["headline"]["speedup"] > 0 and abs(sc["headline"]["efficiency"] - sc["headline"]["speedup"] / 2) < 1e-12
+    assert f"{result}_overlapped" in sc and "kernels_only" in sc
     assert other["all_gather_bytes_per_rank"] == (quarter if result == "replicated" else full)
 
 
@@ -394,6 +401,11 @@ def test_library_issued_collective_single_rank():
     atlas = bt.TileAtlas.new(cfg, device)
     job = ShardedPreprocess(bt.Preprocessor.new(), atlas, bt.AssetServer().insert("s", src), "s", range(0, 4), 0, 1, collective="library")
     bt._ffi.check(bt._ffi.lib().bt_comm_check(job._comm))  # grouped ncclAllGather + ncclBroadcast through the communicator
+    import ctypes
+    ms = ctypes.c_float(-1.0)  # the tile-sized preflight bench.py --gpus N runs before its timed steps
+    bt._ffi.check(bt._ffi.lib().bt_comm_preflight(job._comm, 512 * 512 * 2, ctypes.byref(ms)))
+    assert ms.value >= 0.0
+    assert bt._ffi.lib().bt_comm_preflight(job._comm, 0, None) != 0  # a slot of no bytes is refused
     job.step()
     job.step(profile=True)
     device.synchronize()
@@ -807,3 +819,103 @@ def test_a_rank_reads_only_its_window_of_the_source(world, cube):
                 else:
                     assert np.array_equal(data[k][b:b + c, b:b + c], exp[b:b + c, b:b + c]), (rank, p)
     assert total_uploaded < 1.35 * sum(f.nbytes for f in faces)
+
+
+@pytest.mark.gpu
+def test_two_attachments_sharded_from_deferred_rasters_get_a_window_each():
+    """the source window is decided PER RASTER.  One queue with a height job (R16: fused_main) and an albedo job
+    (Rgba8: fused_direct), both rasters handed over deferred, two emulated ranks.  Each rank's two windows are its strips + halo of
+    THAT raster (round 4 reported an empty window for the raster only fused_direct reads and uploaded nothing for it); the ranks run
+    from rasters that hold nothing outside their windows, the pieces of both attachments are exchanged by hand, and after
+    BT_RUN_SHARD_FINISH rank 0 holds the oracle's tiles of both attachments.  A later BT_RUN_GENERIC run of the kept queue needs the whole
+    rasters: the missing part travels then (the uploaded window is remembered per raster)."""
+    import bevy_terrain_amd as bt
+    from bevy_terrain_amd import _ffi
+    from bevy_terrain_amd.shard import shard_pieces
+
+    device = bt.Device(0)
+    L = _ffi.lib()
+    world, T, b, lods, W = 2, 64, 2, 5, 1000
+    height = K.random_raster(O.FORMAT_R16, W, W, seed=81, holes=0.01)
+    albedo = K.random_raster(O.FORMAT_RGBA8, W, W, seed=82, holes=0.01)
+    n_tiles = sum(4 ** l for l in range(lods))
+    oracle = O.OracleAtlas(lods, 512, False, [(T, b, 1, O.FORMAT_R16), (T, b, 1, O.FORMAT_RGBA8)])
+    oracle.clear_attachment(0).preprocess_tile(0, height, (0, lods)).clear_attachment(1).preprocess_tile(1, albedo, (0, lods)).run(O.usable_cores())
+
+    def job(rank, h, a):
+        cfg = bt.TerrainConfig(lod_count=lods, atlas_size=512, path="t", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+        cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=T, border_size=b, format=bt.AttachmentFormat.R16))
+        cfg.add_attachment(bt.AttachmentConfig(name="albedo", texture_size=T, border_size=b, format=bt.AttachmentFormat.Rgba8))
+        atlas = bt.TileAtlas.new(cfg, device)
+        server = bt.AssetServer().insert("h", h).insert("a", a)
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas).clear_attachment(1, atlas)
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="h", lod_range=range(0, lods)), server, atlas, defer_upload=True)
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=1, path="a", lod_range=range(0, lods)), server, atlas, defer_upload=True)
+        _ffi.check(L.bt_preprocessor_set_shard(pre._h, rank, world))
+        return atlas, pre
+
+    jobs = []
+    for rank in range(world):
+        atlas, pre = job(rank, height, albedo)
+        windows = [pre.source_window(atlas, i)[0] for i in range(2)]
+        for (x0, y0, x1, y1) in windows:  # a strip of the raster: every row, about half the columns + the halo
+            assert (y0, y1) == (0, W) and 0 < x1 - x0 < W // world + 2 * (T + 16), windows
+        poisoned = []
+        for f, (x0, y0, x1, y1) in zip((height, albedo), windows):
+            g = np.zeros_like(f)
+            g[y0:y1, x0:x1] = f[y0:y1, x0:x1]
+            poisoned.append(g)
+        atlas, pre = job(rank, *poisoned)
+        _ffi.check(L.bt_preprocessor_run(pre._h, atlas._h, _ffi.RUN_KEEP_QUEUE | _ffi.RUN_SHARD_LOCAL))
+        device.synchronize()
+        x0, y0, x1, y1 = windows[1]
+        assert pre.source_window(atlas, 1)[1] == (x1 - x0) * (y1 - y0) * 4  # the albedo window travelled, not nothing and not everything
+        jobs.append((atlas, pre, windows, poisoned))
+    pieces = shard_pieces(jobs[0][1])
+    assert {p["attachment_index"] for p in pieces} == {0, 1} and {p["owner_rank"] for p in pieces} == {0, 1}
+    for p in pieces:  # the exchange, by hand
+        if p["owner_rank"] != 0:
+            data = jobs[p["owner_rank"]][0].download_tiles(p["attachment_index"], p["first_layer"], p["layers"])
+            for k in range(p["layers"]):
+                jobs[0][0].upload_tile(p["attachment_index"], p["first_layer"] + k, data[k])
+    atlas0, pre0, _, _ = jobs[0]
+    _ffi.check(L.bt_preprocessor_run(pre0._h, atlas0._h, _ffi.RUN_KEEP_QUEUE | _ffi.RUN_SHARD_FINISH))
+    device.synchronize()
+    assert K.assert_atlas_equal(atlas0, oracle, 0) == n_tiles
+    assert K.assert_atlas_equal(atlas0, oracle, 1) == n_tiles
+
+    # the kept queue once more, unsharded and through the generic plan: its launches read the WHOLE rasters — the part that never
+    # travelled is fetched from the caller's rows (here: the intact ones, handed over again under the same pointers' lifetime rule)
+    atlas1, pre1 = job(1, height, albedo)
+    _ffi.check(L.bt_preprocessor_run(pre1._h, atlas1._h, _ffi.RUN_KEEP_QUEUE | _ffi.RUN_SHARD_LOCAL))
+    device.synchronize()
+    _ffi.check(L.bt_preprocessor_set_shard(pre1._h, 0, 1))
+    _ffi.check(L.bt_preprocessor_run(pre1._h, atlas1._h, _ffi.RUN_KEEP_QUEUE | _ffi.RUN_GENERIC))
+    device.synchronize()
+    assert pre1.source_window(atlas1, 1, generic=True)[1] == albedo.nbytes  # (the last raster that travelled: all of the albedo, not rank 1's strip)
+    assert K.assert_atlas_equal(atlas1, oracle, 0) == n_tiles
+    assert K.assert_atlas_equal(atlas1, oracle, 1) == n_tiles
+
+
+@pytest.mark.gpu
+def test_profile_of_a_sharded_step_counts_each_launch_once():
+    """BT_RUN_SHARD_LOCAL and BT_RUN_SHARD_FINISH of one step are two profiled runs that each leave a whole event
+    row; a launch is averaged over the rows that executed it (round 4 divided by both and halved every time)."""
+    import bevy_terrain_amd as bt
+    from bevy_terrain_amd import _ffi
+
+    device = bt.Device(0)
+    L = _ffi.lib()
+    src = K.random_raster(O.FORMAT_R16, 1100, 1100, seed=5)
+    cfg = bt.TerrainConfig(lod_count=5, atlas_size=512, path="t", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=64, border_size=2))
+    atlas = bt.TileAtlas.new(cfg, device)
+    pre = bt.Preprocessor.new().preprocess_tile(bt.PreprocessDataset(path="s", lod_range=range(0, 5)), bt.AssetServer().insert("s", src), atlas)
+    _ffi.check(L.bt_preprocessor_set_shard(pre._h, 0, 2))
+    steps = 3
+    for _ in range(steps):
+        _ffi.check(L.bt_preprocessor_run(pre._h, atlas._h, _ffi.RUN_KEEP_QUEUE | _ffi.RUN_SHARD_LOCAL | _ffi.RUN_PROFILE))
+        _ffi.check(L.bt_preprocessor_run(pre._h, atlas._h, _ffi.RUN_KEEP_QUEUE | _ffi.RUN_SHARD_FINISH | _ffi.RUN_PROFILE))
+    prof = pre.profile()
+    assert len(prof) >= 3 and prof[0]["kind"] == "fused_main"
+    assert all(l["samples"] == steps and l["avg_ms"] > 0 for l in prof), prof
