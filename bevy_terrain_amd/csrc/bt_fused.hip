@@ -69,6 +69,7 @@ struct FusedArgs {
     // instead of waiting for a launch of their own behind it.  seam_skip: the tail's own apron-row workgroups leave those regions alone.
     const TaskDev* seam_tasks;
     uint32_t seam_count, seam_skip;
+    uint32_t tail_extras;  // fused_tail: extra workgroups per side (apron blocks of the LODs above + that side's share of the seam regions)
     float tlx, tly, brx, bry;
     uint32_t lod;         // finest LOD of this launch (fused_main) / input LOD (fused_tail)
     uint32_t levels;      // LODs produced by this launch: main 1..3 (lod, lod-1, lod-2); tail 1..3 below lod
@@ -1368,18 +1369,30 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A_in) {
     A.regular = kRegular ? 1u : 0u;
     constexpr bool kR16 = kFormat == BT_FORMAT_R16;
     using TT = typename std::conditional<kR16, uint16_t, uint32_t>::type;  // texel
+    // Workgroup -> work, XCD-aware (round 5).  Workgroups go to the XCDs round robin (blockIdx.x % 8) and every XCD has its own L2; a
+    // 64-pixel-wide mosaic column starts b texels into a tile row, i.e. it shares its first and last 128-byte line with the workgroup
+    // beside it — dispatched in mosaic order the two sit on different XCDs and every line is fetched from HBM twice
+    // (profiles/r05_pmc_summary.json: the tail read 67.7 MB for 33.5 MB of texels).  So: XCD k takes the k-th eighth of the mosaic
+    // workgroups (whole rows of them, neighbours in x back to back on one L2), and in front of those its eighth of the extra workgroups —
+    // apron rows (Rgba8: and columns) of the LODs above, on a cube the cross-face seam regions first: short dependent chains that run
+    // beside the mosaic work instead of behind the last of it.
+    const uint32_t nx = ((1u << A.lod) * A.m.center_size + 63u) / 64u, per_side_m = nx * nx, per_side_e = A.tail_extras;
+    const uint32_t total_m = A.sides * per_side_m, total_e = A.sides * per_side_e, chunk_m = (total_m + 7u) / 8u, chunk_e = (total_e + 7u) / 8u;
+    uint32_t side, block_x, block_y;
     {
-        // the grid's FIRST rows are the extra workgroups — apron rows (Rgba8: and columns) of the LODs above, on a cube the cross-face seam
-        // regions in front of them: short dependent chains that then run beside the mosaic workgroups instead of behind the last of them
-        const uint32_t extent = (1u << A.lod) * A.m.center_size, ny = (extent + 63u) / 64u, extra_rows = gridDim.y - ny;
-        if (blockIdx.y < extra_rows) {
-            if (BT_ABLATE(A, 268435456u)) return;  // (268435456: no apron workgroups — timing experiment)
-            uint32_t e = blockIdx.y * gridDim.x + blockIdx.x;
+        const bool plain = BT_ABLATE(A, 1024u);  // (1024: dispatch order — extras, then the mosaic row by row — timing experiment)
+        const uint32_t xcd = blockIdx.x % 8u, j = blockIdx.x / 8u;
+        const bool is_extra = plain ? blockIdx.x < total_e : j < chunk_e;
+        if (is_extra) {
+            const uint32_t id = plain ? blockIdx.x : xcd * chunk_e + j;
+            if (id >= total_e || BT_ABLATE(A, 268435456u)) return;  // (268435456: no extra workgroups — timing experiment)
+            side = id / per_side_e;
+            uint32_t e = id - side * per_side_e;
             if constexpr (kR16) {
                 if (A.seam_count) {  // the first ceil(seam_count / sides) extra workgroups of every side: one cross-face region each
-                    const uint32_t per_side = (A.seam_count + gridDim.z - 1u) / gridDim.z;
+                    const uint32_t per_side = (A.seam_count + A.sides - 1u) / A.sides;
                     if (e < per_side) {
-                        const uint32_t f = blockIdx.z * per_side + e;
+                        const uint32_t f = side * per_side + e;
                         if (f < A.seam_count) {
                             if ((A.m.border_size & 1u) == 0 && (A.m.texture_size & 1u) == 0) stitch_region_body<uint16_t, 2>(A.m, A.atlas, A.seam_tasks[f]);
                             else stitch_region_body<uint16_t, 1>(A.m, A.atlas, A.seam_tasks[f]);
@@ -1388,20 +1401,24 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A_in) {
                     }
                     e -= per_side;
                 }
-                tail_apron_rows(A, blockIdx.z, e);
+                tail_apron_rows(A, side, e);
             } else {
-                tail_aprons_rgba8(A, blockIdx.z, e);
+                tail_aprons_rgba8(A, side, e);
             }
             return;
         }
+        const uint32_t id = plain ? blockIdx.x - total_e : xcd * chunk_m + (j - chunk_e);
+        if (id >= total_m) return;
+        side = id / per_side_m;
+        const uint32_t r = id - side * per_side_m;
+        block_y = r / nx;
+        block_x = r - block_y * nx;
     }
-    const uint32_t mosaic_row = blockIdx.y - (gridDim.y - ((1u << A.lod) * A.m.center_size + 63u) / 64u);
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
     const uint32_t tile_texels = T * T;
-    const uint32_t side = blockIdx.z;
     const uint32_t size = (1u << A.lod) * c;  // mosaic extent of the input LOD (a multiple of 4)
     const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
-    const uint32_t gx = blockIdx.x * 64u + 4u * tx, gy = mosaic_row * 64u + 4u * ty;  // first input pixel
+    const uint32_t gx = block_x * 64u + 4u * tx, gy = block_y * 64u + 4u * ty;  // first input pixel
     const bool active = gx < size && gy < size;
     // ONE division per axis: c is a multiple of 4, so the 4 x 4 block lies in one tile, and the tile / in-tile coordinates
     // of its pixel at LOD-k follow by shifts: tile >> k, ((tile & (2^k - 1)) * c + rem) >> k
@@ -2753,26 +2770,26 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
             fused_main_kernel<false, true, 0, 0><<<blocks, 256, sizeof(MainShared), p->ctx->stream>>>(job.args);
         }
     } else {
-        const uint32_t size = (1u << job.args.lod) * job.args.m.center_size;
-        dim3 grid((size + 63) / 64, (size + 63) / 64, job.args.sides);
+        const uint32_t size = (1u << job.args.lod) * job.args.m.center_size, nx = (size + 63) / 64;
         job.args.seam_tasks = p->tasks_dev + job.seam_first;  // ((re)allocated with the plan: patched at launch like the rasters)
+        uint64_t extras = 0;  // per side
         if (job.args.apron_lods) {
             const uint32_t blocks_per_tile = job.args.m.format == BT_FORMAT_R16
                 ? (job.args.m.border_size * job.args.m.texture_size + 255u) / 256u  // texel pairs of the 2b apron rows
                 : (2u * job.args.m.border_size * (job.args.m.texture_size + (job.args.apron_cols ? job.args.m.center_size : 0u)) + 255u) / 256u;
-            uint64_t extra = 0;
-            for (uint32_t k = 0; k < job.args.apron_lods; k++) extra += (1ull << (2 * (job.args.lod + k))) * blocks_per_tile;
-            // + the cross-face seam regions: the LAST ceil(seam_count / sides) extra workgroups of every side (whole grid rows in front of
-            // them may idle: the kernel counts from the end)
-            extra += (job.args.seam_count + job.args.sides - 1) / job.args.sides;
-            grid.y += uint32_t((extra + grid.x - 1) / grid.x);
+            for (uint32_t k = 0; k < job.args.apron_lods; k++) extras += (1ull << (2 * (job.args.lod + k))) * blocks_per_tile;
+            extras += (job.args.seam_count + job.args.sides - 1) / job.args.sides;  // + the cross-face seam regions, in front of them
         }
+        job.args.tail_extras = uint32_t(extras);
+        // a 1-D grid: XCD k (blockIdx.x % 8) takes the k-th eighth of the extras, then the k-th eighth of the mosaic (see the kernel)
+        const uint64_t total_m = uint64_t(job.args.sides) * nx * nx, total_e = uint64_t(job.args.sides) * extras;
+        const uint32_t blocks = uint32_t(8 * ((total_m + 7) / 8 + (total_e + 7) / 8));
         if (job.args.m.format == BT_FORMAT_R16) {
-            if (job.args.regular) fused_tail_kernel<BT_FORMAT_R16, true><<<grid, 256, 0, p->ctx->stream>>>(job.args);
-            else fused_tail_kernel<BT_FORMAT_R16, false><<<grid, 256, 0, p->ctx->stream>>>(job.args);
+            if (job.args.regular) fused_tail_kernel<BT_FORMAT_R16, true><<<blocks, 256, 0, p->ctx->stream>>>(job.args);
+            else fused_tail_kernel<BT_FORMAT_R16, false><<<blocks, 256, 0, p->ctx->stream>>>(job.args);
         } else {
-            if (job.args.regular) fused_tail_kernel<BT_FORMAT_RGBA8, true><<<grid, 256, 0, p->ctx->stream>>>(job.args);
-            else fused_tail_kernel<BT_FORMAT_RGBA8, false><<<grid, 256, 0, p->ctx->stream>>>(job.args);
+            if (job.args.regular) fused_tail_kernel<BT_FORMAT_RGBA8, true><<<blocks, 256, 0, p->ctx->stream>>>(job.args);
+            else fused_tail_kernel<BT_FORMAT_RGBA8, false><<<blocks, 256, 0, p->ctx->stream>>>(job.args);
         }
     }
     hipError_t e = hipGetLastError();
