@@ -1,5 +1,5 @@
 #!/bin/bash
-# fused_main under BT_FUSED_ABLATE masks (tools/bench_dbg.py, the debug build), all in ONE lease: tools/ablate_ab.sh 0 70 71 ...
+# fused_main under BT_FUSED_ABLATE masks (tools/bench_dbg.py, the debug build), all in ONE lease: tools/experiments/ablate_ab.sh 0 70 71 ...
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for round in 1 2; do for mask in "$@"; do echo -n "ablate $mask: "; BT_FUSED_ABLATE=$mask python $R/tools/bench_dbg.py --no-cpu-baseline --no-end-to-end --no-extras --steps 60 2>/dev/null | python -c "
 import json,sys

@@ -1,6 +1,6 @@
 // Round 3: settle the copy floor.  /opt/skills/guides/MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy; rounds 1-2
 // measured 5.1-5.5 TB/s on their leases with one kernel shape.  This sweep covers the shape space the guide's number could
-// come from, on THIS lease, with the clocks recorded next to it (tools/copy_floor3.sh dumps rocm-smi before and after):
+// come from, on THIS lease, with the clocks recorded next to it (tools/experiments/copy_floor3.sh dumps rocm-smi before and after):
 //   bytes   : 0.25 .. 8 GiB read (+ the same written)          -- 128 MiB and below sit in the Infinity Cache
 //   U       : 1 / 2 / 4 / 8 16-byte loads in flight per lane
 //   wg/CU   : 1 .. 16 resident 256-thread workgroups per CU (grid = 256 * k, grid-stride), and one-chunk-per-workgroup grids
@@ -8,7 +8,7 @@
 //   layout  : interleaved (consecutive workgroups touch consecutive 4 KiB pieces) or blocked (a contiguous range each)
 //   mix     : copy (1 : 1), read only, write only, and the 16k job's mix (3 reads : 4 writes)
 // Output: one line per configuration, TB/s counting bytes read + bytes written.
-// Build: hipcc --offload-arch=gfx950 -O3 -o tools/copy_floor3.out tools/copy_floor3.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/copy_floor3.out tools/experiments/copy_floor3.hip
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>

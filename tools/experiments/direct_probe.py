@@ -5,7 +5,7 @@ this tool runs config 2's albedo job (4096^2 Rgba8, 85 tiles) and prints the dis
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from bevy_terrain_amd import _ffi
 

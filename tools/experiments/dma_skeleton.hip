@@ -11,7 +11,7 @@
 // rows 8k .. 8k+9 of the tile's 1056-byte window (1024 main + 32 tail, the tail in its own LDS area because a DMA
 // instruction writes 64 lanes x 16 bytes contiguously); finest rows leave as one dword per lane, a quarter-size parent row
 // per two tile rows as a dword from every even lane.
-// Build: hipcc --offload-arch=gfx950 -O3 -o tools/dma_skeleton.out tools/dma_skeleton.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/experiments/dma_skeleton.out tools/experiments/dma_skeleton.hip
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>

@@ -1,7 +1,7 @@
 // Does a SIMD of gfx950 issue scalar instructions of one wave beside vector instructions of another, or one instruction per turn?
 // 1024 workgroups x 256 threads (4 waves per SIMD, every CU busy), each wave loops over 8 independent v_fma_f32 plus M scalar
 // instructions (s_add_u32 on private SGPRs / taken branches / s_nop): if scalar issue rides along, time is flat in M until M ~ 8.
-// Build: hipcc --offload-arch=gfx950 -O3 -o tools/issue_probe.out tools/issue_probe.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/issue_probe.out tools/experiments/issue_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -4,7 +4,7 @@ the order of its item list only decides which XCD (and which CU of it) streams w
 unit of time stay the same.  The profiling build (tools/libbevy_terrain_amd_dbg.so) takes an arbitrary order from a
 file (BT_FUSED_ORDER); this tool times fused_main under families of orders and re-measures the best ones.
 
-  python tools/order_search.py [--quick] [--out gpurun_out/order_search.json]
+  python tools/experiments/order_search.py [--quick] [--out gpurun_out/order_search.json]
 
 Order = permutation `perm` of the tile-row order (t = ty * 32 + tx): work position w runs tile perm[w]; XCD k runs the
 positions [128 k, 128 k + 128) in dispatch order (xcd_remap in bt_fused.hip)."""
@@ -16,7 +16,7 @@ import random
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from bevy_terrain_amd import _ffi
 

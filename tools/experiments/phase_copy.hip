@@ -5,7 +5,7 @@
 //   mode 0: free running (load a piece, store it)
 //   mode 1: phase locked: loads only while (t mod P) < Pr, stores only while (t mod P) >= Pr
 //   mode 2: the same windows, but every second workgroup shifted by Pr (its reads meet the others' writes): the control
-// Build: hipcc --offload-arch=gfx950 -O3 -o tools/phase_copy.out tools/phase_copy.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/phase_copy.out tools/experiments/phase_copy.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -4,7 +4,7 @@ side (so every trial gets other addresses), the 16k job timed on each; prints th
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch  # noqa: F401
 import bevy_terrain_amd as bt

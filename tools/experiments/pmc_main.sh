@@ -1,6 +1,6 @@
 #!/bin/bash
 # Extra counter passes for fused_main (one group per run, kernel trace only): issue activity, LDS, the vector-memory path.
-# tools/pmc_main.sh  (through gpurun, from the repo root) -> gpurun_out/pmc_main/<group>/
+# tools/experiments/pmc_main.sh  (through gpurun, from the repo root) -> gpurun_out/pmc_main/<group>/
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/pmc_main

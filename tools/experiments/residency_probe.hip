@@ -1,7 +1,7 @@
 // How many workgroups of a given shape does a CU of gfx950 hold at once?  (Round 4: a 320-thread workgroup — four shading waves +
 // one loader wave — at 96 VGPRs was expected to fit 4 x per CU (20 waves = 5 per SIMD) and did not.)
 // Every workgroup spins for a fixed time; 1024 workgroups on 256 CUs take (1024 / 256 / resident) x that time.
-// Build: hipcc --offload-arch=gfx950 -O3 -o tools/residency_probe.out tools/residency_probe.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/residency_probe.out tools/experiments/residency_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -1,6 +1,6 @@
 #!/bin/bash
 # the rocprofv3 --stats pass of tools/profile_round.sh N times (one process each): fused_main lands in one of two modes per process
-# (profiles/r03_fused_main_experiments.txt §11), so one run is not the kernel.  tools/stats_runs.sh <tag> [N]
+# (profiles/r03_fused_main_experiments.txt §11), so one run is not the kernel.  tools/experiments/stats_runs.sh <tag> [N]
 set -u
 TAG=${1:-r03}; N=${2:-3}
 R=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of bt_preprocessor_run_streamed on the 16k job (profiling build: BT_STREAM_TRACE=1 prints host stamps)."""
 import os, sys, time, tempfile, shutil
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from bevy_terrain_amd import _ffi
 _ffi.LIB_PATH = os.path.join(ROOT, "tools", "libbevy_terrain_amd_dbg.so")

@@ -5,7 +5,7 @@ at the end; this tool runs the headline job and prints each phase over the 1024 
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from bevy_terrain_amd import _ffi
 

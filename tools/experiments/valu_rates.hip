@@ -1,6 +1,6 @@
 // Issue cost of the VALU instructions the Rgba8 paths are made of (gfx950), relative to v_fma_f32: 8 independent chains per
 // wave, 4 waves per SIMD, every CU busy.  Also prints what v_cvt_pk_u8_f32 does with .5 cases (its rounding is not documented
-// in the guides at hand).  Build: hipcc --offload-arch=gfx950 -O3 -o tools/valu_rates.out tools/valu_rates.hip
+// in the guides at hand).  Build: hipcc --offload-arch=gfx950 -O3 -o tools/valu_rates.out tools/experiments/valu_rates.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -3,7 +3,7 @@
 //   fill_tiles : 1024 workgroups, each fills "its" 512 KB tile row by row (1 KB rows, 4 waves = 4 rows per step), lockstep
 //   fill_par   : the same workgroups write only a quarter-size parent tile (128 rows of 1 KB), one row per wave and step,
 //                or (shape 1) every wave writes a 256-byte quarter of each row — the shape fused_main uses
-// Build: hipcc --offload-arch=gfx950 -O3 -o tools/write_floor.out tools/write_floor.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/write_floor.out tools/experiments/write_floor.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
