@@ -157,7 +157,11 @@ def end_to_end(device, src_ptr):
     serial_digest = digest(root)
     streamed = None
     try:
-        streamed_pass(np.ascontiguousarray(host[:4096, :4096]), 4, root)  # warm the side streams / the saver thread's paths
+        warm_dir = tempfile.mkdtemp(prefix="bt_e2e_warm_", dir=parent)  # (its own directory: `root` keeps the serial pass's 1365 files for load_back)
+        try:
+            streamed_pass(np.ascontiguousarray(host[:4096, :4096]), 4, warm_dir)  # warm the side streams / the saver thread's paths
+        finally:
+            shutil.rmtree(warm_dir, ignore_errors=True)
         # every pass writes a FRESH directory, like a real preprocess run (rewriting the files of the pass before makes the file
         # system truncate 716 MB of pages inside the timed span: passes 3 - 5 of the first round-5 profile took 29 - 30 ms against 19.6 - 20 for
         # the first two); the directory of a pass is removed outside its span

@@ -970,7 +970,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         }
                         if constexpr (kDma) {
                             zq[quad] = min(uint32_t(zmin[quad].x), uint32_t(zmin[quad].y));
-                            if (zq[quad] == 0) {
+                            if (__builtin_expect(zq[quad] == 0, 0)) {
                                 // (rare) this thread read a no-data texel for the quad: per-pixel validity from the rows that are still
                                 // staged, the previous atlas value where a footprint has no data (split.wgsl:34-42) — in place, no redo
                                 u16x2 z[5];
@@ -1004,7 +1004,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             const f2 wq = quantise_quarter(sum);
                             q[2 * quad] = uint32_t(wq.x);
                             q[2 * quad + 1] = uint32_t(wq.y);
-                            if (kDma && zq[quad] == 0) {  // kept texels may be 0 (no data): the valid-average (downsample.wgsl:25-39)
+                            if (kDma && __builtin_expect(zq[quad] == 0, 0)) {  // kept texels may be 0 (no data): the valid-average (downsample.wgsl:25-39)
                                 q[2 * quad] = downsample4(ua[0], ua[1], ub[0], ub[1]);  // OFFSETS order
                                 q[2 * quad + 1] = downsample4(ua[2], ua[3], ub[2], ub[3]);
                             }
@@ -1054,7 +1054,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                 // a LOD-1 texel of the 2 x 2 block without data (0: only ever the result of a no-data quad): the valid-average
                                 const uint32_t m0 = even ? q[0] : q[2], m1 = even ? q[1] : q[3];                         // this lane's column
                                 const uint32_t p0 = (even ? both[0] : both[2]) >> 16, p1 = (even ? both[1] : both[3]) >> 16;  // the partner's
-                                if (min(min(m0, m1), min(p0, p1)) == 0) w3 = even ? downsample4(m0, m1, p0, p1) : downsample4(p0, p1, m0, m1);
+                                if (__builtin_expect(min(min(m0, m1), min(p0, p1)) == 0, 0)) w3 = even ? downsample4(m0, m1, p0, p1) : downsample4(p0, p1, m0, m1);
                             }
                             const uint32_t row3 = (b + cy3_first + (even ? 0u : 1u)) * T;
                             if (is_centre && !BT_ABLATE(A, 64u)) tile3[row3 + b + cx3] = uint16_t(w3);
