@@ -720,3 +720,41 @@ def test_ctx_trim_gives_back_the_kept_buffers(device, tmp_path):
         assert freed >= src.nbytes, freed  # the raster + three pinned buffers
         assert device.trim() == 0
     assert len(digests[0]) == 21 and digests[0] == digests[1]
+
+
+@pytest.mark.parametrize("W", [2048, 2200, 1016])
+def test_dma_variant_fixes_nodata_in_the_chunk_loop_incl_overlays(device, W):
+    """Round 5: the LDS-DMA variant of fused_main (T = 512, raster base and pitch 16-byte aligned) handles no-data where it meets it —
+    per-pixel validity from the rows still staged, the PREVIOUS atlas texel for pixels without data (split.wgsl:34-42), valid-averages
+    for the two parent LODs — instead of redoing flagged chunks behind the loop.  Two datasets over the same tiles: the first leaves
+    non-zero previous values, the second has single no-data texels, cell-shaped holes, a band that blanks whole 8-row chunks, holes on tile
+    edges (aprons are pulled through the neighbour's formula) and a hole in the first source rows.  Source / tile ratios: ~1 (the static
+    9-row path with the occasional skipped row), 1.08 (rows skip often: the table-driven path) and 0.5 (magnification)."""
+    T, b, lods = 512, 2, 3
+    rng = np.random.default_rng(W)
+    base = K.random_raster(O.FORMAT_R16, W, W, seed=W + 1, holes=0.01)
+    over = K.random_raster(O.FORMAT_R16, W, W, seed=W + 2)
+    over[rng.integers(0, W, 400), rng.integers(0, W, 400)] = 0              # single texels
+    for _ in range(40):                                                     # cells like the masked 16k job's
+        y, x = rng.integers(0, W - 40), rng.integers(0, W - 60)
+        over[y:y + 37, x:x + 53] = 0
+    over[W // 3:W // 3 + 30, :] = 0                                         # whole chunks without data
+    over[:, W // 2 - 3:W // 2 + 3] = 0                                      # across the x seam of the finest tiles (pulled aprons)
+    over[W // 2 - 2:W // 2 + 2, W // 5:W // 2] = 0                          # ... and along a y seam
+    over[0:3, 100:300] = 0                                                  # the clamped first rows
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=32, path="t", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=T, border_size=b))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer().insert("base", base).insert("over", over)
+    pre = bt.Preprocessor.new()
+    pre.preprocess_tile(bt.PreprocessDataset(path="base", lod_range=range(0, lods)), server, atlas).run(atlas)
+    oracle = O.OracleAtlas(lods, 32, False, [(T, b, 1, O.FORMAT_R16)])
+    oracle.preprocess_tile(0, base, (0, lods)).run(O.usable_cores())
+    assert K.assert_atlas_equal(atlas, oracle) == 21
+    pre.preprocess_tile(bt.PreprocessDataset(path="over", lod_range=range(0, lods)), server, atlas)
+    pre.run(atlas, keep_queue=True)
+    assert pre.stats()["fused_jobs"] == 1
+    oracle.preprocess_tile(0, over, (0, lods)).run(O.usable_cores())
+    assert K.assert_atlas_equal(atlas, oracle) == 21
+    pre.run(atlas)  # the same queue over its own output: every kept texel is now the value it already holds
+    assert K.assert_atlas_equal(atlas, oracle) == 21
