@@ -46,6 +46,14 @@ constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 #define BT_ABLATE(A, bits) 0u
 #endif
 constexpr uint32_t kMainRows = 8;                // centre rows per fused_main workgroup (multiple of 4)
+#ifndef BT_DMA_POS
+#define BT_DMA_POS 0
+#endif
+// Where a chunk issues the next chunk's LDS-DMA rows: 0 at its top (the product), 1 / 2 behind its first / second quad of rows, 10 + r behind
+// the LDS reads of output row r of the static path.  Round 5, same-lease product builds (profiles/r05_dma_issue_position.txt): behind the
+// first quad the clean 16k job is 0 .. 1.8 % faster (bimodal from run to run), behind rows 2 / 3 ~1 % faster with the masked job 2 % slower,
+// behind the second quad 3 % slower — inside the noise that matters, so the issue stays at the top.
+constexpr uint32_t kDmaPos = BT_DMA_POS;
 constexpr uint32_t kMaxBorder = 8;
 
 struct MainItem {  // one finest-LOD tile
@@ -860,7 +868,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             window(k + 1, next_ymin, next_slots);
             if constexpr (kDma) {
                 if (BT_ABLATE(A, 2048u)) __builtin_amdgcn_s_setprio(3);  // (2048: the DMA issue at top priority — timing experiment)
-                dma_issue(s_buf + ((k + 1) & 1u) * buf_texels, next_ymin, next_slots);
+                if (kDmaPos == 0) dma_issue(s_buf + ((k + 1) & 1u) * buf_texels, next_ymin, next_slots);
             }
             else if (kStaged && wide && !BT_ABLATE(A, 8u)) stage_issue(next_ymin, next_slots, pre);
         }
@@ -953,6 +961,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                 na = u16x2{pa0[(r + 2) * P], pb0[(r + 2) * P]};
                                 nb = u16x2{pa1[(r + 2) * P], pb1[(r + 2) * P]};
                             }
+                            if (kDma && kDmaPos == 10 + r && more) dma_issue(s_buf + ((k + 1) & 1u) * buf_texels, next_ymin, next_slots);
                             if constexpr (kDma) {
                                 const u16x2 zrow = __builtin_elementwise_min(ta, tb);
                                 zmin[quad] = __builtin_elementwise_min(zmin[quad], zrow);
@@ -998,6 +1007,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                 else dst5[(4 * quad + i) * (T / 2)] = ua[i] | (ub[i] << 16);
                             }
                         }
+                        if (kDma && kDmaPos == quad + 1 && more) dma_issue(s_buf + ((k + 1) & 1u) * buf_texels, next_ymin, next_slots);
                         if (do4) {
                             // two level-1 pixels (row pairs 0-1, 2-3 of the quad), one per packed lane: ((a0 + a1) + b0) + b1, / 4
                             const f2 sum = ((conv2(ua[0], ua[2]) + conv2(ua[1], ua[3])) + conv2(ub[0], ub[2])) + conv2(ub[1], ub[3]);
@@ -1128,6 +1138,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
 #pragma unroll
                         for (uint32_t i = 0; i < 4; i++) tile5_u32[((py + i) * T + px0) >> 1] = ua[i] | (ub[i] << 16);
                     }
+                    if (kDma && kDmaPos != 0 && q == ((kDmaPos == 1 || kDmaPos >= 10) ? 0u : (nrows > 4 ? 4u : 0u)) && more) dma_issue(s_buf + ((k + 1) & 1u) * buf_texels, next_ymin, next_slots);
                     if (do4) {
                         // two level-1 pixels (row pairs 0-1 and 2-3) in the two packed lanes: ((a0 + a1) + b0) + b1, then / 4
                         const f2 s = ((conv2(ua[0], ua[2]) + conv2(ua[1], ua[3])) + conv2(ub[0], ub[2])) + conv2(ub[1], ub[3]);
