@@ -383,11 +383,9 @@ struct MainShared {  // fixed part of the dynamic LDS block (size is a multiple 
     float2 row_fy[kMaxChunks * kMainRows];  // y weights (fy, 1 - fy): read by every lane at one address (a broadcast), used as they arrive
     int win_ymin[kMaxChunks];              // source window of a chunk: first row ...
     uint32_t win_slots[kMaxChunks];        // ... and row count; bit 31: the chunk's rows use source rows y, y+1, ..., y+kMainRows
-    uint32_t nodata[2][4];                 // [chunk parity][wave]: the staged window holds a no-data texel; kDma: [parity][0] = some thread of the chunk read one
     RowParam apron[2 * kMaxBorder];  // [0, b): top apron rows, [b, 2b): bottom apron rows (pad = mosaic row ry)
     int xmin, xmax;
-    uint32_t redo[2];  // fast variants: bit (k - k_begin) = chunk k saw a no-data texel and is redone by the generic rows after the run
-    uint32_t redo_waves[kMaxChunks / 8];  // ... and which of the workgroup's four waves saw it (4 bits per chunk): only those redo their columns
+    uint32_t pad_[2];  // (the dynamic LDS block behind this struct stays 16-byte aligned)
 };
 static_assert(sizeof(MainShared) % 16 == 0, "LDS carve must stay 16-byte aligned");
 
@@ -444,6 +442,7 @@ template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP, bool kDma = fal
 __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t item_index, uint32_t k_begin, uint32_t k_end, uint8_t* smem) {
     MainShared& S = *reinterpret_cast<MainShared*>(smem);
     uint16_t* s_buf = reinterpret_cast<uint16_t*>(smem + sizeof(MainShared));
+    constexpr bool kFix = kStaged && !kGeneric;  // the fast variants: no-data is detected per thread and quad of rows and fixed in place (round 5)
     const uint32_t buf_texels = A.lds_rows * (kP ? kP : A.lds_pitch);  // two staging buffers (chunk parity)
 
     // A workgroup is persistent over a run of row chunks (kMainRows centre rows each) of ONE finest tile:
@@ -525,7 +524,6 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     // atlas tile holding each column's pixels (keep-previous rule reads it when the source has no data)
     const uint32_t home_col = is_right && t5.e != kInvalid ? t5.e : (is_left && t5.w != kInvalid ? t5.w : t5.self);
 
-    if (tid < 2u + kMaxChunks / 8u) (tid < 2u ? S.redo[tid] : S.redo_waves[tid - 2u]) = 0;
     // the first left-apron pair reads the leftmost source column, the last right-apron pair the rightmost
     if (tid == half_c + half_b) S.xmin = min(axa.i0, axb.i0);
     if (tid == half_c + half_b - 1) S.xmax = max(axa.i1, axb.i1);
@@ -558,6 +556,9 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     const global_bytes data = (global_bytes)raster.data;  // loaded from memory: tell the compiler it is global
     const uint32_t chunks_per_row = P / 8u;
     const uint32_t row_texels = uint32_t(raster.pitch / 2u);  // addressable texels per source row
+    // (16-byte pieces: base and pitch 16-byte aligned — a row then ends on a piece boundary and no piece straddles it.  The library pads the
+    // rasters it uploads and copies a borrowed unaligned device raster once, bt_host.cpp add_raster: the texel-by-texel staging below is left
+    // for deferred host rasters of odd width)
     const bool wide = ((reinterpret_cast<uintptr_t>(raster.data) | raster.pitch) & 15u) == 0;
     constexpr uint32_t kBatch = 4;  // 16-byte loads per thread and chunk (host guarantees slots * pitch / 8 <= 256 * kBatch)
 
@@ -589,34 +590,22 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             v[i] = BT_ABLATE(A, 32768u) ? __builtin_nontemporal_load(ptr) : *ptr;  // (32768: streaming loads, timing experiment)
         }
     };
-    // registers -> LDS; returns this thread's "saw a no-data texel" bit
-    auto stage_commit = [&](uint16_t* s_src, uint32_t slots, const u32x4 (&v)[kBatch]) -> bool {
+    // registers -> LDS
+    auto stage_commit = [&](uint16_t* s_src, uint32_t slots, const u32x4 (&v)[kBatch]) {
         const uint32_t bound = slots * P * 2u;
         uint8_t* s_bytes = reinterpret_cast<uint8_t*>(s_src);
-        u16x2 zmin = {1, 1};
 #pragma unroll
-        for (uint32_t i = 0; i < kBatch; i++) {
+        for (uint32_t i = 0; i < kBatch; i++)
             if (lds_off[i] < bound) *reinterpret_cast<u32x4*>(s_bytes + lds_off[i]) = v[i];
-            // scalar copies first: a bit_cast applied directly to a vector element reads element 0 (seen in the ISA)
-            const uint32_t w0 = v[i].x, w1 = v[i].y, w2 = v[i].z, w3 = v[i].w;
-            const u16x2 m01 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, w0), __builtin_bit_cast(u16x2, w1));
-            const u16x2 m23 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, w2), __builtin_bit_cast(u16x2, w3));
-            zmin = __builtin_elementwise_min(zmin, __builtin_elementwise_min(m01, m23));
-        }
-        return zmin.x == 0 || zmin.y == 0;
     };
     // unaligned rasters (odd widths / pitches): texel by texel, no prefetch
-    auto stage_narrow = [&](uint16_t* s_src, int ymin, uint32_t slots) -> bool {
-        bool z = false;
+    auto stage_narrow = [&](uint16_t* s_src, int ymin, uint32_t slots) {
         for (uint32_t i = tid; i < slots * P; i += 256u) {
             const uint32_t slot = i / P, kk = i - slot * P;
             const uint32_t x = uint32_t(xa) + kk;
             const global_u16 row = (global_u16)(data + uint64_t(ymin + int(slot)) * raster.pitch);
-            const uint16_t t = x < raster.width ? row[x] : uint16_t(1);
-            s_src[i] = t;
-            z = z || t == 0;
+            s_src[i] = x < raster.width ? row[x] : uint16_t(1);
         }
-        return z;
     };
 
     // LDS-DMA staging of a window: wave w moves window rows w, w + 4, ...; a row is one 1 KB instruction (64 lanes x 16
@@ -690,43 +679,29 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     // ---- first chunk: stage synchronously
     int ymin = 0;
     uint32_t slots = 0;
-    bool nodata = !kStaged;
     u32x4 pre[kBatch];
     window(k_begin, ymin, slots);
     if constexpr (kDma) {
         dma_issue(s_buf + (k_begin & 1u) * buf_texels, ymin, slots);
-        nodata = false;
     } else if (kStaged && !BT_ABLATE(A, 8u)) {
         if (wide) {
             stage_issue(ymin, slots, pre);
-            nodata = stage_commit(s_buf + (k_begin & 1u) * buf_texels, slots, pre);
+            stage_commit(s_buf + (k_begin & 1u) * buf_texels, slots, pre);
         } else {
-            nodata = stage_narrow(s_buf + (k_begin & 1u) * buf_texels, ymin, slots);
+            stage_narrow(s_buf + (k_begin & 1u) * buf_texels, ymin, slots);
         }
     }
     // the tile's b x b apron corners (4 b^2 pixels by the general formula): evaluated while the first rows are on their way
     if constexpr (kStaged) {
         if (k_begin == 0) corner_pixels(A, item_index, tid, 256u);
     }
-    // block-wide OR of the threads' bits around ONE barrier: a wave writes its ballot into the slot of the chunk's
-    // parity, everybody reads the four slots after the barrier (the slot is rewritten two barriers later)
-    auto any_nodata = [&](bool mine, uint32_t parity) -> bool {
-        if constexpr (kDma) {  // a plain barrier behind the landing of this wave's DMA rows (and, one counter, its stores)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            return false;
-        }
-        if (BT_ABLATE(A, 16777216u)) {  // (16777216: the barrier without the no-data flag exchange — timing of the control path, clean inputs only)
-            __syncthreads();
-            return false;
-        }
-        const unsigned long long wave_bits = __ballot(mine);
-        if ((tid & 63u) == 0) S.nodata[parity][tid >> 6] = wave_bits != 0ull;
+    // the chunk barrier: the staged rows of the next chunk are visible behind it (kDma: behind the landing of this wave's DMA rows —
+    // and, one memory counter, of its stores).  No no-data flag travels any more: every fast variant fixes a no-data quad where it meets it.
+    auto chunk_barrier = [&]() {
+        if constexpr (kDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const uint32_t* f = S.nodata[parity];
-        return __builtin_amdgcn_readfirstlane(int(f[0] | f[1] | f[2] | f[3])) != 0;
     };
-    // ---- per-chunk pieces shared by the loop and by the redo of flagged chunks behind it
+    // ---- per-chunk pieces
     uint16_t* s_src = s_buf;  // staged rows of the chunk being shaded ...
     int cur_ymin = 0;         // ... and the source row of its first slot
     auto fetch_row = [&](int y) -> Texel4 {
@@ -737,10 +712,6 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             const global_u16 row = (global_u16)(data + uint64_t(y) * raster.pitch);
             return convert4(row[axa.i0], row[axa.i1], row[axb.i0], row[axb.i1]);
         }
-    };
-    auto flag_chunk = [&](uint32_t kk) {  // thread 0 only: the whole chunk, every wave
-        S.redo[(kk - k_begin) >> 5] |= 1u << ((kk - k_begin) & 31u);
-        S.redo_waves[(kk - k_begin) >> 3] |= 0xFu << (((kk - k_begin) & 7u) * 4u);
     };
     // apron rows (first / last chunk of a tile only): the centre columns are rows like any other (the north / south
     // neighbour's centre rows, or clamped into the own centre); the b x b corners follow the diagonal neighbour alone
@@ -851,7 +822,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         }
     };
 
-    bool has_nodata = any_nodata(nodata, k_begin & 1u);
+    chunk_barrier();
     wg_stamp(1);
 
     for (uint32_t k = k_begin; k < k_end; k++) {
@@ -892,18 +863,14 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
 #include "bt_fused_debug.inc"  // (per-chunk time stamps, rotating wave priorities: timing experiments)
 #undef BT_FUSED_DEBUG_CHUNK_PROBES
 #endif
-        // a chunk with no-data goes to the generic rows as a whole
-        const bool skip_chunk = !kGeneric && has_nodata;
-        if (skip_chunk && tid == 0) flag_chunk(k);
-
-        if (!skip_chunk) apron_rows(k, std::integral_constant<bool, kGeneric || kDma>{});  // (kDma: no-data is handled where it is met, inside the loop)
+        apron_rows(k, std::integral_constant<bool, true>{});  // (every variant handles no-data where it is met: the keep-previous form)
 
 #ifdef BT_DEBUG_HOOKS
 #define BT_FUSED_DEBUG_SKELETON_STORES
 #include "bt_fused_debug.inc"  // (memory-skeleton store shapes of the profiling build)
 #undef BT_FUSED_DEBUG_SKELETON_STORES
 #endif
-        if (!BT_ABLATE(A, 16u) && !skip_chunk) {
+        if (!BT_ABLATE(A, 16u)) {
             if constexpr (kStaged && !kGeneric) {
                 typedef float f2 __attribute__((ext_vector_type(2)));
                 const f2 gx = {gxa, gxb}, fx = {fxa, fxb};
@@ -945,7 +912,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                     auto conv2p = [&](u16x2 t) -> f2 { return conv2(t.x, t.y); };
                     f2 hprev = conv2p(ta) * gx + conv2p(tb) * fx;
                     uint32_t q[4];
-                    // kDma: smallest raw texel this thread read for the rows of a quad (source rows 4 * quad .. 4 * quad + 4), per column pair half
+                    // smallest raw texel this thread read for the rows of a quad (source rows 4 * quad .. 4 * quad + 4), per column pair half
                     u16x2 zmin[2] = {__builtin_elementwise_min(ta, tb), u16x2{0xFFFFu, 0xFFFFu}};
                     uint32_t zq[2] = {1u, 1u};
                     uint32_t* dst5 = tile5_u32 + (((b + cr0) * T + px0) >> 1);
@@ -962,7 +929,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                 nb = u16x2{pa1[(r + 2) * P], pb1[(r + 2) * P]};
                             }
                             if (kDma && kDmaPos == 10 + r && more) dma_issue(s_buf + ((k + 1) & 1u) * buf_texels, next_ymin, next_slots);
-                            if constexpr (kDma) {
+                            if constexpr (kFix) {
                                 const u16x2 zrow = __builtin_elementwise_min(ta, tb);
                                 zmin[quad] = __builtin_elementwise_min(zmin[quad], zrow);
                                 if (quad == 0 && i == 3) zmin[1] = zrow;  // source row 4 feeds both quads
@@ -977,7 +944,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             ua[i] = uint32_t(w.x);
                             ub[i] = uint32_t(w.y);
                         }
-                        if constexpr (kDma) {
+                        if constexpr (kFix) {
                             zq[quad] = min(uint32_t(zmin[quad].x), uint32_t(zmin[quad].y));
                             if (__builtin_expect(zq[quad] == 0, 0)) {
                                 // (rare) this thread read a no-data texel for the quad: per-pixel validity from the rows that are still
@@ -1014,7 +981,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             const f2 wq = quantise_quarter(sum);
                             q[2 * quad] = uint32_t(wq.x);
                             q[2 * quad + 1] = uint32_t(wq.y);
-                            if (kDma && __builtin_expect(zq[quad] == 0, 0)) {  // kept texels may be 0 (no data): the valid-average (downsample.wgsl:25-39)
+                            if (kFix && __builtin_expect(zq[quad] == 0, 0)) {  // kept texels may be 0 (no data): the valid-average (downsample.wgsl:25-39)
                                 q[2 * quad] = downsample4(ua[0], ua[1], ub[0], ub[1]);  // OFFSETS order
                                 q[2 * quad + 1] = downsample4(ua[2], ua[3], ub[2], ub[3]);
                             }
@@ -1060,7 +1027,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             const float sa = even ? colsum.x : recv1, sb = even ? recv1 : c02.y, sc = even ? recv2 : c13.y;
                             const float s3 = (sa + sb) + sc;
                             uint32_t w3 = uint32_t(0.5f + (0.25f * (65535.0f / 65536.0f)) * s3);  // scaled domain, see quantise_quarter; the clamp is a no-op here
-                            if constexpr (kDma) {
+                            if constexpr (kFix) {
                                 // a LOD-1 texel of the 2 x 2 block without data (0: only ever the result of a no-data quad): the valid-average
                                 const uint32_t m0 = even ? q[0] : q[2], m1 = even ? q[1] : q[3];                         // this lane's column
                                 const uint32_t p0 = (even ? both[0] : both[2]) >> 16, p1 = (even ? both[1] : both[3]) >> 16;  // the partner's
@@ -1077,11 +1044,11 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         }
                     }
                 } else {
-                uint32_t zrow = 1;  // kDma: smallest raw texel of the row hblend converted last
+                uint32_t zrow = 1;  // smallest raw texel of the row hblend converted last
                 auto hblend = [&](int y) -> f2 {  // (mix(t00, t10, fx) for column a, same for column b) of source row y
                     const uint16_t* row = s_src + uint32_t(y - cur_ymin) * P;
                     const uint32_t r0 = row[la0], r1 = row[lb0], r2 = row[la1], r3 = row[lb1];
-                    if constexpr (kDma) zrow = min(min(r0, r1), min(r2, r3));
+                    if constexpr (kFix) zrow = min(min(r0, r1), min(r2, r3));
                     const f2 left = conv2(r0, r1), right = conv2(r2, r3);
                     return left * gx + right * fx;
                 };
@@ -1117,7 +1084,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         ua[i] = uint32_t(w.x);
                         ub[i] = uint32_t(w.y);
                     }
-                    const bool fix = kDma && zq == 0;
+                    const bool fix = kFix && zq == 0;
                     if (fix) {
                         // (rare) this thread read a no-data texel for the quad: per-pixel validity from the staged rows, the previous
                         // atlas value where a footprint has no data (split.wgsl:34-42) — in place, like the static path above
@@ -1165,7 +1132,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                 const float s3 = ((mine.x + mine.y) + theirs.x) + theirs.y;
                                 uint32_t w3 = uint32_t(0.5f + (0.25f * (65535.0f / 65536.0f)) * s3);  // scaled domain (conv2)
                                 // a LOD-1 texel of the block without data (0: only ever the result of a no-data quad): the valid-average
-                                if (kDma && min(min(q0, q1), min(other0, other1)) == 0) w3 = downsample4(q0, q1, other0, other1);
+                                if (kFix && min(min(q0, q1), min(other0, other1)) == 0) w3 = downsample4(q0, q1, other0, other1);
                                 const uint32_t cy3 = cy3_base + (cy >> 2);
                                 tile3[(b + cy3) * T + b + cx3] = uint16_t(w3);
                                 if (x3_count) xpush3(cy3, uint16_t(w3));
@@ -1182,46 +1149,16 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         if (!more) break;
         // chunk k + 1 goes into the other staging buffer (nobody reads it any more: its last readers passed the
         // previous barrier), the row table of chunk k + 3 replaces the one of chunk k after the barrier
-        nodata = !kStaged;
         if (kStaged && !kDma && !BT_ABLATE(A, 8u)) {
             uint16_t* s_next = s_buf + ((k + 1) & 1u) * buf_texels;
-            nodata = wide ? stage_commit(s_next, next_slots, pre) : stage_narrow(s_next, next_ymin, next_slots);
+            if (wide) stage_commit(s_next, next_slots, pre);
+            else stage_narrow(s_next, next_ymin, next_slots);
         }
         ymin = next_ymin;
         slots = next_slots;
-        has_nodata = any_nodata(nodata, (k + 1) & 1u);
+        chunk_barrier();
     }
     wg_stamp(2);
-    if constexpr (kStaged && !kGeneric && !kDma) {  // (kDma handles no-data where it meets it, inside the loop: fix)
-        // ---- redo of the flagged chunks with the generic rows: stage the window once more (nobody reads LDS any more), run the
-        // apron rows and the rows with validity.  Clean inputs pay one barrier and one LDS read per tile.
-        __syncthreads();
-        const uint32_t redo0 = uint32_t(__builtin_amdgcn_readfirstlane(int(S.redo[0]))), redo1 = uint32_t(__builtin_amdgcn_readfirstlane(int(S.redo[1])));
-        if (redo0 | redo1) {
-#pragma unroll 1
-            for (uint32_t k = k_begin; k < k_end; k++) {
-                if (!(((k - k_begin) < 32u ? redo0 >> (k - k_begin) : redo1 >> (k - k_begin - 32u)) & 1u)) continue;
-                window(k, ymin, slots);
-                if (wide) {
-                    stage_issue(ymin, slots, pre);
-                    stage_commit(s_buf, slots, pre);
-                } else {
-                    stage_narrow(s_buf, ymin, slots);
-                }
-                __syncthreads();
-                s_src = s_buf;
-                cur_ymin = ymin;
-                // a wave whose lanes all read clean texels stored its columns of this chunk (finest rows, parents, pushes) in the fast
-                // pass — every reduction of the pyramid stays inside a lane pair — and has nothing to redo
-                const uint32_t waves = uint32_t(__builtin_amdgcn_readfirstlane(int(S.redo_waves[(k - k_begin) >> 3]))) >> (((k - k_begin) & 7u) * 4u);
-                if (((waves >> uint32_t(__builtin_amdgcn_readfirstlane(int(tid >> 6)))) & 1u) && !BT_ABLATE(A, 131072u)) {  // (131072: the redo stages but computes nothing — timing experiment)
-                    apron_rows(k, std::true_type{});
-                    generic_rows(k);
-                }
-                __syncthreads();  // the next flagged chunk overwrites the staged rows
-            }
-        }
-    }
 #ifdef BT_DEBUG_HOOKS
     if (BT_ABLATE(A, 134217728u) && tid == 0)
         reinterpret_cast<unsigned long long*>(A.atlas + uint64_t(A.m.atlas_size - 1u) * tile_texels)[item_index * 8u + 4u] = __builtin_amdgcn_s_memrealtime();

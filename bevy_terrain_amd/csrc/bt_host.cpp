@@ -1255,26 +1255,49 @@ bt_status add_raster(bt_preprocessor* p, const bt_atlas* a, uint32_t ai, const b
         set_error("bt_raster.on_device = %u", src->on_device);
         return BT_ERR_INVALID_ARGUMENT;
     }
-    if (src->on_device != 1u) {
-        void* dev = nullptr;
-        BT_HIP(hipSetDevice(p->ctx->device));
-        // the caller's buffer ends with the last texel of the last row, not with a whole pitch
-        const uint64_t bytes = pitch * (src->height - 1) + uint64_t(src->width) * px;
-        if (p->ctx->spare_raster && p->ctx->spare_raster_bytes >= pitch * src->height) {  // the buffer the previous queue released
-            dev = p->ctx->spare_raster;
+    // fused_main moves the source in 16-byte pieces (LDS-DMA, or 16-byte register loads): base and pitch must be multiples of 16 bytes, else
+    // it stages texel by texel — a 16380-texel-wide R16 raster ran 3 x slower than the 16384-wide one (0.81 vs 0.27 ms).  So the library pads
+    // what it uploads itself, and copies a BORROWED device raster whose base or pitch is not 16-byte aligned into a padded buffer of its own
+    // (0.5 GB: 0.15 ms) when the queue first runs — the caller's memory is read then, as before.  Deferred host rasters keep the caller's pitch
+    // (their bands travel as plain 1-D copies).
+    const uint64_t row_bytes = uint64_t(src->width) * px, padded_pitch = (row_bytes + 15u) & ~uint64_t(15);
+    const bool r16 = fmt == BT_FORMAT_R16;
+    auto take_buffer = [&](uint64_t need, void** dev) -> bt_status {
+        if (p->ctx->spare_raster && p->ctx->spare_raster_bytes >= need) {  // the buffer the previous queue released
+            *dev = p->ctx->spare_raster;
             p->ctx->spare_raster = nullptr;
             r.alloc_bytes = p->ctx->spare_raster_bytes;
             p->ctx->spare_raster_bytes = 0;
         } else {
-            BT_HIP(hipMalloc(&dev, pitch * src->height));
-            r.alloc_bytes = pitch * src->height;
+            BT_HIP(hipMalloc(dev, need));
+            r.alloc_bytes = need;
         }
+        return BT_OK;
+    };
+    if (src->on_device == 1u && r16 && ((reinterpret_cast<uintptr_t>(src->data) | pitch) & 15u) != 0) {
+        void* dev = nullptr;
+        BT_HIP(hipSetDevice(p->ctx->device));
+        if (bt_status st = take_buffer(padded_pitch * src->height, &dev)) return st;
+        r.dev_src = src->data;  // copied (device to device, row by row) by the first run of the queue
+        r.dev_src_pitch = pitch;
+        r.pending = true;
+        r.dev = {dev, src->width, src->height, padded_pitch};
+        r.owned = true;
+    } else if (src->on_device != 1u) {
+        void* dev = nullptr;
+        BT_HIP(hipSetDevice(p->ctx->device));
+        // the caller's buffer ends with the last texel of the last row, not with a whole pitch
+        const uint64_t bytes = pitch * (src->height - 1) + row_bytes;
+        const bool pad = src->on_device == 0u && r16 && (pitch & 15u) != 0;
+        const uint64_t dev_pitch = pad ? padded_pitch : pitch;
+        if (bt_status st = take_buffer(dev_pitch * src->height, &dev)) return st;
         if (src->on_device == BT_RASTER_HOST_DEFERRED) {  // copied when the queue runs; the caller keeps the rows alive until then
             r.host = src->data;
             r.host_bytes = bytes;
             r.pending = true;
         } else {
-            hipError_t e = hipMemcpyAsync(dev, src->data, bytes, hipMemcpyHostToDevice, p->ctx->stream);
+            hipError_t e = pad ? hipMemcpy2DAsync(dev, dev_pitch, src->data, pitch, row_bytes, src->height, hipMemcpyHostToDevice, p->ctx->stream)
+                               : hipMemcpyAsync(dev, src->data, bytes, hipMemcpyHostToDevice, p->ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
             if (e != hipSuccess) {
                 hipFree(dev);
@@ -1282,6 +1305,7 @@ bt_status add_raster(bt_preprocessor* p, const bt_atlas* a, uint32_t ai, const b
             }
         }
         r.dev.data = dev;
+        r.dev.pitch = dev_pitch;
         r.owned = true;
     }
     *index = int32_t(p->rasters.size());
@@ -1485,6 +1509,14 @@ bool fused_source_window(const bt_preprocessor* p, uint32_t raster, uint32_t out
 bt_status upload_pending_rasters(bt_preprocessor* p) {
     for (size_t i = 0; i < p->rasters.size(); i++) {
         Raster& r = p->rasters[i];
+        if (r.dev_src) {  // a borrowed, unaligned device raster: its padded copy is made when the queue first runs
+            if (r.pending) {
+                const uint64_t px2 = r.format == BT_FORMAT_R16 ? 2 : 4;
+                BT_HIP(hipMemcpy2DAsync((void*)r.dev.data, r.dev.pitch, r.dev_src, r.dev_src_pitch, uint64_t(r.dev.width) * px2, r.dev.height, hipMemcpyDeviceToDevice, p->ctx->stream));
+                r.pending = false;
+            }
+            continue;
+        }
         if (!r.host) continue;  // not a deferred raster
         uint32_t w[4] = {0u, 0u, r.dev.width, r.dev.height};
         const uint64_t px = r.format == BT_FORMAT_R16 ? 2 : 4;
@@ -1556,7 +1588,7 @@ bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* a, const ch
     bool streamable = !p->plan.empty() && fused_stream_bands(p, p->plan[0], rows_per_band, &raster, &bands) && bands.size() > 1;
     uint32_t pending = 0;
     for (const Raster& r : p->rasters) pending += r.pending;
-    streamable = streamable && pending == 1 && p->rasters[size_t(raster)].pending;
+    streamable = streamable && pending == 1 && p->rasters[size_t(raster)].pending && p->rasters[size_t(raster)].host != nullptr;
     for (size_t i = 1; streamable && i < p->plan.size(); i++) streamable = p->plan[i].kind != kLaunchFusedMain && p->plan[i].kind != kLaunchFusedDirect;
     if (!p->saves_recorded) {
         for (const Task& t : p->queue)

@@ -122,6 +122,8 @@ struct Raster {
     const void* host = nullptr;
     uint64_t host_bytes = 0;
     bool pending = false;
+    const void* dev_src = nullptr;  // a borrowed device raster that is not 16-byte aligned: copied into the padded buffer `dev` by the first run
+    uint64_t dev_src_pitch = 0;
     uint32_t uploaded[4] = {0, 0, 0, 0};  // the window {x0, y0, x1, y1} of the deferred raster that has travelled (a sharded run: this rank's)
     uint64_t alloc_bytes = 0;  // size of the owned device allocation
 };

@@ -101,7 +101,9 @@ typedef struct bt_raster {
     uint64_t row_pitch;  /* bytes; 0 = tightly packed */
     uint32_t format;     /* BT_FORMAT_R16 or BT_FORMAT_RGBA8; must equal the attachment's */
     uint32_t on_device;  /* 0: host memory (copied to the GPU by the call), 1: device pointer (borrowed
-                            until the preprocessor has run), BT_RASTER_HOST_DEFERRED: host memory that stays the
+                            until the preprocessor has run; an R16 raster whose base or pitch is not a multiple of 16 bytes
+                            is copied into a padded buffer by the queue's FIRST run — a kept queue does not see later
+                            changes of it), BT_RASTER_HOST_DEFERRED: host memory that stays the
                             caller's until the queue has run — copied by bt_preprocessor_run (all at once) or by
                             bt_preprocessor_run_streamed (band by band, beside the kernels and the downloads).  A queue kept
                             with BT_RUN_KEEP_QUEUE may read the rows again (only the window a sharded rank needs travels;

@@ -758,3 +758,36 @@ def test_dma_variant_fixes_nodata_in_the_chunk_loop_incl_overlays(device, W):
     assert K.assert_atlas_equal(atlas, oracle) == 21
     pre.run(atlas)  # the same queue over its own output: every kept texel is now the value it already holds
     assert K.assert_atlas_equal(atlas, oracle) == 21
+
+
+@pytest.mark.parametrize("W", [1100, 1101, 1104])
+def test_unaligned_rasters_are_padded_for_the_16_byte_staging(device, W):
+    """Round 5: fused_main moves the source in 16-byte pieces, which needs base and pitch 16-byte aligned.  A host raster the library uploads
+    is padded on the way (W = 1100: pitch 2200 -> 2208); a BORROWED device raster with such a pitch is copied into a padded buffer by the
+    queue's first run (the caller's memory is read then, not at preprocess_tile); an odd width (1101: pitch 2202) pads the same way; 1104 needs
+    nothing.  All against the oracle, with no-data, through the fused plan at T = 512; a kept queue runs again from the copy."""
+    T, b, lods = 512, 2, 2
+    src = K.random_raster(O.FORMAT_R16, 1000, W, seed=W, holes=0.02)
+    oracle = K.oracle_planar(src, lods, T, b, O.FORMAT_R16, atlas_size=16)
+    for on_device in (False, True):
+        cfg = bt.TerrainConfig(lod_count=lods, atlas_size=16, path="t", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+        cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=T, border_size=b))
+        atlas = bt.TileAtlas.new(cfg, device)
+        ptr = None
+        if on_device:
+            ptr = device.upload(np.zeros_like(src))  # tightly packed rows: pitch = 2 W; filled only AFTER the raster has been handed over
+            server = bt.AssetServer().insert("s", (ptr, W, 1000))
+        else:
+            server = bt.AssetServer().insert("s", src)
+        pre = bt.Preprocessor.new().preprocess_tile(bt.PreprocessDataset(path="s", lod_range=range(0, lods)), server, atlas)
+        if on_device:
+            import ctypes
+            bt._ffi.check(bt._ffi.lib().bt_memcpy_h2d(device._h, ctypes.c_void_p(ptr), src.ctypes.data_as(ctypes.c_void_p), src.nbytes))
+            device.synchronize()
+        pre.run(atlas, keep_queue=True)
+        assert pre.stats()["fused_jobs"] == 1
+        assert K.assert_atlas_equal(atlas, oracle) == 5, on_device
+        pre.run(atlas)
+        assert K.assert_atlas_equal(atlas, oracle) == 5, on_device
+        if ptr is not None:
+            device.free(ptr)
