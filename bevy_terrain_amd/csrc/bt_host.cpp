@@ -1288,12 +1288,13 @@ bt_status add_raster(bt_preprocessor* p, const bt_atlas* a, uint32_t ai, const b
         BT_HIP(hipSetDevice(p->ctx->device));
         // the caller's buffer ends with the last texel of the last row, not with a whole pitch
         const uint64_t bytes = pitch * (src->height - 1) + row_bytes;
-        const bool pad = src->on_device == 0u && r16 && (pitch & 15u) != 0;
+        const bool pad = r16 && (pitch & 15u) != 0;  // (deferred rasters too: their windows / bands then travel as pitched copies)
         const uint64_t dev_pitch = pad ? padded_pitch : pitch;
         if (bt_status st = take_buffer(dev_pitch * src->height, &dev)) return st;
         if (src->on_device == BT_RASTER_HOST_DEFERRED) {  // copied when the queue runs; the caller keeps the rows alive until then
             r.host = src->data;
             r.host_bytes = bytes;
+            r.host_pitch = pitch;
             r.pending = true;
         } else {
             hipError_t e = pad ? hipMemcpy2DAsync(dev, dev_pitch, src->data, pitch, row_bytes, src->height, hipMemcpyHostToDevice, p->ctx->stream)
@@ -1531,12 +1532,12 @@ bt_status upload_pending_rasters(bt_preprocessor* p) {
         if (!r.pending && covered) continue;
         p->uploaded_source_bytes = 0;
         if (!empty && !covered) {
-            if (w[0] == 0 && w[1] == 0 && w[2] == r.dev.width && w[3] == r.dev.height) {
+            if (w[0] == 0 && w[1] == 0 && w[2] == r.dev.width && w[3] == r.dev.height && r.host_pitch == r.dev.pitch) {
                 BT_HIP(hipMemcpyAsync((void*)r.dev.data, r.host, r.host_bytes, hipMemcpyHostToDevice, p->ctx->stream));
                 p->uploaded_source_bytes = r.host_bytes;
-            } else {
-                const uint64_t off = uint64_t(w[1]) * r.dev.pitch + uint64_t(w[0]) * px;
-                BT_HIP(hipMemcpy2DAsync((uint8_t*)r.dev.data + off, r.dev.pitch, (const uint8_t*)r.host + off, r.dev.pitch, (w[2] - w[0]) * px, w[3] - w[1],
+            } else {  // a window, or a padded device copy: pitched
+                const uint64_t off_dev = uint64_t(w[1]) * r.dev.pitch + uint64_t(w[0]) * px, off_host = uint64_t(w[1]) * r.host_pitch + uint64_t(w[0]) * px;
+                BT_HIP(hipMemcpy2DAsync((uint8_t*)r.dev.data + off_dev, r.dev.pitch, (const uint8_t*)r.host + off_host, r.host_pitch, (w[2] - w[0]) * px, w[3] - w[1],
                                         hipMemcpyHostToDevice, p->ctx->stream));
                 p->uploaded_source_bytes = uint64_t(w[2] - w[0]) * px * (w[3] - w[1]);
             }
@@ -1684,9 +1685,17 @@ bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* a, const ch
     for (size_t k = 0; k < nb && rc == BT_OK; k++) {
         const uint64_t end_row = k + 1 == nb ? r.dev.height : bands[k].source_row_end;
         if (end_row > done_rows) {
-            const uint64_t off = done_rows * r.dev.pitch, end = std::min<uint64_t>(r.host_bytes, end_row * r.dev.pitch);
             stamp("upload begin", k);
-            if (hipMemcpyAsync(dev + off, host + off, end - off, hipMemcpyHostToDevice, p->ctx->copy_stream) != hipSuccess) rc = BT_ERR_DEVICE;
+            hipError_t ce;
+            if (r.host_pitch == r.dev.pitch) {
+                const uint64_t off = done_rows * r.dev.pitch, end = std::min<uint64_t>(r.host_bytes, end_row * r.dev.pitch);
+                ce = hipMemcpyAsync(dev + off, host + off, end - off, hipMemcpyHostToDevice, p->ctx->copy_stream);
+            } else {  // a padded device copy (the caller's rows are not 16-byte aligned): the band as a pitched copy
+                const uint64_t row_bytes = uint64_t(r.dev.width) * (r.format == BT_FORMAT_R16 ? 2 : 4);
+                ce = hipMemcpy2DAsync(dev + done_rows * r.dev.pitch, r.dev.pitch, host + done_rows * r.host_pitch, r.host_pitch, row_bytes, end_row - done_rows,
+                                      hipMemcpyHostToDevice, p->ctx->copy_stream);
+            }
+            if (ce != hipSuccess) rc = BT_ERR_DEVICE;
             stamp("upload call returned", k);
             done_rows = end_row;
         }

@@ -121,6 +121,7 @@ struct Raster {
     // (all at once by bt_preprocessor_run, band by band next to the kernels by bt_preprocessor_run_streamed)
     const void* host = nullptr;
     uint64_t host_bytes = 0;
+    uint64_t host_pitch = 0;  // the caller's row pitch (the device copy's may be padded to 16 bytes)
     bool pending = false;
     const void* dev_src = nullptr;  // a borrowed device raster that is not 16-byte aligned: copied into the padded buffer `dev` by the first run
     uint64_t dev_src_pitch = 0;

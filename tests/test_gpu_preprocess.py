@@ -791,3 +791,32 @@ def test_unaligned_rasters_are_padded_for_the_16_byte_staging(device, W):
         assert K.assert_atlas_equal(atlas, oracle) == 5, on_device
         if ptr is not None:
             device.free(ptr)
+
+
+def test_streamed_run_pads_a_deferred_raster_of_unaligned_pitch(device, tmp_path):
+    """A deferred host raster whose rows are not 16-byte aligned (4100 texels: pitch 8200) gets a padded device copy too: its bands travel
+    as pitched copies, fused_main stages it by LDS-DMA, and the streamed run's files equal the serial run's and the oracle's tiles."""
+    W, lods = 4100, 4
+    src = K.random_raster(O.FORMAT_R16, W, W, seed=12, holes=0.01)
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=128, path="terrains/streamed_u", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=512, border_size=2, format=bt.AttachmentFormat.R16))
+    roots = []
+    for streamed in (False, True):
+        root = str(tmp_path / ("streamed" if streamed else "serial"))
+        atlas = bt.TileAtlas.new(cfg, device)
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas, root)
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="src", lod_range=range(0, lods)), bt.AssetServer().insert("src", src), atlas,
+                            defer_upload=streamed)
+        if streamed:
+            st = pre.run_streamed(atlas, root)
+            assert st["streamed"] and st["bands"] == 2
+        else:
+            pre.run(atlas)
+            pre.save(atlas, root)
+        roots.append((root, atlas))
+    d0, d1 = (a.attachment_directory(r, 0) for r, a in roots)
+    names = sorted(os.listdir(d0))
+    assert names == sorted(os.listdir(d1)) and len(names) == 85
+    for n in names:
+        assert open(os.path.join(d0, n), "rb").read() == open(os.path.join(d1, n), "rb").read(), n
+    assert K.assert_atlas_equal(roots[1][1], K.oracle_planar(src, lods, 512, 2, O.FORMAT_R16, atlas_size=128)) == 85
