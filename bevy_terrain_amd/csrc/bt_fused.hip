@@ -49,6 +49,7 @@ constexpr uint32_t kMainRows = 8;                // centre rows per fused_main w
 #ifndef BT_DMA_POS
 #define BT_DMA_POS 0
 #endif
+
 // Where a chunk issues the next chunk's LDS-DMA rows: 0 at its top (the product), 1 / 2 behind its first / second quad of rows, 10 + r behind
 // the LDS reads of output row r of the static path.  Round 5, same-lease product builds (profiles/r05_dma_issue_position.txt): behind the
 // first quad the clean 16k job is 0 .. 1.8 % faster (bimodal from run to run), behind rows 2 / 3 ~1 % faster with the masked job 2 % slower,
@@ -1401,8 +1402,9 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A_in) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 if constexpr (kR16) {  // 4-byte aligned (b even)
-                    t[r][0] = *reinterpret_cast<const uint32_t*>(p + r * T);
-                    t[r][1] = *reinterpret_cast<const uint32_t*>(p + r * T + 2);
+                    const uint2 w = *reinterpret_cast<const uint2 __attribute__((aligned(4)))*>(p + r * T);  // one 8-byte load from a dword-aligned address
+                    t[r][0] = w.x;
+                    t[r][1] = w.y;
                 } else {  // 8-byte aligned (b even or not: (b + 4k) texels of 4 bytes; pairs need b even) — two texels per load
                     if ((b & 1u) == 0) {
                         const uint2 lo = *reinterpret_cast<const uint2*>(p + r * T), hi = *reinterpret_cast<const uint2*>(p + r * T + 2);
