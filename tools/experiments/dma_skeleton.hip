@@ -407,6 +407,60 @@ template <int ARITH, int POLICY> __global__ __launch_bounds__(256) void vdram(co
     }
 }
 
+// ------------------------------------------------------------------------------------------------ round 5: strided chunks
+// PARTS workgroups per tile, workgroup j shades the chunks j, j + PARTS, ...: the PARTS workgroups of a tile (dispatched back to back on one
+// XCD) then write PARTS consecutive 8 KB pieces of the tile and read PARTS x 8 consecutive source rows at any moment — longer DRAM bursts,
+// a quarter of the tiles in flight — at the price of PARTS generations of workgroups.  Ring: three chunks x 10 rows, two chunks ahead.
+template <int ARITH, uint32_t PARTS> __global__ __launch_bounds__(256) void vstride(const uint8_t* src, uint8_t* tiles, uint8_t* parents) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[30 * (kRowMain + kRowTail)];
+    constexpr uint32_t kTail30 = 30 * kRowMain, kChunks = 64 / PARTS;
+    const uint32_t q = gridDim.x / 8, work = (blockIdx.x % 8) * q + blockIdx.x / 8;
+    const uint32_t tile = work / PARTS, part = work % PARTS, ty = tile / 32, tx = tile % 32;
+    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63u;
+    const gbytes base = (gbytes)src + uint64_t(ty) * 512 * kPitch + uint64_t(tx) * 1024;
+    const lbytes ring = (lbytes)lds;
+    auto dma_chunk = [&](uint32_t i) {  // chunk i of this workgroup = tile chunk part + i * PARTS: source rows 8 k .. 8 k + 9 into slot i % 3
+        const uint32_t k = part + i * PARTS, slot0 = (i % 3u) * 10u;
+        for (uint32_t r = wave; r < 10u; r += 4u) {
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(base + uint64_t(8u * k + r) * kPitch + lane * 16),
+                                             (void __attribute__((address_space(3)))*)(ring + (slot0 + r) * kRowMain), 16, 0, 0);
+            if (lane < 2)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(base + uint64_t(8u * k + r) * kPitch + 1024 + lane * 16),
+                                                 (void __attribute__((address_space(3)))*)(ring + kTail30 + (slot0 + r) * kRowTail), 16, 0, 0);
+        }
+    };
+    dma_chunk(0);
+    if (kChunks > 1) dma_chunk(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    uint32_t* d5 = reinterpret_cast<uint32_t*>(tiles + uint64_t(tx * 32 + ty) * 524288 + 4) + tid;
+    uint32_t* d4 = reinterpret_cast<uint32_t*>(parents + uint64_t((tx / 2) * 16 + ty / 2) * 524288 + uint64_t(ty & 1u) * 262144 + (tx & 1u) * 512 + 4) + (tid >> 1);
+    const uint32_t c0 = 2 * tid, c1 = 2 * tid + 2;
+    auto col = [&](uint32_t c, uint32_t& off, uint32_t& stride) {
+        if (c < 512) { off = c * 2; stride = kRowMain; } else { off = kTail30 + (c - 512) * 2; stride = kRowTail; }
+    };
+    uint32_t o00, s00, o01, s01, o10, s10, o11, s11;
+    col(c0, o00, s00); col(c0 + 1, o01, s01); col(c1, o10, s10); col(c1 + 1, o11, s11);
+    for (uint32_t i = 0; i < kChunks; i++) {
+        if (i + 2 < kChunks) dma_chunk(i + 2);
+        const uint32_t k = part + i * PARTS, slot0 = (i % 3u) * 10u;
+        auto tex = [&](uint32_t r, uint32_t off, uint32_t stride) -> uint32_t { return *reinterpret_cast<const uint16_t*>(lds + off + (slot0 + r) * stride); };
+        f2 carry = {float(tex(0, o00, s00)), float(tex(0, o10, s10))};
+        uint32_t out[8];
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++) out[r] = shade<ARITH>(tex(r + 1, o00, s00), tex(r + 1, o01, s01), tex(r + 1, o10, s10), tex(r + 1, o11, s11), carry, 0.125f * float(r));
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++) d5[(k * 8 + r) * 256] = out[r];
+        if ((tid & 1u) == 0) {
+#pragma unroll
+            for (uint32_t r = 0; r < 4; r++) d4[(k * 4 + r) * 256] = out[2 * r] + out[2 * r + 1];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a three-slot ring: the chunk after next must have landed before it is shaded two barriers on; kept simple)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 template <typename F> static float timeit(F f) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -429,6 +483,15 @@ int main(int argc, char** argv) {
     hipMemset(src, 3, 16384ull * kPitch + (1 << 20));
     for (int i = 0; i < 200; i++) v0<0><<<1024, 256>>>(src, tiles, parents, 3);
     hipDeviceSynchronize();
+    if (argc > 1 && !strcmp(argv[1], "stride")) {  // round 5: PARTS workgroups per tile, chunks interleaved between them
+        for (int rep = 0; rep < 3; rep++) {
+            printf("arith 24: V1 %6.1f | strided ring, 1 part %6.1f | 2 parts %6.1f | 4 parts %6.1f | 8 parts %6.1f us\n", timeit([&] { v12<24, false><<<1024, 256>>>(src, tiles, parents, 3); }),
+                   timeit([&] { vstride<24, 1><<<1024, 256>>>(src, tiles, parents); }), timeit([&] { vstride<24, 2><<<2048, 256>>>(src, tiles, parents); }),
+                   timeit([&] { vstride<24, 4><<<4096, 256>>>(src, tiles, parents); }), timeit([&] { vstride<24, 8><<<8192, 256>>>(src, tiles, parents); }));
+            fflush(stdout);
+        }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "dram")) {  // round 5: store cache policies x chip-wide read / write phase separation (promotion gate: <= 225 us at arith 24)
         const char* pol[6] = {"plain", "sc0", "sc1", "sc0 sc1", "nt", "sc0 sc1 nt"};
         for (int rep = 0; rep < 2; rep++) {
