@@ -8,17 +8,19 @@
 // 2x2 child-mosaic pixels below it (downsample.wgsl:18-20, child_size = c/2).  So nothing needs the
 // reference's write-section copies, per-tile dispatches or phase barriers.
 //
-//   fused_main : one workgroup = 32 centre rows of one finest-LOD tile (+ the apron rows at the tile's
-//                top / bottom).  The source rows it needs are staged once into LDS with 16-byte loads
-//                (one 1 KiB wave-instruction per source row), every thread owns one pair of texture
-//                columns and walks down the rows: complete, already stitched 1024-byte tile rows of the
-//                finest LOD leave as one coalesced store per wave (aprons are *pulled*: evaluated with the
-//                neighbour tile's own formula, hence bit-identical to its centre); row pairs reduce in
-//                registers and lane pairs via DPP to the next two LODs, which are *pushed* into the parent
-//                and grand-parent tiles including the aprons of their neighbours.
-//   fused_tail : the remaining (tiny) LODs, three at a time, from the atlas: 32x32 mosaic pixels per
-//                workgroup, LDS hand-off between levels, same push.
-//   cube seams : tiles on a cube-face edge get their aprons from the generic stitch kernel afterwards.
+//   fused_main  : one persistent workgroup per finest-LOD tile (256 threads, a thread = one pair of texture columns), 8 centre rows
+//                 per chunk.  While chunk k is shaded out of LDS the source rows of chunk k + 1 travel into the other LDS buffer — by
+//                 LDS-DMA (one 1 KiB instruction per source row and wave) where the raster is 16-byte aligned, through registers
+//                 otherwise.  Complete, already stitched 1024-byte tile rows of the finest LOD leave as one coalesced store per wave
+//                 (aprons are *pulled*: evaluated with the neighbour tile's own formula, hence bit-identical to its centre); row
+//                 pairs reduce in registers and lane pairs via DPP to the next two LODs, which are *pushed* into the parent and
+//                 grand-parent tiles including the aprons of their x neighbours.  No-data is handled where it is met, per thread
+//                 and quad of rows, inside the chunk loop.
+//   fused_direct: the same for Rgba8 without LDS staging (a thread = one centre column, software-pipelined 4-row blocks).
+//   fused_tail  : the remaining (small) LODs, three per launch, from the atlas: 64 x 64 mosaic pixels per workgroup, 4 x 4 per thread,
+//                 no LDS, same push; extra workgroups write the apron rows of the LODs above and, on a cube, the cross-face seam regions
+//                 whose sources fused_main produced; the workgroup -> work mapping is XCD-aware.
+//   cube seams  : what is left (the top LODs the tail itself produces) comes from stitch_region_kernel afterwards.
 //
 // Arithmetic contract: identical to bt_kernels.hip / oracle (IEEE binary32, -ffp-contract=off).  The one
 // liberty: t / 65535.0f is evaluated as q0 = t*r, e = fma(-q0, 65535, t), q = fma(e, r, q0) with
@@ -427,18 +429,15 @@ __device__ __forceinline__ void corner_pixels(const FusedArgs& A, uint32_t item_
     }
 }
 
-// kGeneric == false: the fast variant (packed f32, no validity bookkeeping).  A chunk whose source window holds a
-// no-data texel is flagged in S.redo; when the run is through, the workgroup stages the flagged chunks once more and redoes
-// them with the generic rows (per-pixel validity, the keep-previous rule, the valid-average) — the same code the kGeneric
-// variant runs inside its loop, here behind the loop, where its registers do not add to the fast loop's (inside the loop
-// the two cost ~90 spilled VGPRs at the 4-waves-per-SIMD budget; rounds 1-3 therefore ran the generic rows as a launch of
-// their own, fused_todo, which was an empty 4096-wave launch + a kernel boundary on every clean input).  kStaged == false
-// reads the source directly (window too large for LDS) and always takes the generic loop.
-// kDma (fast staged variant only, rasters 16-byte aligned): the source rows of the next chunk travel global -> LDS by
-// LDS-DMA (global_load_lds_dwordx4: no staging registers, no commit pass); the no-data test moves from the staging pass to
-// the texels each thread actually reads, per thread: a thread (pair) that saw a no-data texel stores nothing for that
-// quad of rows and flags the chunk; the redo behind the loop rewrites the whole chunk (identical values where the fast pass
-// did store, keep-previous / valid-average where it did not).
+// kGeneric == false: the fast variants (packed f32 in the 2^16-scaled domain).  No-data (split.wgsl:34-42, downsample.wgsl:25-39) is detected
+// in the texels each thread actually reads, per quad of rows, and fixed in place inside the chunk loop: the thread re-reads the quad's source
+// rows from LDS (still staged), derives per-pixel validity, fetches the previous atlas texel for the pixels without data and stores the quad
+// as usual; the LOD-1 pixels of such a quad and, where a LOD-1 texel came out 0, the LOD-2 pixel take downsample4's valid-average.  (Rounds
+// 1-3 ran the generic rows over flagged chunks as a launch of their own, fused_todo; round 4 redid flagged chunks behind the loop — every one
+// staged a second time; both are gone.)  kGeneric == true with kStaged == false reads the source directly (window too large for LDS) and runs
+// the generic rows — per-pixel validity for every pixel — inside its loop.
+// kDma (fast staged variant, rasters 16-byte aligned — the library pads what it uploads, bt_host.cpp add_raster): the source rows of the next
+// chunk travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no commit pass).
 template <bool kStaged, bool kGeneric, uint32_t kT, uint32_t kP, bool kDma = false>
 __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t item_index, uint32_t k_begin, uint32_t k_end, uint8_t* smem) {
     MainShared& S = *reinterpret_cast<MainShared*>(smem);
