@@ -70,6 +70,8 @@ def test_library_reports_the_shader_files_it_executes():
 def test_generated_code_is_not_tracked():
     """nothing derived from the reference's sources enters the history: oracle/_ref/ is git-ignored"""
     root = os.path.dirname(HERE)
+    if subprocess.run(["git", "rev-parse", "--is-inside-work-tree"], cwd=root, capture_output=True).returncode != 0:
+        pytest.skip("not a git work tree (an exported copy of the repository)")
     tracked = subprocess.run(["git", "ls-files", "oracle/_ref"], cwd=root, capture_output=True, text=True).stdout.strip()
     assert tracked == ""
     assert subprocess.run(["git", "check-ignore", "-q", "oracle/_ref/gen_split.inc"], cwd=root).returncode == 0
