@@ -820,3 +820,18 @@ def test_streamed_run_pads_a_deferred_raster_of_unaligned_pitch(device, tmp_path
     for n in names:
         assert open(os.path.join(d0, n), "rb").read() == open(os.path.join(d1, n), "rb").read(), n
     assert K.assert_atlas_equal(roots[1][1], K.oracle_planar(src, lods, 512, 2, O.FORMAT_R16, atlas_size=128)) == 85
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (9, 1), (1, 17), (8, 8)])
+@pytest.mark.parametrize("fmt", [O.FORMAT_R16, O.FORMAT_RGBA8])
+def test_tiny_rasters_through_the_512_wide_plans(device, fmt, shape):
+    """Extreme magnification at the production tile size: a raster of a few texels (padded to 16-byte rows by the library) blown up to
+    5 tiles of 512^2 — every source index clamps, whole chunks read ONE source row — through the plan the product picks and the generic one;
+    with a no-data texel where there is room for one."""
+    src = K.random_raster(fmt, shape[0], shape[1], seed=shape[0] * 31 + shape[1])
+    if src.shape[0] * src.shape[1] > 4:
+        (src[..., 0] if fmt == O.FORMAT_RGBA8 else src)[src.shape[0] // 2, src.shape[1] // 2] = 0
+    oracle = K.oracle_planar(src, 2, 512, 2, fmt, atlas_size=8)
+    for generic in (False, True):
+        atlas, _ = K.product_planar(device, src, 2, 512, 2, fmt, atlas_size=8, generic=generic)
+        assert K.assert_atlas_equal(atlas, oracle) == 5, generic
