@@ -835,3 +835,31 @@ def test_tiny_rasters_through_the_512_wide_plans(device, fmt, shape):
     for generic in (False, True):
         atlas, _ = K.product_planar(device, src, 2, 512, 2, fmt, atlas_size=8, generic=generic)
         assert K.assert_atlas_equal(atlas, oracle) == 5, generic
+
+
+def test_32k_job_seven_lods_beyond_the_bench_size(device):
+    """Maximum-size check one step past BASELINE's largest input: a 32768^2 R16 source (2 GiB: row and layer offsets beyond 2^31 bytes),
+    lod_count 7 -> 5461 tiles (a 2.7 GB atlas attachment: texel offsets up to 1.4 x 10^9), a no-data patch across a tile seam.  The index
+    contract for all 5461 tiles, and every 11th tile + the whole top of the pyramid byte for byte against the oracle."""
+    size, lods = 32768, 7
+    ptr = device.synth_fbm_r16(size, size, 77)
+    src = device.download(ptr, (size, size), np.uint16)
+    src[16000:16700, 20000:20900] = 0
+    device.free(ptr)
+    ptr = device.upload(src)
+    n_tiles = sum(4 ** l for l in range(lods))
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=5500, path="terrains/big", model=bt.TerrainModel.planar((0.0, 0.0, 0.0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=512, border_size=2, format=bt.AttachmentFormat.R16))
+    atlas = bt.TileAtlas.new(cfg, device)
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_tile(
+        bt.PreprocessDataset(attachment_index=0, path="big", lod_range=range(0, lods)), bt.AssetServer().insert("big", (ptr, size, size)), atlas)
+    pre.run(atlas)
+    device.free(ptr)
+    st = pre.stats()
+    assert st["fused_jobs"] == 1 and st["tiles"] == n_tiles
+    oracle = O.OracleAtlas(lods, 5500, False, [(512, 2, 1, O.FORMAT_R16)])
+    oracle.clear_attachment(0).preprocess_tile(0, src, (0, lods)).run(O.usable_cores())
+    assert [((c.side, c.lod, c.x, c.y), i) for c, i in atlas.tiles()] == oracle.tiles()
+    picked = sorted(set(range(0, n_tiles, 11)) | set(range(n_tiles - 341, n_tiles)))  # a sample of the two finest LODs + LODs 0 .. 4 completely
+    for i in picked:
+        assert np.array_equal(atlas.download_tiles(0, i, 1)[0], oracle.tile(0, i)), (i, oracle.tiles()[i])
