@@ -69,6 +69,18 @@ def main():
         ONLY = sys.argv[sys.argv.index("--only") + 1]
     device = bt.Device(0)
     out = {}
+    if "--big32k" in sys.argv:  # one step past BASELINE's largest input: 32768^2 R16, lod_count 7, 5461 tiles (four generations of fused_main's workgroups)
+        size, lods = 32768, 7
+        ptr = device.synth_fbm_r16(size, size, 77)
+        cfg = bt.TerrainConfig(lod_count=lods, atlas_size=5500, path="terrains/big", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+        cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=512, border_size=2, format=bt.AttachmentFormat.R16))
+        atlas = bt.TileAtlas.new(cfg, device)
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_tile(
+            bt.PreprocessDataset(attachment_index=0, path="b", lod_range=range(0, lods)), bt.AssetServer().insert("b", (ptr, size, size)), atlas)
+        ms, prof, st = time_job(device, pre, atlas, steps=20)
+        print(json.dumps({"big_32k": {"ms": ms, "tiles": st["tiles"], "algorithmic_bytes": st["algorithmic_bytes"], "GBps": st["algorithmic_bytes"] / ms / 1e6,
+                                      "launches": launches_of(prof)}}))
+        return
     if "--masked16k" in sys.argv or ONLY == "config3_masked_16k":
         print(json.dumps({"config3_masked_16k": masked_16k(device)}))
         return
