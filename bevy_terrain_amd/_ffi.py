@@ -89,7 +89,7 @@ class SphericalDatasetC(C.Structure):
 
 class RunStatsC(C.Structure):
     _fields_ = [("kernel_launches", C.c_uint32), ("tiles", C.c_uint32), ("algorithmic_bytes", C.c_uint64),
-                ("fused_jobs", C.c_uint32), ("generic_jobs", C.c_uint32)]
+                ("fused_jobs", C.c_uint32), ("generic_jobs", C.c_uint32), ("prev_zero_launches", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class ShardRangeC(C.Structure):
@@ -245,11 +245,13 @@ PROTOTYPES = {
     "bt_selftest": (_i32, [_vp, _P(_u32)]),
     "bt_synth_fbm_r16": (_i32, [_vp, _vp, _u32, _u32, _u64, _u32, _u32, _u32, _u32, _u32]),
     "bt_preprocessor_run_streamed": (_i32, [_vp, _vp, C.c_char_p, _u32, _vp]),
+    "bt_preprocessor_run_streamed_sharded": (_i32, [_vp, _vp, _vp, C.c_char_p, _u32, _vp]),
 }
 
 
 class StreamStatsC(C.Structure):
-    _fields_ = [("streamed", C.c_uint32), ("bands", C.c_uint32)]
+    _fields_ = [("streamed", C.c_uint32), ("bands", C.c_uint32), ("banded_launches", C.c_uint32), ("early_tiles", C.c_uint32),
+                ("uploaded_bytes", C.c_uint64), ("saved_bytes", C.c_uint64)]
 
 
 RASTER_HOST_DEFERRED = 2

@@ -146,7 +146,11 @@ void bt_comm_destroy(bt_comm* comm) {
 // ONE grouped collective (in-place all-gather + in-place broadcast from the last rank — the two shapes a sharded step issues) moves
 // them, and every byte is verified on the host.  bt_comm_check: 4 KB slots; bt_comm_preflight: the caller's slot size (an atlas tile).
 bt_status bt_comm_preflight(bt_comm* comm, uint64_t slot_bytes, float* elapsed_ms) {
-    if (!comm || slot_bytes == 0 || slot_bytes > (1ull << 30)) return BT_ERR_INVALID_ARGUMENT;
+    // (a health check, not a bandwidth test: a slot is a tile or a few — world + 1 slots are allocated on the device AND on the host)
+    if (!comm || slot_bytes == 0 || slot_bytes > (64ull << 20)) {
+        set_error("bt_comm_preflight: slot_bytes %llu (1 .. 64 MiB)", (unsigned long long)slot_bytes);
+        return BT_ERR_INVALID_ARGUMENT;
+    }
     if (bt_status s = need_rccl()) return s;
     bt_ctx* ctx = comm->ctx;
     BT_HIP(hipSetDevice(ctx->device));
@@ -180,13 +184,15 @@ bt_status bt_comm_preflight(bt_comm* comm, uint64_t slot_bytes, float* elapsed_m
     hipFree(dev);
     if (e != hipSuccess) return hip_fail(e, "bt_comm_preflight");
     if (rc) return rc;
-    for (uint32_t r = 0; r <= comm->world; r++)
-        for (size_t i = 0; i < slot; i++)
-            if (host[slot * r + i] != (r == comm->world ? 0x7E : uint8_t(0x40 + r))) {
-                set_error("bt_comm_preflight: rank %u of %u: slot %u byte %zu holds 0x%02x after the grouped all-gather + broadcast", comm->rank, comm->world, r, i,
-                          host[slot * r + i]);
-                return BT_ERR_DEVICE;
-            }
+    for (uint32_t r = 0; r <= comm->world; r++) {
+        const uint8_t want = r == comm->world ? 0x7E : uint8_t(0x40 + r);
+        const uint8_t* got = host.data() + slot * r;
+        if (got[0] == want && (slot == 1 || memcmp(got, got + 1, slot - 1) == 0)) continue;  // every byte equals the first, the first is right
+        size_t i = 0;
+        while (i < slot && got[i] == want) i++;
+        set_error("bt_comm_preflight: rank %u of %u: slot %u byte %zu holds 0x%02x after the grouped all-gather + broadcast", comm->rank, comm->world, r, i, got[i]);
+        return BT_ERR_DEVICE;
+    }
     if (elapsed_ms) *elapsed_ms = ms;
     return BT_OK;
 }
@@ -242,6 +248,19 @@ bt_status check_comm(const bt_preprocessor* p, const bt_comm* comm) {
     return BT_OK;
 }
 }  // namespace
+
+namespace bt {
+bt_status shard_exchange(bt_preprocessor* p, bt_atlas* a, bt_comm* comm, hipStream_t stream, bool distributed) {
+    if (!comm) {
+        set_error("the exchange of a sharded step needs a communicator");
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    if (bt_status s = need_rccl()) return s;
+    if (comm->world == 1) return BT_OK;
+    return grouped_exchange(p, a, comm, stream, distributed);
+}
+bt_status shard_check_comm(const bt_preprocessor* p, const bt_comm* comm) { return check_comm(p, comm); }
+}  // namespace bt
 
 extern "C" {
 

@@ -92,6 +92,10 @@ struct FusedArgs {
     uint32_t apron_lods;  // fused_tail: LODs lod, lod+1, ... (this many) get their top / bottom apron rows from extra workgroups
     uint32_t rotate_priority;  // fused_main: wave priority rotates with the chunk index (see fused_main_chunks)
     uint32_t apron_cols;  // fused_tail (Rgba8 after fused_direct, which writes centres only): ... and their left / right apron columns
+    // fused_main / fused_direct: every finest tile of the job still holds bt_atlas_create's zeros (Attachment::written, decided by the host per
+    // run): "the previous value" of a pixel without data (split.wgsl:34-42) IS 0 — taken as a constant instead of fetched from the atlas.  Both
+    // reference examples are this case (clear_attachment, then one dataset per attachment: preprocess_planar.rs:16-60).
+    uint32_t prev_zero;
     uint32_t ablate;      // debug only (env BT_FUSED_ABLATE): 1 no pyramid, 2 no finest stores, 4 no parent stores, 64 no grand-parent stores (static path), 8 no staging loads, 16 prologue only, 256 / 512 finest / parent stores without arithmetic (use with 16); skeleton shapes: 65536 parent rows in bursts of four chunks, 262144 parent rows as 16-byte stores, 1048576 finest rows as 16-byte stores
 };
 
@@ -347,7 +351,7 @@ __device__ __forceinline__ uint32_t split_value_slow(const FusedArgs& A, const R
     const global_u16 row1 = (global_u16)((global_bytes)r.data + uint64_t(ay.i1) * r.pitch);
     const uint32_t t00 = row0[ax.i0], t10 = row0[ax.i1], t01 = row1[ax.i0], t11 = row1[ax.i1];
     if (t00 == 0 || t10 == 0 || t01 == 0 || t11 == 0) {
-        if (home_index == kInvalid) return 0;
+        if (home_index == kInvalid || A.prev_zero) return 0;
         return A.atlas[uint64_t(home_index) * T * T + uint64_t(b + ry) * T + b + rx];
     }
     const float top = mixf(unorm16_to_float(t00), unorm16_to_float(t10), ax.fr);
@@ -731,8 +735,13 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             if (kKeep && min(min(t0.za, t1.za), min(t0.zb, t1.zb)) == 0) {
                 const uint32_t nrow = top ? t5.n : t5.s;
                 const uint16_t* h = A.atlas + uint64_t(nrow == kInvalid ? t5.self : nrow) * tile_texels + (b + S.apron[r].pad) * T + b;
-                if (min(t0.za, t1.za) == 0) va = h[rxa];
-                if (min(t0.zb, t1.zb) == 0) vb = h[rxb];
+                if (A.prev_zero) {
+                    if (min(t0.za, t1.za) == 0) va = 0;
+                    if (min(t0.zb, t1.zb) == 0) vb = 0;
+                } else {
+                    if (min(t0.za, t1.za) == 0) va = h[rxa];
+                    if (min(t0.zb, t1.zb) == 0) vb = h[rxb];
+                }
                 asm volatile("" : "+v"(va), "+v"(vb));  // (the values arrive inside the rare branch: no wait for everything in flight behind it)
             }
             tile5_u32[(py * T + px0) >> 1] = va | (vb << 16);
@@ -786,8 +795,8 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         if (vb[i] & 0x10000u) vb[i] = prev_b[i];
                     } else {
                         const uint16_t* h = A.atlas + uint64_t(home_col) * tile_texels + (b + cr0 + q + i) * T + b;
-                        if (va[i] & 0x10000u) va[i] = h[rxa];
-                        if (vb[i] & 0x10000u) vb[i] = h[rxb];
+                        if (va[i] & 0x10000u) va[i] = A.prev_zero ? 0u : uint32_t(h[rxa]);
+                        if (vb[i] & 0x10000u) vb[i] = A.prev_zero ? 0u : uint32_t(h[rxb]);
                     }
                 }
             }
@@ -955,10 +964,18 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                     z[j] = __builtin_elementwise_min(u16x2{pa0[(4 * quad + j) * P], pb0[(4 * quad + j) * P]},
                                                                      u16x2{pa1[(4 * quad + j) * P], pb1[(4 * quad + j) * P]});
                                 const uint16_t* h = A.atlas + uint64_t(home_col) * tile_texels + (b + cr0 + 4 * quad) * T + b;
+                                if (A.prev_zero) {  // a fresh atlas: the previous value is bt_atlas_create's 0 — no fetch, no wait
 #pragma unroll
-                                for (uint32_t i = 0; i < 4; i++) {
-                                    if (min(z[i].x, z[i + 1].x) == 0) ua[i] = h[i * T + rxa];
-                                    if (min(z[i].y, z[i + 1].y) == 0) ub[i] = h[i * T + rxb];
+                                    for (uint32_t i = 0; i < 4; i++) {
+                                        if (min(z[i].x, z[i + 1].x) == 0) ua[i] = 0;
+                                        if (min(z[i].y, z[i + 1].y) == 0) ub[i] = 0;
+                                    }
+                                } else {
+#pragma unroll
+                                    for (uint32_t i = 0; i < 4; i++) {
+                                        if (min(z[i].x, z[i + 1].x) == 0) ua[i] = h[i * T + rxa];
+                                        if (min(z[i].y, z[i + 1].y) == 0) ub[i] = h[i * T + rxb];
+                                    }
                                 }
                                 // the fetched values arrive HERE, inside the rare branch: left pending, the compiler guards the stores behind the
                                 // branch — on the fast path too — with s_waitcnt vmcnt(0), a wait for the next chunk's DMA rows and every store
@@ -1094,8 +1111,8 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             const int yy = row_y0[q + i];
                             const uint16_t* r0 = s_src + uint32_t((yy & 0x7fffffff) - cur_ymin) * P;
                             const uint16_t* r1 = r0 + (yy < 0 ? 0u : P);
-                            if (min(min(r0[la0], r0[la1]), min(r1[la0], r1[la1])) == 0) ua[i] = h[i * T + rxa];
-                            if (min(min(r0[lb0], r0[lb1]), min(r1[lb0], r1[lb1])) == 0) ub[i] = h[i * T + rxb];
+                            if (min(min(r0[la0], r0[la1]), min(r1[la0], r1[la1])) == 0) ua[i] = A.prev_zero ? 0u : uint32_t(h[i * T + rxa]);
+                            if (min(min(r0[lb0], r0[lb1]), min(r1[lb0], r1[lb1])) == 0) ub[i] = A.prev_zero ? 0u : uint32_t(h[i * T + rxb]);
                         }
 #pragma unroll
                         for (uint32_t i = 0; i < 4; i++) asm volatile("" : "+v"(ua[i]), "+v"(ub[i]));  // (the values arrive inside the rare branch, see the static path)
@@ -1539,7 +1556,7 @@ __device__ __forceinline__ uint32_t rgba8_value_slow(const FusedArgs& A, const R
     const global_u32_t row1 = (global_u32_t)((global_bytes_t)r.data + uint64_t(ay.i1) * r.pitch);
     const H4 top = hrow_rgba8(row0[ax.i0], row0[ax.i1], ax.fr), bot = hrow_rgba8(row1[ax.i0], row1[ax.i1], ax.fr);
     if (!(top.valid && bot.valid)) {
-        if (home_index == kInvalid) return 0;
+        if (home_index == kInvalid || A.prev_zero) return 0;
         return reinterpret_cast<const uint32_t*>(A.atlas)[uint64_t(home_index) * T * T + uint64_t(b + ry) * T + b + rx];
     }
     return vmix_rgba8(top, bot, ay.fr);
@@ -1876,8 +1893,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                     for (uint32_t r = 0; r < kRows; r++)
                         if (used && r < nrows && keep[r]) {
-                            out[r] = atlas[uint64_t(home) * tile_texels + (b + cr0 + r) * T + b + home_col];
-                            if (apron_lane) tile[(b + cr0 + r) * T + store_px] = out[r];
+                            // (A.prev_zero: a fresh atlas — the kept value is bt_atlas_create's 0, and the pixel, unwritten, already holds it)
+                            out[r] = A.prev_zero ? 0u : atlas[uint64_t(home) * tile_texels + (b + cr0 + r) * T + b + home_col];
+                            if (apron_lane && !A.prev_zero) tile[(b + cr0 + r) * T + store_px] = out[r];
                         }
                 }
                 // the fetched values arrive HERE: left pending, the compiler would guard the reductions below — which the fast path
@@ -2018,6 +2036,9 @@ struct FusedJobDev {  // one fused launch of a compiled queue
     bool direct = false;     // a fused_direct launch (reads the source texel by texel: no staged window)
     uint32_t seam_first = 0;  // fused_tail with seam workgroups: its tasks are p->tasks_dev[seam_first ...] (args.seam_count of them)
     float tly = 0.0f, bry = 1.0f;
+    // fused_main / fused_direct: the atlas layers of the job's finest tiles (a no-data pixel's "previous value" is read from one of them) and of
+    // all its tiles (written by this job's launches); fused_begin_run decides args.prev_zero from Attachment::written before every run
+    std::vector<uint32_t> finest_layers, all_layers;
 };
 
 // the fused path's per-queue state, owned by the bt_preprocessor that compiled it (bt_preprocessor::fused)
@@ -2272,6 +2293,16 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                     source_bytes += uint64_t(p->rasters[t->raster].dev.width) * p->rasters[t->raster].dev.height * bpp;
                 }
         }
+        std::vector<uint32_t> finest_layers, all_layers;  // (Attachment::written bookkeeping: fused_begin_run)
+        for (uint32_t side = 0; side < sides; side++)
+            for (uint32_t lod = lod_lo; lod <= lod_hi; lod++) {
+                const uint32_t off = grid_offsets[side * 32 + lod];
+                for (size_t i = 0; i < (size_t(1) << (2 * lod)); i++)
+                    if (grids[off + i] != kInvalid) {
+                        all_layers.push_back(grids[off + i]);
+                        if (lod == lod_hi) finest_layers.push_back(grids[off + i]);
+                    }
+            }
         auto tiles_at = [&](uint32_t lod) {
             uint64_t n = 0;
             for (uint32_t side = 0; side < sides; side++) {
@@ -2330,6 +2361,8 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             job.args.item_count = uint32_t(items.size());
             job.host_items = items;
             job.direct = true;
+            job.finest_layers = finest_layers;
+            job.all_layers = all_layers;
             job.tly = args.tly;
             job.bry = args.bry;
             {   // row blocks per workgroup: as many as keep at least one resident generation (1024 workgroups) busy
@@ -2357,6 +2390,8 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         main_job.args.levels = main_levels;
         main_job.args.item_count = uint32_t(items.size());
         main_job.host_items = items;
+        main_job.finest_layers = finest_layers;
+        main_job.all_layers = all_layers;
         main_job.tly = args.tly;
         main_job.bry = args.bry;
         {
@@ -2487,6 +2522,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             const uint32_t levels = std::min(3u, in_lod - lod_lo);
             uint64_t lt_extra = 0;
             FusedJobDev tail{args, ai};
+            tail.all_layers = all_layers;
             tail.args.lod = in_lod;
             tail.args.levels = levels;
             // the first tail launch also fills the top / bottom apron rows of the LODs fused_main produced (see above)
@@ -2554,6 +2590,23 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                         if (out_x != out_y && !(t->rel[i].atlas_index != BT_INVALID_ATLAS_INDEX && t->rel[i].coordinate.side != t->coord.side)) in_tail = false;
                     }
                 }
+            if (in_tail) {
+                // ... and every face-edge tile of those LODs that the grids hold HAS a stitch task (seam_skip makes the tail's apron-row workgroups
+                // leave the cross-face regions of every such grid tile alone: one without a task would keep stale apron texels there)
+                std::unordered_set<uint32_t> stitched;
+                for (const Task* t : stitches)
+                    if (on_face_edge(t) && t->coord.lod >= main_lo && t->coord.lod < lod_hi) stitched.insert(t->atlas_index);
+                for (uint32_t side = 0; side < sides && in_tail; side++)
+                    for (uint32_t lod = main_lo; lod < lod_hi && in_tail; lod++) {
+                        const uint32_t n = 1u << lod, off = grid_offsets[side * 32 + lod];
+                        for (uint32_t x = 0; x < n && in_tail; x++)
+                            for (uint32_t y = 0; y < n; y++) {
+                                if (!(x == 0 || y == 0 || x == n - 1 || y == n - 1)) continue;
+                                const uint32_t v = grids[off + (size_t(x) << lod) + y];
+                                if (v != kInvalid && !stitched.count(v)) { in_tail = false; break; }
+                            }
+                    }
+            }
             uint64_t tail_pixels = 0, late_pixels = 0;
             const uint32_t tail_first = uint32_t(tasks.size());
             for (int pass = 0; pass < 2; pass++) {  // the tail launch's regions first, then the later launch's
@@ -2596,6 +2649,34 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
 
 bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, uint32_t item_begin, uint32_t item_count);
 bt_status fused_launch(bt_preprocessor* p, bt_atlas* a, const Launch& l) { return fused_launch_range(p, a, l, 0u, 0xFFFFFFFFu); }
+
+// Before the launches of a run, in plan order: a fused main / direct launch whose finest tiles are all still unwritten since bt_atlas_create
+// (Attachment::written) runs with FusedArgs::prev_zero — bit-identical by construction, the fetch would return the memset's 0 — and every
+// launch marks the layers it writes, so a later job of the same queue that overlays these tiles takes the fetching path.  Returns how many
+// launches got the flag (bt_run_stats::prev_zero_launches).
+uint32_t fused_begin_run(bt_preprocessor* p, bt_atlas* a) {
+    uint32_t flagged = 0;
+    for (const Launch& l : p->plan) {
+        Attachment& at = a->attachments[l.attachment];
+        if (l.kind == kLaunchSplit || l.kind == kLaunchDownsample || l.kind == kLaunchStitch) {
+            for (uint32_t i = l.first_task; i < l.first_task + l.task_count && i < p->tasks_host.size(); i++) at.mark_written(p->tasks_host[i].atlas_index, 1);
+            continue;
+        }
+        if (!p->fused || l.aux0 >= p->fused->jobs.size()) continue;
+        FusedJobDev& job = p->fused->jobs[l.aux0];
+        if (l.kind == kLaunchFusedMain || l.kind == kLaunchFusedDirect) {
+            bool fresh = !job.finest_layers.empty();
+            for (uint32_t layer : job.finest_layers) fresh = fresh && layer < at.written.size() && !at.written[layer];
+#ifdef BT_DEBUG_HOOKS
+            if (getenv("BT_FUSED_NO_PREV_ZERO")) fresh = false;
+#endif
+            job.args.prev_zero = fresh ? 1u : 0u;
+            flagged += fresh;
+        }
+        for (uint32_t layer : job.all_layers) at.mark_written(layer, 1);
+    }
+    return flagged;
+}
 
 // Bands of whole tile rows of a fused main launch, with the last source row each band's kernels read (the bottom apron rows
 // of its last tile row are evaluated with the next tile row's formula: same f32 operations as the kernel's row tables).
@@ -2647,26 +2728,33 @@ bool fused_source_window(const bt_preprocessor* p, uint32_t raster, uint32_t out
     return true;
 }
 
-bool fused_stream_bands(bt_preprocessor* p, const Launch& l, uint32_t tile_rows_per_band, int32_t* raster, std::vector<StreamBand>* bands) {
-    if (l.kind != kLaunchFusedMain || !p->fused || l.aux0 >= p->fused->jobs.size() || tile_rows_per_band == 0) return false;
+// Bands of whole tile rows of a fused main / direct launch (streamed runs), with the raster each band reads and the last source row its
+// kernels touch (the bottom apron rows of its last tile row are evaluated with the next tile row's formula: same f32 operations as the
+// kernels' row tables).  The items are in (side, tile row, x) order; a band never crosses a side (a cube job: six rasters, one after the
+// other).  tile_rows_per_band == 0: a quarter of the face's tile rows, at most 4 (the 16k job: 8 bands of 4 rows; a 4k job: 4 bands of 2).
+bool fused_stream_bands(bt_preprocessor* p, const Launch& l, uint32_t tile_rows_per_band, std::vector<StreamBand>* bands) {
+    if ((l.kind != kLaunchFusedMain && l.kind != kLaunchFusedDirect) || !p->fused || l.aux0 >= p->fused->jobs.size()) return false;
     const FusedJobDev& job = p->fused->jobs[l.aux0];
     const std::vector<MainItem>& items = job.host_items;
-    if (items.empty() || job.args.lds_rows == 0) return false;
-    for (const MainItem& it : items)
-        if (it.side != items[0].side || it.raster != items[0].raster) return false;  // one face, one source
-    const RasterDev& r = p->rasters[items[0].raster].dev;
+    if (items.empty() || (l.kind == kLaunchFusedMain && job.args.lds_rows == 0)) return false;  // (the unstaged fused_main is two kernels over the whole item list)
     const uint32_t c = job.args.m.center_size, b = job.args.m.border_size, n = 1u << job.args.lod;
+    if (tile_rows_per_band == 0) tile_rows_per_band = std::max(1u, std::min(4u, n / 4u));
     const float scale = float(n);
-    auto axis = [&](uint32_t tile, uint32_t row) { return split_axis(row, c, tile, scale, job.tly, job.bry, r.height); };
-    *raster = int32_t(items[0].raster);
     bands->clear();
     size_t i = 0;
     while (i < items.size()) {
+        const uint32_t side = items[i].side, raster = items[i].raster;
+        if (raster >= p->rasters.size()) return false;
+        const RasterDev& r = p->rasters[raster].dev;
+        auto axis = [&](uint32_t tile, uint32_t row) { return split_axis(row, c, tile, scale, job.tly, job.bry, r.height); };
         StreamBand band{};
         band.item_begin = uint32_t(i);
         band.tile_y_begin = items[i].y;
+        band.side = side;
+        band.raster = raster;
         uint32_t rows = 0, y = items[i].y;
-        while (i < items.size() && (items[i].y == y || rows + 1 < tile_rows_per_band)) {
+        while (i < items.size() && items[i].side == side && (items[i].y == y || rows + 1 < tile_rows_per_band)) {
+            if (items[i].raster != raster) return false;  // one source per side
             if (items[i].y != y) {
                 if (items[i].y < y) return false;  // not in tile-row order
                 y = items[i].y;
@@ -2678,12 +2766,27 @@ bool fused_stream_bands(bt_preprocessor* p, const Launch& l, uint32_t tile_rows_
         band.tile_y_end = y + 1;
         const int hi = y + 1 < n ? axis(y + 1, b - 1).i1 : axis(y, c - 1).i1;
         band.source_row_end = uint32_t(std::min<int64_t>(int64_t(r.height), int64_t(hi) + 1));
+        // a raster's bands follow each other and its source rows never decrease from band to band (they do not for a dataset rectangle with
+        // top < bottom); a raster that comes back after another one's bands cannot be streamed
+        if (!bands->empty() && bands->back().raster == raster) {
+            if (bands->back().source_row_end > band.source_row_end) return false;
+        } else {
+            for (const StreamBand& earlier : *bands)
+                if (earlier.raster == raster) return false;
+        }
         bands->push_back(band);
     }
-    // source rows must not decrease from band to band (they do not for a dataset rectangle with top < bottom)
-    for (size_t k = 1; k < bands->size(); k++)
-        if ((*bands)[k].source_row_end < (*bands)[k - 1].source_row_end) return false;
     return true;
+}
+
+void fused_launch_tiles(const bt_preprocessor* p, const Launch& l, uint32_t item_begin, uint32_t item_count, std::vector<FusedTile>* out) {
+    out->clear();
+    if ((l.kind != kLaunchFusedMain && l.kind != kLaunchFusedDirect) || !p->fused || l.aux0 >= p->fused->jobs.size()) return;
+    const FusedJobDev& job = p->fused->jobs[l.aux0];
+    for (uint64_t i = item_begin; i < uint64_t(item_begin) + item_count && i < job.host_items.size(); i++) {
+        const MainItem& it = job.host_items[size_t(i)];
+        out->push_back({{it.side, job.args.lod, it.x, it.y}, it.atlas_index});
+    }
 }
 
 bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, uint32_t item_begin, uint32_t item_count) {
@@ -2695,7 +2798,7 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
     std::vector<FusedJobDev>& jobs = p->fused->jobs;
     FusedJobDev job = jobs[l.aux0];
     job.args.rasters = p->rasters_dev;
-    if (l.kind == kLaunchFusedMain && item_begin < job.args.item_count) {  // a band of the item list (streamed runs); default: all
+    if ((l.kind == kLaunchFusedMain || l.kind == kLaunchFusedDirect) && item_begin < job.args.item_count) {  // a band of the item list (streamed runs); default: all
         job.args.items += item_begin;
         job.args.item_count = std::min(item_count, job.args.item_count - item_begin);
     }

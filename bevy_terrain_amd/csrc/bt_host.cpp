@@ -9,6 +9,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <array>
 #include <cerrno>
 #include <cmath>
 #include <cstdarg>
@@ -161,20 +162,28 @@ static bt_status make_dirs(const std::string& dir) {
 // container on a 256-thread host may own 16 of them, and std::thread::hardware_concurrency() reports the host's
 uint32_t usable_cpus() {
     uint32_t n = 0;
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    if (sched_getaffinity(0, sizeof set, &set) == 0) n = uint32_t(CPU_COUNT(&set));
+    // (a dynamically sized mask: the fixed cpu_set_t holds 1024 CPUs and sched_getaffinity fails with EINVAL on a larger host)
+    for (size_t cpus = 1024; cpus <= (1u << 20) && n == 0; cpus *= 4) {
+        cpu_set_t* set = CPU_ALLOC(cpus);
+        if (!set) break;
+        const size_t bytes = CPU_ALLOC_SIZE(cpus);
+        CPU_ZERO_S(bytes, set);
+        const int rc = sched_getaffinity(0, bytes, set);
+        if (rc == 0) n = uint32_t(CPU_COUNT_S(bytes, set));
+        CPU_FREE(set);
+        if (rc != 0 && errno != EINVAL) break;
+    }
     if (n == 0) n = std::max(1u, std::thread::hardware_concurrency());
-    auto quota_from = [](const char* path, const char* period_path) -> double {
-        FILE* f = fopen(path, "r");
+    auto quota_from = [](const std::string& path, const std::string& period_path) -> double {
+        FILE* f = fopen(path.c_str(), "r");
         if (!f) return 0.0;
         char a[64] = "", b2[64] = "";
         const int got = fscanf(f, "%63s %63s", a, b2);
         fclose(f);
         if (got < 1 || !strcmp(a, "max")) return 0.0;
         double quota = atof(a), period = got >= 2 ? atof(b2) : 0.0;
-        if (period_path) {
-            FILE* g = fopen(period_path, "r");
+        if (!period_path.empty()) {
+            FILE* g = fopen(period_path.c_str(), "r");
             if (g) {
                 if (fscanf(g, "%63s", b2) == 1) period = atof(b2);
                 fclose(g);
@@ -182,8 +191,35 @@ uint32_t usable_cpus() {
         }
         return quota > 0.0 && period > 0.0 ? quota / period : 0.0;
     };
-    double q = quota_from("/sys/fs/cgroup/cpu.max", nullptr);
-    if (q <= 0.0) q = quota_from("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+    // The process's OWN cgroup (/proc/self/cgroup): without a cgroup namespace — a systemd slice, some Kubernetes set-ups — the quota sits in
+    // a nested directory, not at the mount's root; every ancestor's quota applies, the smallest wins.  v2: "0::/path"; v1: "N:cpu,cpuacct:/path".
+    std::string v2_path, v1_path;
+    if (FILE* f = fopen("/proc/self/cgroup", "r")) {
+        char line[1024];
+        while (fgets(line, sizeof line, f)) {
+            std::string l(line);
+            while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
+            const size_t c1 = l.find(':'), c2 = c1 == std::string::npos ? c1 : l.find(':', c1 + 1);
+            if (c2 == std::string::npos) continue;
+            const std::string controllers = l.substr(c1 + 1, c2 - c1 - 1), path = l.substr(c2 + 1);
+            if (controllers.empty()) v2_path = path;
+            else if (("," + controllers + ",").find(",cpu,") != std::string::npos) v1_path = path;
+        }
+        fclose(f);
+    }
+    double q = 0.0;
+    auto walk = [&](const std::string& root, std::string path, const char* file, const char* period_file) {
+        for (;;) {  // the cgroup itself, then every ancestor up to the mount's root
+            const std::string dir = root + (path == "/" ? "" : path);
+            const double v = quota_from(dir + "/" + file, period_file ? dir + "/" + period_file : std::string());
+            if (v > 0.0 && (q <= 0.0 || v < q)) q = v;
+            if (path.empty() || path == "/") break;
+            const size_t cut = path.find_last_of('/');
+            path = cut == 0 || cut == std::string::npos ? "/" : path.substr(0, cut);
+        }
+    };
+    walk("/sys/fs/cgroup", v2_path.empty() ? "/" : v2_path, "cpu.max", nullptr);
+    if (q <= 0.0) walk("/sys/fs/cgroup/cpu", v1_path.empty() ? "/" : v1_path, "cpu.cfs_quota_us", "cpu.cfs_period_us");
     if (q > 0.0) n = std::min(n, std::max(1u, uint32_t(q + 0.999)));
     return n;
 }
@@ -399,6 +435,7 @@ bt_status bt_atlas_create(bt_ctx* ctx, const bt_terrain_config* config, bt_atlas
             return hip_fail(e, "atlas allocation");
         }
         at.mips.assign(c.mip_level_count ? c.mip_level_count : 1, nullptr);
+        at.written.assign(config->atlas_size, 0);
         a->attachments.push_back(at);
     }
     *out = a;
@@ -537,7 +574,12 @@ uint32_t bt_atlas_tiles(const bt_atlas* a, bt_tile_coordinate* coords, uint32_t*
 
 bt_status bt_atlas_attachment_storage(const bt_atlas* a, uint32_t ai, void** ptr, uint64_t* tile_bytes, uint32_t* layers) {
     if (!a || ai >= a->attachments.size()) return BT_ERR_INVALID_ARGUMENT;
-    if (ptr) *ptr = a->attachments[ai].level0;
+    if (ptr) {
+        *ptr = a->attachments[ai].level0;
+        // the caller may write through this pointer (a host-side collective does): no layer counts as "still zero since bt_atlas_create" any more
+        Attachment& at = const_cast<bt_atlas*>(a)->attachments[ai];
+        at.mark_written(0, uint32_t(at.written.size()));
+    }
     if (tile_bytes) *tile_bytes = a->attachments[ai].tile_bytes;
     if (layers) *layers = a->config.atlas_size;
     return BT_OK;
@@ -560,6 +602,7 @@ bt_status bt_atlas_upload_tile(bt_atlas* a, uint32_t ai, uint32_t layer, const v
     if (!a || ai >= a->attachments.size() || !src) return BT_ERR_INVALID_ARGUMENT;
     const Attachment& at = a->attachments[ai];
     if (layer >= a->config.atlas_size || src_bytes != at.tile_bytes) return BT_ERR_INVALID_ARGUMENT;
+    a->attachments[ai].mark_written(layer, 1);
     BT_HIP(hipMemcpyAsync((uint8_t*)at.level0 + at.tile_bytes * layer, src, src_bytes, hipMemcpyHostToDevice, a->ctx->stream));
     BT_HIP(hipStreamSynchronize(a->ctx->stream));
     return BT_OK;
@@ -686,12 +729,13 @@ class FileWriters {
     std::string error_;
 };
 
-// Download + write tiles of one attachment: D2H through three pinned buffers on `stream` (runs of consecutive layers are one
-// copy), files written by the writer threads while the next chunk downloads.  add() may be called several times (the
-// streamed run hands over band after band); the tiles of one add() are written in atlas-index order.
+// Download + write tiles: D2H through three pinned buffers on `stream` (runs of consecutive layers are one copy), files written by
+// the writer threads while the next chunk downloads.  add() may be called many times (the streamed run hands over band after band,
+// attachment after attachment); the tiles of one add() are written in atlas-index order.
 class TileSaver {
   public:
-    TileSaver(bt_atlas* a, uint32_t ai, std::string directory, hipStream_t stream) : a_(a), ai_(ai), dir_(std::move(directory)), stream_(stream) {}
+    typedef std::vector<std::pair<uint32_t, bt_tile_coordinate>> Tiles;
+    TileSaver(bt_atlas* a, hipStream_t stream) : a_(a), stream_(stream) {}
     ~TileSaver() {
         if (writers_)
             for (uint32_t k = 0; k < kBuffers; k++) writers_->wait_buffer(k);
@@ -699,11 +743,10 @@ class TileSaver {
             if (copied_[k]) hipEventDestroy(copied_[k]);
     }
     bt_status begin() {
-        const Attachment& at = a_->attachments[ai_];
-        if (bt_status s = make_dirs(dir_)) return s;
         BT_HIP(hipSetDevice(a_->ctx->device));
-        chunk_ = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (32ull << 20) / at.tile_bytes)));
-        if (bt_status s = ctx_staging(a_->ctx, std::max<size_t>(32ull << 20, at.tile_bytes))) return s;
+        size_t largest = 32ull << 20;
+        for (const Attachment& at : a_->attachments) largest = std::max<size_t>(largest, at.tile_bytes);
+        if (bt_status s = ctx_staging(a_->ctx, largest)) return s;
         for (uint32_t k = 0; k < kBuffers; k++) {
             hipError_t e = hipEventCreateWithFlags(&copied_[k], hipEventDisableTiming);
             if (e != hipSuccess) return hip_fail(e, "save events");
@@ -720,16 +763,21 @@ class TileSaver {
     }
     // taper: the call's last tiles travel in shrinking chunks (half of what is left, down to 8 tiles) — full-size chunks keep the
     // copy engine at its rate, the small ones at the very end shorten the writers' tail behind the last copy
-    bt_status add(std::vector<std::pair<uint32_t, bt_tile_coordinate>> tiles, bool taper = false) {
-        const Attachment& at = a_->attachments[ai_];
+    bt_status add(uint32_t ai, const std::string& dir, Tiles tiles, bool taper = false) {
+        const Attachment& at = a_->attachments[ai];
         void** pinned = a_->ctx->staging;
+        if (std::find(dirs_.begin(), dirs_.end(), dir) == dirs_.end()) {
+            if (bt_status s = make_dirs(dir)) return s;
+            dirs_.push_back(dir);
+        }
+        const uint32_t chunk = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (32ull << 20) / at.tile_bytes)));
         std::sort(tiles.begin(), tiles.end(), [](const auto& l, const auto& r) { return l.first < r.first; });
         tiles.erase(std::unique(tiles.begin(), tiles.end(), [](const auto& l, const auto& r) { return l.first == r.first && operator_eq(l.second, r.second); }),
                     tiles.end());
         const size_t n = tiles.size();
         for (size_t lo = 0, step = 0; lo < n; lo += step) {
-            step = chunk_;
-            if (taper && n - lo <= 2 * size_t(chunk_)) step = std::max<size_t>(std::min<size_t>(8, chunk_), (n - lo) / 2);
+            step = chunk;
+            if (taper && n - lo <= 2 * size_t(chunk)) step = std::max<size_t>(std::min<size_t>(8, chunk), (n - lo) / 2);
             const size_t hi = std::min(n, lo + step);
             const uint32_t k = uint32_t(chunks_++ % kBuffers);
             writers_->wait_buffer(k);
@@ -762,7 +810,10 @@ class TileSaver {
             if (bt_status s = hand_over()) return s;  // the chunk enqueued BEFORE this one: wait for its copies, queue its files
             in_flight_.assign(tiles.begin() + lo, tiles.begin() + hi);
             in_flight_buffer_ = k;
+            in_flight_ai_ = ai;
+            in_flight_dir_ = dir;
             have_in_flight_ = true;
+            saved_bytes_ += uint64_t(hi - lo) * at.tile_bytes;
         }
         return BT_OK;
     }
@@ -771,42 +822,43 @@ class TileSaver {
         for (uint32_t k = 0; k < kBuffers; k++) writers_->wait_buffer(k);
         return writers_->status();
     }
+    uint64_t saved_bytes() const { return saved_bytes_; }
 
   private:
     static constexpr uint32_t kBuffers = bt_ctx::kStagingBuffers;
     bt_status hand_over() {
         if (!have_in_flight_) return BT_OK;
         have_in_flight_ = false;
-        const Attachment& at = a_->attachments[ai_];
+        const Attachment& at = a_->attachments[in_flight_ai_];
         hipError_t e = hipEventSynchronize(copied_[in_flight_buffer_]);
         if (e != hipSuccess) return hip_fail(e, "tile download");
         std::vector<FileWriters::Job> jobs;
         for (size_t i = 0; i < in_flight_.size(); i++) {
             char name[64];
             bt_tile_name(in_flight_[i].second, name, sizeof name);
-            jobs.push_back({dir_ + "/" + name + ".bin", (const uint8_t*)a_->ctx->staging[in_flight_buffer_] + at.tile_bytes * i, size_t(at.tile_bytes), in_flight_buffer_});
+            jobs.push_back({in_flight_dir_ + "/" + name + ".bin", (const uint8_t*)a_->ctx->staging[in_flight_buffer_] + at.tile_bytes * i, size_t(at.tile_bytes), in_flight_buffer_});
         }
         writers_->push(std::move(jobs));
         return BT_OK;
     }
     bt_atlas* a_;
-    uint32_t ai_;
-    std::string dir_;
     hipStream_t stream_;
-    uint32_t chunk_ = 1;
     size_t chunks_ = 0;
     hipEvent_t copied_[kBuffers] = {};
     std::unique_ptr<FileWriters> writers_;
-    std::vector<std::pair<uint32_t, bt_tile_coordinate>> in_flight_;
-    uint32_t in_flight_buffer_ = 0;
+    std::vector<std::string> dirs_;  // directories that exist by now
+    Tiles in_flight_;
+    uint32_t in_flight_buffer_ = 0, in_flight_ai_ = 0;
+    std::string in_flight_dir_;
     bool have_in_flight_ = false;
+    uint64_t saved_bytes_ = 0;
 };
 
 bt_status save_tiles(bt_atlas* a, uint32_t ai, const char* directory, std::vector<std::pair<uint32_t, bt_tile_coordinate>> tiles) {
     if (tiles.empty()) return make_dirs(directory);
-    TileSaver saver(a, ai, directory, a->ctx->stream);
+    TileSaver saver(a, a->ctx->stream);
     if (bt_status s = saver.begin()) return s;
-    if (bt_status s = saver.add(std::move(tiles))) return s;
+    if (bt_status s = saver.add(ai, directory, std::move(tiles))) return s;
     return saver.finish();
 }
 
@@ -985,6 +1037,7 @@ bt_status bt_atlas_load_tiles(bt_atlas* a, uint32_t ai, const char* directory, c
             for (size_t t = 0; t < index[k].size();) {  // runs of consecutive layers are one copy
                 size_t run = 1;
                 while (t + run < index[k].size() && index[k][t + run] == index[k][t] + run) run++;
+                a->attachments[ai].mark_written(index[k][t], uint32_t(run));
                 hipError_t e = hipMemcpyAsync((uint8_t*)at.level0 + at.tile_bytes * index[k][t], (const uint8_t*)pinned[k] + at.tile_bytes * t,
                                               at.tile_bytes * run, hipMemcpyHostToDevice, a->ctx->stream);
                 if (e != hipSuccess) return hip_fail(e, "tile upload");
@@ -1083,7 +1136,8 @@ bt_status bt_atlas_update(bt_atlas* a, const char* assets_root, uint32_t max_loa
                 continue;
             }
             const AtlasTileAttachment& t = batch[k];
-            const Attachment& at = a->attachments[t.attachment_index];
+            Attachment& at = a->attachments[t.attachment_index];
+            at.mark_written(t.atlas_index, 1);
             hipError_t e = hipMemcpyAsync((uint8_t*)at.level0 + at.tile_bytes * t.atlas_index, (const uint8_t*)pinned + largest * k, at.tile_bytes,
                                           hipMemcpyHostToDevice, a->ctx->stream);
             if (e != hipSuccess) rc = hip_fail(e, "tile upload");
@@ -1501,21 +1555,25 @@ bt_status bt_preprocessor_save(bt_preprocessor* p, bt_atlas* a, const char* asse
 
 namespace bt {
 bool fused_source_window(const bt_preprocessor* p, uint32_t raster, uint32_t out[4]);
+bt_status shard_exchange(bt_preprocessor* p, bt_atlas* a, bt_comm* comm, hipStream_t stream, bool distributed);  // bt_comm.cpp: the grouped collective of a sharded step
+bt_status shard_check_comm(const bt_preprocessor* p, const bt_comm* comm);
 
 // Deferred host rasters travel when the queue runs.  A SHARDED preprocessor (compiled plan known) uploads only the texels its
 // own launches read — its column strips + halo (a rank never touches the rest of the source).  What has travelled is
-// remembered per raster (Raster::uploaded): when a kept queue is compiled again — another rank / world (bt_preprocessor_set_shard),
-// BT_RUN_GENERIC or BT_RUN_REFERENCE_DISPATCH, whose launches read the whole raster — and its launches read texels outside that
-// window, the missing part travels before the run (the caller keeps the rows of a deferred raster alive until the queue is released).
-bt_status upload_pending_rasters(bt_preprocessor* p) {
+// remembered per raster (Raster::windows, every rectangle the device holds): when a kept queue is compiled again — another rank / world
+// (bt_preprocessor_set_shard), BT_RUN_GENERIC or BT_RUN_REFERENCE_DISPATCH, whose launches read the whole raster — and its launches read
+// texels outside every such rectangle, the missing window travels before the run (the caller keeps the rows of a deferred raster alive
+// until the queue is RELEASED: the ABI-6 lifetime rule of bt_raster).  A borrowed device raster that is not 16-byte aligned is copied into
+// its padded buffer by EVERY run ("borrowed" means "read at run time", whatever the width).  skip[i] != 0: raster i is handled by the
+// caller (the streamed run uploads it band by band).
+bt_status upload_pending_rasters(bt_preprocessor* p, const std::vector<uint8_t>* skip) {
     for (size_t i = 0; i < p->rasters.size(); i++) {
         Raster& r = p->rasters[i];
-        if (r.dev_src) {  // a borrowed, unaligned device raster: its padded copy is made when the queue first runs
-            if (r.pending) {
-                const uint64_t px2 = r.format == BT_FORMAT_R16 ? 2 : 4;
-                BT_HIP(hipMemcpy2DAsync((void*)r.dev.data, r.dev.pitch, r.dev_src, r.dev_src_pitch, uint64_t(r.dev.width) * px2, r.dev.height, hipMemcpyDeviceToDevice, p->ctx->stream));
-                r.pending = false;
-            }
+        if (skip && i < skip->size() && (*skip)[i]) continue;
+        if (r.dev_src) {
+            const uint64_t px2 = r.format == BT_FORMAT_R16 ? 2 : 4;
+            BT_HIP(hipMemcpy2DAsync((void*)r.dev.data, r.dev.pitch, r.dev_src, r.dev_src_pitch, uint64_t(r.dev.width) * px2, r.dev.height, hipMemcpyDeviceToDevice, p->ctx->stream));
+            r.pending = false;
             continue;
         }
         if (!r.host) continue;  // not a deferred raster
@@ -1528,23 +1586,24 @@ bt_status upload_pending_rasters(bt_preprocessor* p) {
             w[3] = r.dev.height;
         }
         const bool empty = !(w[2] > w[0] && w[3] > w[1]);
-        const bool covered = empty || (r.uploaded[2] > r.uploaded[0] && w[0] >= r.uploaded[0] && w[1] >= r.uploaded[1] && w[2] <= r.uploaded[2] && w[3] <= r.uploaded[3]);
+        const bool covered = empty || r.holds(w);
         if (!r.pending && covered) continue;
-        p->uploaded_source_bytes = 0;
-        if (!empty && !covered) {
-            if (w[0] == 0 && w[1] == 0 && w[2] == r.dev.width && w[3] == r.dev.height && r.host_pitch == r.dev.pitch) {
-                BT_HIP(hipMemcpyAsync((void*)r.dev.data, r.host, r.host_bytes, hipMemcpyHostToDevice, p->ctx->stream));
-                p->uploaded_source_bytes = r.host_bytes;
-            } else {  // a window, or a padded device copy: pitched
-                const uint64_t off_dev = uint64_t(w[1]) * r.dev.pitch + uint64_t(w[0]) * px, off_host = uint64_t(w[1]) * r.host_pitch + uint64_t(w[0]) * px;
-                BT_HIP(hipMemcpy2DAsync((uint8_t*)r.dev.data + off_dev, r.dev.pitch, (const uint8_t*)r.host + off_host, r.host_pitch, (w[2] - w[0]) * px, w[3] - w[1],
-                                        hipMemcpyHostToDevice, p->ctx->stream));
-                p->uploaded_source_bytes = uint64_t(w[2] - w[0]) * px * (w[3] - w[1]);
-            }
-            BT_HIP(hipStreamSynchronize(p->ctx->stream));
-            // (a window that does not contain the previous one replaces it in the record: the device still holds both, the record stays conservative)
-            for (int k = 0; k < 4; k++) r.uploaded[k] = w[k];
+        p->uploaded_source_bytes = 0;  // (the last deferred raster that was looked at: an empty window travels as 0 bytes)
+        if (covered) {
+            r.pending = false;
+            continue;
         }
+        if (w[0] == 0 && w[1] == 0 && w[2] == r.dev.width && w[3] == r.dev.height && r.host_pitch == r.dev.pitch) {
+            BT_HIP(hipMemcpyAsync((void*)r.dev.data, r.host, r.host_bytes, hipMemcpyHostToDevice, p->ctx->stream));
+            p->uploaded_source_bytes = r.host_bytes;
+        } else {  // a window, or a padded device copy: pitched
+            const uint64_t off_dev = uint64_t(w[1]) * r.dev.pitch + uint64_t(w[0]) * px, off_host = uint64_t(w[1]) * r.host_pitch + uint64_t(w[0]) * px;
+            BT_HIP(hipMemcpy2DAsync((uint8_t*)r.dev.data + off_dev, r.dev.pitch, (const uint8_t*)r.host + off_host, r.host_pitch, (w[2] - w[0]) * px, w[3] - w[1],
+                                    hipMemcpyHostToDevice, p->ctx->stream));
+            p->uploaded_source_bytes = uint64_t(w[2] - w[0]) * px * (w[3] - w[1]);
+        }
+        BT_HIP(hipStreamSynchronize(p->ctx->stream));
+        r.add_window(w);
         r.pending = false;
     }
     return BT_OK;
@@ -1557,84 +1616,186 @@ bt_status ctx_side_streams(bt_ctx* ctx) {
     if (!ctx->save_stream) BT_HIP(hipStreamCreateWithFlags(&ctx->save_stream, hipStreamNonBlocking));
     return BT_OK;
 }
-}  // namespace
 
-extern "C" {
+// One step of a streamed run: an upload (optional), a launch — a whole plan entry or a band of a fused main / direct launch — and the
+// tiles that are complete, and may leave, once that launch has run.
+struct StreamStep {
+    size_t plan_index = 0;
+    bool band = false;
+    uint32_t item_begin = 0, item_count = 0;
+    int32_t raster = -1;        // band: rows below `row_end` of this deferred raster travel first (those that have not yet)
+    uint32_t row_end = 0;
+    uint32_t attachment = 0;
+    TileSaver::Tiles early;     // the band's finished finest tiles
+    TileSaver::Tiles rest;      // behind the attachment's last launch: every tile of it that has not left yet
+    bool exchange_before = false;  // a sharded run with a communicator: the grouped collective precedes this step's launch
+};
 
-// The reference's own span (preprocessor.rs:363,419: sources loaded -> all saves done) as ONE overlapped pipeline: the source
-// raster travels to the GPU in bands of tile rows on a copy queue, each band's kernels start when its rows (and the few
-// apron rows below it) have landed, and a second thread downloads and writes a band's finished tiles on a third queue while
-// the next bands upload and run: H2D, kernels, D2H and the file system work at the same time (PCIe is full duplex).  The
-// parent LODs are complete only after the last band + the tail launch and are written last, then config.tc.
-bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* a, const char* assets_root, uint32_t flags, bt_stream_stats* out) {
+bt_status run_streamed_impl(bt_preprocessor* p, bt_atlas* a, bt_comm* comm, const char* assets_root, uint32_t flags, bt_stream_stats* out) {
     if (!p || !a || !assets_root) return BT_ERR_INVALID_ARGUMENT;
     if (p->ctx != a->ctx) {
         set_error("preprocessor and atlas belong to different contexts");
         return BT_ERR_INVALID_ARGUMENT;
     }
-    if (p->shard_world > 1) {
-        set_error("bt_preprocessor_run_streamed: not for sharded preprocessors");
-        return BT_ERR_UNSUPPORTED;
+    const bool sharded = p->shard_world > 1;
+    uint32_t halves = flags & (BT_RUN_SHARD_LOCAL | BT_RUN_SHARD_FINISH);
+    if (!sharded || !halves) halves = BT_RUN_SHARD_LOCAL | BT_RUN_SHARD_FINISH;
+    const bool local = (halves & BT_RUN_SHARD_LOCAL) != 0, finish = (halves & BT_RUN_SHARD_FINISH) != 0;
+    if (sharded && local && finish && !comm) {
+        set_error("bt_preprocessor_run_streamed_sharded: both halves in one call need a communicator (or call BT_RUN_SHARD_LOCAL, exchange, BT_RUN_SHARD_FINISH)");
+        return BT_ERR_INVALID_ARGUMENT;
     }
     BT_HIP(hipSetDevice(p->ctx->device));
     bt_stream_stats st{};
-    if (bt_status s = ensure_compiled(p, a, flags & (BT_RUN_GENERIC | BT_RUN_REFERENCE_DISPATCH))) return s;
-    // streamable: the plan starts with ONE fused main launch over one deferred host raster (planar job, one attachment)
-    int32_t raster = -1;
-    std::vector<StreamBand> bands;
-    uint32_t rows_per_band = 4;
-#ifdef BT_DEBUG_HOOKS
-    if (const char* e = getenv("BT_STREAM_BAND_ROWS")) rows_per_band = uint32_t(std::max(1, atoi(e)));
-#endif
-    bool streamable = !p->plan.empty() && fused_stream_bands(p, p->plan[0], rows_per_band, &raster, &bands) && bands.size() > 1;
-    uint32_t pending = 0;
-    for (const Raster& r : p->rasters) pending += r.pending;
-    streamable = streamable && pending == 1 && p->rasters[size_t(raster)].pending && p->rasters[size_t(raster)].host != nullptr;
-    for (size_t i = 1; streamable && i < p->plan.size(); i++) streamable = p->plan[i].kind != kLaunchFusedMain && p->plan[i].kind != kLaunchFusedDirect;
+    const uint32_t mode = flags & (BT_RUN_GENERIC | BT_RUN_REFERENCE_DISPATCH);
+    if (bt_status s = ensure_compiled(p, a, mode)) return s;
+    if (sharded) {
+        // only the distributed result makes sense here (a replicated atlas has no "share" to write): the finest LOD stays where it was computed
+        if (p->shard_pieces.empty()) {
+            set_error("bt_preprocessor_run_streamed_sharded: the queue does not shard (world %u must divide its units; fused plans only)", p->shard_world);
+            return BT_ERR_UNSUPPORTED;
+        }
+        for (const bt_shard_piece& piece : p->shard_pieces)
+            if (piece.side != p->shard_pieces[0].side) {
+                set_error("BT_RUN_SHARD_DISTRIBUTED needs a one-sided (planar) job: cube seams read finest tiles of other ranks");
+                return BT_ERR_UNSUPPORTED;
+            }
+        p->shard_distributed = true;
+    }
     if (!p->saves_recorded) {
         for (const Task& t : p->queue)
             if (t.type == kSave) a->to_save.push_back({t.coord, t.atlas_index, t.attachment_index});
         p->saves_recorded = true;
     }
+
+    // ---- the steps: the plan's entries in launch order (a sharded step: the local half, the exchange, the finishing half), bandable
+    // launches cut into bands
+    uint32_t rows_per_band = 0;  // automatic
+#ifdef BT_DEBUG_HOOKS
+    if (const char* e = getenv("BT_STREAM_BAND_ROWS")) rows_per_band = uint32_t(std::max(1, atoi(e)));
+#endif
+    std::vector<StreamStep> steps;
+    std::vector<uint8_t> banded_raster(p->rasters.size(), 0);
+    std::vector<std::vector<StreamBand>> bands_of(p->plan.size());
+    for (int half = 0; half < 2; half++) {
+        if (half == 0 ? !local : !finish) continue;
+        bool first_of_half = true;
+        for (size_t i = 0; i < p->plan.size(); i++) {
+            const Launch& l = p->plan[i];
+            if (sharded ? (l.phase == 2) != (half == 1) : half == 1) continue;
+            std::vector<StreamBand>& bands = bands_of[i];
+            bool bandable = fused_stream_bands(p, l, rows_per_band, &bands) && !bands.empty();
+            for (const StreamBand& b : bands) {
+                const Raster& r = p->rasters[b.raster];
+                bandable = bandable && r.host != nullptr && r.pending && !r.dev_src;  // a deferred host raster that has not travelled
+            }
+            StreamStep proto;
+            proto.plan_index = i;
+            proto.attachment = l.attachment;
+            proto.exchange_before = sharded && comm && half == 1 && first_of_half && local;
+            first_of_half = false;
+            if (!bandable) {
+                bands.clear();
+                steps.push_back(proto);
+                continue;
+            }
+            for (size_t k = 0; k < bands.size(); k++) {
+                StreamStep sb = proto;
+                sb.exchange_before = proto.exchange_before && k == 0;
+                sb.band = true;
+                sb.item_begin = bands[k].item_begin;
+                sb.item_count = bands[k].item_count;
+                sb.raster = int32_t(bands[k].raster);
+                // (the last band of a raster takes the rest of it: rows below the last tile row's apron that no kernel reads still count as uploaded)
+                const bool last_of_raster = k + 1 == bands.size() || bands[k + 1].raster != bands[k].raster;
+                sb.row_end = last_of_raster ? p->rasters[bands[k].raster].dev.height : bands[k].source_row_end;
+                banded_raster[bands[k].raster] = 1;
+                steps.push_back(sb);
+            }
+            st.banded_launches++;
+            st.bands += uint32_t(bands.size());
+        }
+    }
+    const bool streamable = st.bands > 1;
     if (!streamable) {  // the same result, one leg after the other
-        if (bt_status s = bt_preprocessor_run(p, a, (flags & (BT_RUN_GENERIC | BT_RUN_REFERENCE_DISPATCH)) | BT_RUN_KEEP_QUEUE)) return s;
-        if (bt_status s = bt_preprocessor_save(p, a, assets_root)) return s;
-        if (out) *out = st;
-        return (flags & BT_RUN_KEEP_QUEUE) ? BT_OK : release_queue(p);
+        const uint32_t keep = mode | BT_RUN_KEEP_QUEUE;
+        if (!sharded) {
+            if (bt_status s = bt_preprocessor_run(p, a, keep)) return s;
+        } else {
+            if (local)
+                if (bt_status s = bt_preprocessor_run(p, a, keep | BT_RUN_SHARD_LOCAL | BT_RUN_SHARD_DISTRIBUTED)) return s;
+            if (local && finish)
+                if (bt_status s = shard_exchange(p, a, comm, p->ctx->stream, true)) return s;
+            if (finish)
+                if (bt_status s = bt_preprocessor_run(p, a, keep | BT_RUN_SHARD_FINISH | BT_RUN_SHARD_DISTRIBUTED)) return s;
+        }
+        if (finish)
+            if (bt_status s = bt_preprocessor_save(p, a, assets_root)) return s;
+        bt_stream_stats none{};
+        if (out) *out = none;
+        return ((flags & BT_RUN_KEEP_QUEUE) || !finish) ? BT_OK : release_queue(p);
     }
     if (bt_status s = ctx_side_streams(p->ctx)) return s;
-    const Launch main = p->plan[0];
-    const uint32_t ai = main.attachment;
-    Raster& r = p->rasters[size_t(raster)];
-    const size_t nb = bands.size();
-    std::vector<hipEvent_t> uploaded(nb, nullptr), computed(nb + 1, nullptr);
-    bt_status rc = BT_OK;
-    auto make_events = [&](std::vector<hipEvent_t>& v) {
-        for (hipEvent_t& e : v)
-            if (rc == BT_OK && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = BT_ERR_DEVICE;
-    };
-    make_events(uploaded);
-    make_events(computed);
 
-    // which tiles to write after which band: the finest tiles of its tile rows; everything else after the last launch
+    // ---- which tiles leave after which step.  A finest tile of a banded launch leaves with its band when nothing later writes it: the
+    // attachment has ONE job in the queue (an overlay or an adjacent dataset would write or stitch it again), and on a cube it does not
+    // touch a face edge (its cross-face aprons are stitched after the last face).  Everything else of an attachment leaves behind the
+    // attachment's last launch.  A sharded rank writes its share only (shard_holder).
     const std::string terrain = std::string(assets_root) + "/" + a->config.path;
-    const std::string dir = terrain + "/data/" + a->attachments[ai].cfg.name;
-    // (entries of other attachments may wait in a->to_save from an earlier, unsaved run: they neither count here nor get lost below)
-    const uint32_t finest = [&] {
-        uint32_t l = 0;
-        for (const AtlasTileAttachment& t : a->to_save)
-            if (t.attachment_index == ai) l = std::max(l, t.coordinate.lod);
-        return l;
-    }();
-    std::vector<std::vector<std::pair<uint32_t, bt_tile_coordinate>>> band_tiles(nb + 1);
-    for (const AtlasTileAttachment& t : a->to_save) {
-        if (t.attachment_index != ai || t.atlas_index == BT_INVALID_ATLAS_INDEX) continue;
-        size_t slot = nb;
-        if (t.coordinate.lod == finest)
-            for (size_t k = 0; k < nb; k++)
-                if (t.coordinate.y >= bands[k].tile_y_begin && t.coordinate.y < bands[k].tile_y_end) { slot = k; break; }
-        band_tiles[slot].push_back({t.atlas_index, t.coordinate});
+    auto dir_of = [&](uint32_t ai) { return terrain + "/data/" + a->attachments[ai].cfg.name; };
+    std::vector<uint32_t> jobs_of(a->attachments.size(), 0);
+    {
+        std::vector<std::vector<uint32_t>> seen(a->attachments.size());
+        for (const Task& t : p->queue)
+            if (t.type == kSplit && std::find(seen[t.attachment_index].begin(), seen[t.attachment_index].end(), t.job) == seen[t.attachment_index].end()) {
+                seen[t.attachment_index].push_back(t.job);
+                jobs_of[t.attachment_index]++;
+            }
     }
+    std::vector<uint8_t> in_plan(a->attachments.size(), 0);
+    for (const StreamStep& sp : steps) in_plan[sp.attachment] = 1;
+    // to_save entries of the attachments this run handles, by (attachment, atlas index)
+    std::vector<std::unordered_map<uint32_t, bt_tile_coordinate>> waiting(a->attachments.size());
+    for (const AtlasTileAttachment& t : a->to_save) {
+        if (t.atlas_index == BT_INVALID_ATLAS_INDEX || !in_plan[t.attachment_index]) continue;
+        if (sharded && shard_holder(p, t.attachment_index, t.coordinate.lod, t.atlas_index) != p->shard_rank) continue;
+        waiting[t.attachment_index][t.atlas_index] = t.coordinate;
+    }
+    const bool spherical = a->config.spherical != 0;
+    for (StreamStep& sp : steps) {
+        if (!sp.band || jobs_of[sp.attachment] != 1) continue;
+        std::vector<FusedTile> tiles;
+        fused_launch_tiles(p, p->plan[sp.plan_index], sp.item_begin, sp.item_count, &tiles);
+        for (const FusedTile& t : tiles) {
+            const bt_tile_coordinate& c = t.coordinate;
+            const uint32_t n = 1u << c.lod;
+            if (spherical && (c.x == 0 || c.y == 0 || c.x == n - 1 || c.y == n - 1)) continue;
+            auto w = waiting[sp.attachment].find(t.atlas_index);
+            if (w == waiting[sp.attachment].end() || !operator_eq(w->second, c)) continue;
+            sp.early.push_back({t.atlas_index, c});
+            waiting[sp.attachment].erase(w);
+        }
+        st.early_tiles += uint32_t(sp.early.size());
+    }
+    if (finish)
+        for (uint32_t ai = 0; ai < a->attachments.size(); ai++) {
+            if (!in_plan[ai] || waiting[ai].empty()) continue;
+            size_t last = steps.size();
+            for (size_t k = 0; k < steps.size(); k++)
+                if (steps[k].attachment == ai) last = k;
+            for (const auto& [index, coord] : waiting[ai]) steps[last].rest.push_back({index, coord});
+        }
+    size_t last_saving = 0;
+    for (size_t k = 0; k < steps.size(); k++)
+        if (!steps[k].early.empty() || !steps[k].rest.empty()) last_saving = k;
+
+    const size_t ns = steps.size();
+    std::vector<hipEvent_t> computed(ns, nullptr);
+    hipEvent_t uploaded = nullptr;
+    bt_status rc = BT_OK;
+    for (hipEvent_t& e : computed)
+        if (rc == BT_OK && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = BT_ERR_DEVICE;
+    if (rc == BT_OK && hipEventCreateWithFlags(&uploaded, hipEventDisableTiming) != hipSuccess) rc = BT_ERR_DEVICE;
 
 #ifdef BT_DEBUG_HOOKS
     const bool trace = getenv("BT_STREAM_TRACE") != nullptr;
@@ -1645,105 +1806,173 @@ bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* a, const ch
 #else
     auto stamp = [](const char*, size_t) {};
 #endif
-    // the saver: band after band as their kernels are enqueued (host handshake), ordered on the GPU by events
+    // the saver: step after step as their kernels are enqueued (host handshake), ordered on the GPU by events
     std::mutex m;
     std::condition_variable cv;
-    size_t launched = 0;  // bands (then nb + 1: everything) whose `computed` event has been recorded
+    size_t launched = 0;  // steps whose `computed` event has been recorded
     bool abort_run = false;
     bt_status save_rc = BT_OK;
     char save_error[512] = "";
+    uint64_t saved_bytes = 0;
     std::thread saver([&] {
         hipSetDevice(p->ctx->device);
-        TileSaver ts(a, ai, dir, p->ctx->save_stream);
+        TileSaver ts(a, p->ctx->save_stream);
         bt_status s = ts.begin();
-        for (size_t k = 0; k <= nb && s == BT_OK; k++) {
+        for (size_t k = 0; k < ns && s == BT_OK; k++) {
+            if (steps[k].early.empty() && steps[k].rest.empty()) continue;
             {
                 std::unique_lock<std::mutex> lock(m);
                 cv.wait(lock, [&] { return launched > k || abort_run; });
                 if (abort_run) break;
             }
             if (hipStreamWaitEvent(p->ctx->save_stream, computed[k], 0) != hipSuccess) s = BT_ERR_DEVICE;
-            stamp("saver: band enqueued by the launcher", k);
-            if (s == BT_OK && !band_tiles[k].empty()) s = ts.add(std::move(band_tiles[k]), k == nb);
-            stamp("saver: band's copies issued, previous chunks handed to the writers", k);
+            stamp("saver: step enqueued by the launcher", k);
+            const std::string dir = dir_of(steps[k].attachment);
+            if (s == BT_OK && !steps[k].early.empty()) s = ts.add(steps[k].attachment, dir, std::move(steps[k].early), k == last_saving && steps[k].rest.empty());
+            if (s == BT_OK && !steps[k].rest.empty()) s = ts.add(steps[k].attachment, dir, std::move(steps[k].rest), k == last_saving);
+            stamp("saver: step's copies issued, previous chunks handed to the writers", k);
         }
         if (s == BT_OK) s = ts.finish();
+        saved_bytes = ts.saved_bytes();
         if (s != BT_OK) {
             snprintf(save_error, sizeof save_error, "%s", bt_last_error());
             save_rc = s;
         }
     });
 
-    // this thread: upload band k (a pageable copy holds the host until it is done; the GPU meanwhile runs band k - 1), launch it
-    const uint8_t* host = (const uint8_t*)r.host;
-    uint8_t* dev = (uint8_t*)r.dev.data;
-    uint64_t done_rows = 0;
+    // this thread: upload what a step needs (a pageable copy holds the host until it is done; the GPU meanwhile runs the step before), launch it
     auto publish = [&](size_t n) {
         { std::lock_guard<std::mutex> lock(m); launched = n; }
         cv.notify_all();
     };
-    for (size_t k = 0; k < nb && rc == BT_OK; k++) {
-        const uint64_t end_row = k + 1 == nb ? r.dev.height : bands[k].source_row_end;
-        if (end_row > done_rows) {
-            stamp("upload begin", k);
-            hipError_t ce;
-            if (r.host_pitch == r.dev.pitch) {
-                const uint64_t off = done_rows * r.dev.pitch, end = std::min<uint64_t>(r.host_bytes, end_row * r.dev.pitch);
-                ce = hipMemcpyAsync(dev + off, host + off, end - off, hipMemcpyHostToDevice, p->ctx->copy_stream);
-            } else {  // a padded device copy (the caller's rows are not 16-byte aligned): the band as a pitched copy
-                const uint64_t row_bytes = uint64_t(r.dev.width) * (r.format == BT_FORMAT_R16 ? 2 : 4);
-                ce = hipMemcpy2DAsync(dev + done_rows * r.dev.pitch, r.dev.pitch, host + done_rows * r.host_pitch, r.host_pitch, row_bytes, end_row - done_rows,
-                                      hipMemcpyHostToDevice, p->ctx->copy_stream);
-            }
-            if (ce != hipSuccess) rc = BT_ERR_DEVICE;
-            stamp("upload call returned", k);
-            done_rows = end_row;
+    // rasters no band covers (a launch that cannot be banded reads them): whole, up front, on the kernels' stream
+    if (rc == BT_OK && local) rc = upload_pending_rasters(p, &banded_raster);
+    if (rc == BT_OK && local) p->stats.prev_zero_launches = fused_begin_run(p, a);
+    // per banded raster: the column window that travels (a sharded rank: its strips + halo) and the rows that have
+    std::vector<std::array<uint32_t, 4>> window(p->rasters.size());
+    std::vector<uint32_t> done_rows(p->rasters.size(), 0);
+    for (size_t i = 0; i < p->rasters.size() && rc == BT_OK; i++) {
+        if (!banded_raster[i]) continue;
+        const Raster& r = p->rasters[i];
+        uint32_t w[4] = {0u, 0u, r.dev.width, r.dev.height};
+        if (!(sharded && fused_source_window(p, uint32_t(i), w))) {
+            w[0] = w[1] = 0;
+            w[2] = r.dev.width;
+            w[3] = r.dev.height;
         }
-        if (rc == BT_OK && hipEventRecord(uploaded[k], p->ctx->copy_stream) != hipSuccess) rc = BT_ERR_DEVICE;
-        if (rc == BT_OK && hipStreamWaitEvent(p->ctx->stream, uploaded[k], 0) != hipSuccess) rc = BT_ERR_DEVICE;
-        if (rc == BT_OK) rc = fused_launch_range(p, a, main, bands[k].item_begin, bands[k].item_count);
+        window[i] = {w[0], w[1], w[2], w[3]};
+        done_rows[i] = w[1];
+    }
+    for (size_t k = 0; k < ns && rc == BT_OK; k++) {
+        const StreamStep& sp = steps[k];
+        const Launch& l = p->plan[sp.plan_index];
+        if (sp.exchange_before) rc = shard_exchange(p, a, comm, p->ctx->stream, true);
+        if (rc != BT_OK) break;
+        if (sp.band) {
+            Raster& r = p->rasters[size_t(sp.raster)];
+            const std::array<uint32_t, 4>& w = window[size_t(sp.raster)];
+            const uint32_t end_row = std::min(sp.row_end, w[3]);
+            uint32_t& done = done_rows[size_t(sp.raster)];
+            if (end_row > done && w[2] > w[0]) {
+                stamp("upload begin", k);
+                const uint64_t px = r.format == BT_FORMAT_R16 ? 2 : 4;
+                const uint8_t* host = (const uint8_t*)r.host;
+                uint8_t* dev = (uint8_t*)r.dev.data;
+                hipError_t ce;
+                if (r.host_pitch == r.dev.pitch && w[0] == 0 && w[2] == r.dev.width) {
+                    const uint64_t off = uint64_t(done) * r.dev.pitch, end = std::min<uint64_t>(r.host_bytes, uint64_t(end_row) * r.dev.pitch);
+                    ce = hipMemcpyAsync(dev + off, host + off, end - off, hipMemcpyHostToDevice, p->ctx->copy_stream);
+                    st.uploaded_bytes += end - off;
+                } else {  // a column window (a sharded rank's strips) or a padded device copy (the caller's rows are not 16-byte aligned): pitched
+                    ce = hipMemcpy2DAsync(dev + uint64_t(done) * r.dev.pitch + w[0] * px, r.dev.pitch, host + uint64_t(done) * r.host_pitch + w[0] * px, r.host_pitch,
+                                          uint64_t(w[2] - w[0]) * px, end_row - done, hipMemcpyHostToDevice, p->ctx->copy_stream);
+                    st.uploaded_bytes += uint64_t(w[2] - w[0]) * px * (end_row - done);
+                }
+                if (ce != hipSuccess) rc = BT_ERR_DEVICE;
+                stamp("upload call returned", k);
+                done = end_row;
+                if (rc == BT_OK && hipEventRecord(uploaded, p->ctx->copy_stream) != hipSuccess) rc = BT_ERR_DEVICE;
+                if (rc == BT_OK && hipStreamWaitEvent(p->ctx->stream, uploaded, 0) != hipSuccess) rc = BT_ERR_DEVICE;
+            }
+            if (rc == BT_OK) rc = fused_launch_range(p, a, l, sp.item_begin, sp.item_count);
+        } else {
+            rc = run_plan_entry(p, a, l);
+        }
         if (rc == BT_OK && hipEventRecord(computed[k], p->ctx->stream) != hipSuccess) rc = BT_ERR_DEVICE;
         if (rc == BT_OK) publish(k + 1);
     }
-    // the raster counts as uploaded only when every band went out; after a failure a later run of the kept queue uploads it whole
-    if (rc == BT_OK) {
-        r.pending = false;
-        r.uploaded[0] = r.uploaded[1] = 0;  // every band has travelled: the whole raster
-        r.uploaded[2] = r.dev.width;
-        r.uploaded[3] = r.dev.height;
-    }
-    for (size_t i = 1; i < p->plan.size() && rc == BT_OK; i++) rc = run_plan_entry(p, a, p->plan[i]);
-    if (rc == BT_OK && hipEventRecord(computed[nb], p->ctx->stream) != hipSuccess) rc = BT_ERR_DEVICE;
-    if (rc == BT_OK) publish(nb + 1);
-    else {
+    // a raster counts as uploaded only when every band of it went out; after a failure a later run of the kept queue uploads it whole
+    if (rc == BT_OK)
+        for (size_t i = 0; i < p->rasters.size(); i++)
+            if (banded_raster[i]) {
+                Raster& r = p->rasters[i];
+                const uint32_t w[4] = {window[i][0], window[i][1], window[i][2], window[i][3]};
+                r.pending = false;
+                if (w[2] > w[0] && w[3] > w[1]) r.add_window(w);
+            }
+    p->uploaded_source_bytes = st.uploaded_bytes;
+    if (rc != BT_OK) {
         { std::lock_guard<std::mutex> lock(m); abort_run = true; }
         cv.notify_all();
     }
-    stamp("all launched", nb);
+    stamp("all launched", ns);
     saver.join();
-    stamp("saver done", nb);
+    stamp("saver done", ns);
     hipStreamSynchronize(p->ctx->stream);
     if (rc != BT_OK || save_rc != BT_OK) {  // nothing of this call may still read the caller's raster or write the pinned buffers
         hipStreamSynchronize(p->ctx->copy_stream);
         hipStreamSynchronize(p->ctx->save_stream);
     }
-    for (hipEvent_t e : uploaded) if (e) hipEventDestroy(e);
     for (hipEvent_t e : computed) if (e) hipEventDestroy(e);
+    if (uploaded) hipEventDestroy(uploaded);
     if (rc == BT_ERR_DEVICE) set_error("bt_preprocessor_run_streamed: HIP call failed (%s)", hipGetErrorString(hipGetLastError()));
     if (rc != BT_OK) return rc;
     if (save_rc != BT_OK) {
         set_error("%s", save_error);
         return save_rc;
     }
-    // the saver wrote exactly the entries of attachment `ai`; whatever else waits in the atlas's list (Save tasks of another
-    // attachment from an earlier run that was not saved yet) goes through bt_preprocessor_save, which also writes config.tc
-    a->to_save.erase(std::remove_if(a->to_save.begin(), a->to_save.end(), [&](const AtlasTileAttachment& t) { return t.attachment_index == ai; }),
+    st.saved_bytes = saved_bytes;
+    // What the saver wrote leaves the atlas's list.  A finishing call wrote every entry of the plan's attachments (a sharded rank: its
+    // share — the others' entries go too, their holders write them); a local-only call only the early tiles.  Whatever else waits (Save
+    // tasks of another attachment from an earlier run that was not saved yet) goes through bt_preprocessor_save, which also writes config.tc.
+    a->to_save.erase(std::remove_if(a->to_save.begin(), a->to_save.end(),
+                                    [&](const AtlasTileAttachment& t) {
+                                        if (!in_plan[t.attachment_index]) return false;
+                                        if (finish) return true;
+                                        const auto& w = waiting[t.attachment_index];
+                                        const bool mine = !sharded || shard_holder(p, t.attachment_index, t.coordinate.lod, t.atlas_index) == p->shard_rank;
+                                        return mine && w.find(t.atlas_index) == w.end();  // (held by this rank and no longer waiting: it left with a band)
+                                    }),
                      a->to_save.end());
-    if (bt_status s = bt_preprocessor_save(p, a, assets_root)) return s;
+    if (finish)
+        if (bt_status s = bt_preprocessor_save(p, a, assets_root)) return s;
     st.streamed = 1;
-    st.bands = uint32_t(nb);
     if (out) *out = st;
-    return (flags & BT_RUN_KEEP_QUEUE) ? BT_OK : release_queue(p);
+    return ((flags & BT_RUN_KEEP_QUEUE) || !finish) ? BT_OK : release_queue(p);
+}
+}  // namespace
+
+extern "C" {
+
+// The reference's own span (preprocessor.rs:363,419: sources loaded -> all saves done) as ONE overlapped pipeline: the source
+// rasters travel to the GPU in bands of tile rows on a copy queue, each band's kernels start when its rows (and the few
+// apron rows below it) have landed, and a second thread downloads and writes a band's finished tiles on a third queue while
+// the next bands upload and run: H2D, kernels, D2H and the file system work at the same time (PCIe is full duplex).  Round 6: every
+// fused main / direct launch of the plan is banded — several attachments (examples/preprocess_planar.rs:16-60), the six faces of a
+// cube job (examples/preprocess_spherical.rs:20-48) — and a sharded rank streams its own window and share.
+bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* a, const char* assets_root, uint32_t flags, bt_stream_stats* out) {
+    if (p && p->shard_world > 1) {
+        set_error("bt_preprocessor_run_streamed: a sharded preprocessor runs through bt_preprocessor_run_streamed_sharded");
+        return BT_ERR_UNSUPPORTED;
+    }
+    return run_streamed_impl(p, a, nullptr, assets_root, flags, out);
+}
+
+bt_status bt_preprocessor_run_streamed_sharded(bt_preprocessor* p, bt_atlas* a, bt_comm* comm, const char* assets_root, uint32_t flags, bt_stream_stats* out) {
+    if (!p) return BT_ERR_INVALID_ARGUMENT;
+    if (comm && p->shard_world > 1)
+        if (bt_status s = shard_check_comm(p, comm)) return s;
+    return run_streamed_impl(p, a, comm, assets_root, flags, out);
 }
 
 bt_status bt_preprocessor_last_run_stats(const bt_preprocessor* p, bt_run_stats* out) {

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cstdint>
 #include <deque>
 #include <string>
@@ -84,6 +85,13 @@ struct Attachment {
     uint64_t tile_bytes = 0;
     void* level0 = nullptr;           // atlas_size x T x T texels
     std::vector<void*> mips;          // level k (k>=1): atlas_size x (T>>k)^2 texels; lazily allocated
+    // written[layer] == 0: the layer still holds bt_atlas_create's zeros (a wgpu texture starts zeroed) — nothing has run on it, been
+    // uploaded or loaded into it, and its device pointer has not been handed out (bt_atlas_attachment_storage marks every layer).  A split of a
+    // job whose finest tiles are all unwritten takes "the previous value" of a no-data pixel (split.wgsl:34-42) as 0 without fetching it.
+    std::vector<uint8_t> written;
+    void mark_written(uint32_t first, uint32_t count) {
+        for (uint64_t i = first; i < uint64_t(first) + count && i < written.size(); i++) written[i] = 1;
+    }
 };
 
 // TileState of the atlas (tile_atlas.rs:260-277): `loading` = 0 is LoadingState::Loaded, n > 0 is Loading(n).
@@ -125,7 +133,20 @@ struct Raster {
     bool pending = false;
     const void* dev_src = nullptr;  // a borrowed device raster that is not 16-byte aligned: copied into the padded buffer `dev` by the first run
     uint64_t dev_src_pitch = 0;
-    uint32_t uploaded[4] = {0, 0, 0, 0};  // the window {x0, y0, x1, y1} of the deferred raster that has travelled (a sharded run: this rank's)
+    // the rectangles {x0, y0, x1, y1} of a deferred raster that have travelled (a sharded run: this rank's window): the device holds each of
+    // them completely; a window counts as present when ONE of them contains it
+    std::vector<std::array<uint32_t, 4>> windows;
+    bool holds(const uint32_t w[4]) const {
+        for (const std::array<uint32_t, 4>& h : windows)
+            if (w[0] >= h[0] && w[1] >= h[1] && w[2] <= h[2] && w[3] <= h[3]) return true;
+        return false;
+    }
+    void add_window(const uint32_t w[4]) {
+        if (holds(w)) return;
+        windows.erase(std::remove_if(windows.begin(), windows.end(), [&](const std::array<uint32_t, 4>& h) { return h[0] >= w[0] && h[1] >= w[1] && h[2] <= w[2] && h[3] <= w[3]; }),
+                      windows.end());
+        windows.push_back({w[0], w[1], w[2], w[3]});
+    }
     uint64_t alloc_bytes = 0;  // size of the owned device allocation
 };
 
@@ -204,17 +225,25 @@ void fused_release(struct ::bt_preprocessor* p);
 bt_status release_queue(struct ::bt_preprocessor* p);  // bt_run.cpp
 bt_status ensure_compiled(struct ::bt_preprocessor* p, struct ::bt_atlas* a, uint32_t mode);  // bt_run.cpp: queue -> launch plan
 bt_status run_plan_entry(struct ::bt_preprocessor* p, struct ::bt_atlas* a, const Launch& l);  // bt_run.cpp: one launch of the plan
-bt_status upload_pending_rasters(struct ::bt_preprocessor* p);  // bt_host.cpp: deferred host rasters, all at once
+uint32_t fused_begin_run(struct ::bt_preprocessor* p, struct ::bt_atlas* a);  // bt_fused.hip: per run, before its launches (FusedArgs::prev_zero, Attachment::written)
+bt_status upload_pending_rasters(struct ::bt_preprocessor* p, const std::vector<uint8_t>* skip = nullptr);  // bt_host.cpp: deferred host rasters, all at once (skip[i]: not raster i)
 
-// streamed run (bt_host.cpp drives it): a fused main launch cut into bands of whole tile rows
+// streamed run (bt_host.cpp drives it): a fused main / direct launch cut into bands of whole tile rows
 struct StreamBand {
-    uint32_t item_begin, item_count;  // into the job's item list (tile-row order)
+    uint32_t item_begin, item_count;  // into the job's item list ((side, tile row, x) order)
     uint32_t tile_y_begin, tile_y_end;
-    uint32_t source_row_end;          // the band's kernels read source rows below this one (exclusive)
+    uint32_t side, raster;            // the cube side of the band's tiles and the source raster they read
+    uint32_t source_row_end;          // the band's kernels read rows of that raster below this one (exclusive)
 };
-// true when plan entry `l` is a fused main launch over ONE planar raster that can run band by band
-bool fused_stream_bands(struct ::bt_preprocessor* p, const Launch& l, uint32_t tile_rows_per_band, int32_t* raster, std::vector<StreamBand>* bands);
+// true when plan entry `l` is a fused main / direct launch that can run band by band (tile_rows_per_band 0: automatic)
+bool fused_stream_bands(struct ::bt_preprocessor* p, const Launch& l, uint32_t tile_rows_per_band, std::vector<StreamBand>* bands);
 bt_status fused_launch_range(struct ::bt_preprocessor* p, struct ::bt_atlas* a, const Launch& l, uint32_t item_begin, uint32_t item_count);
+// the finest tiles [item_begin, item_begin + item_count) of a fused main / direct launch, in launch order
+struct FusedTile {
+    bt_tile_coordinate coordinate;
+    uint32_t atlas_index;
+};
+void fused_launch_tiles(const struct ::bt_preprocessor* p, const Launch& l, uint32_t item_begin, uint32_t item_count, std::vector<FusedTile>* out);
 
 // coordinate math (bt_host.cpp)
 void tile_children(bt_tile_coordinate c, bt_tile_coordinate out[4]);
@@ -242,6 +271,7 @@ struct bt_preprocessor {
     std::vector<bt::Launch> plan;
     bt::TaskDev* tasks_dev = nullptr;
     size_t tasks_dev_cap = 0;
+    std::vector<bt::TaskDev> tasks_host;  // the same records on the host (which layers a batched launch writes: Attachment::written)
     bt::RasterDev* rasters_dev = nullptr;
     size_t rasters_dev_cap = 0;
     bt_run_stats stats{};

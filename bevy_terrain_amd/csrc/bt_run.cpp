@@ -133,6 +133,7 @@ bt_status ensure_compiled(bt_preprocessor* p, bt_atlas* a, uint32_t mode) {
         // synchronous staging of two small arrays; done once per queue, not per run
         if (!tasks.empty()) BT_HIP(hipMemcpy(p->tasks_dev, tasks.data(), tasks.size() * sizeof(TaskDev), hipMemcpyHostToDevice));
         if (!rasters.empty()) BT_HIP(hipMemcpy(p->rasters_dev, rasters.data(), rasters.size() * sizeof(RasterDev), hipMemcpyHostToDevice));
+        p->tasks_host = tasks;
 
         // statistics: algorithmic bytes = every source texel once + every produced tile texel once
         bt_run_stats st{};
@@ -189,12 +190,29 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
     BT_HIP(hipSetDevice(p->ctx->device));
     const uint32_t mode = flags & (BT_RUN_GENERIC | BT_RUN_REFERENCE_DISPATCH);
     if (bt_status s = ensure_compiled(p, a, mode)) return s;
-    if (bt_status s = upload_pending_rasters(p)) return s;  // rasters handed over with BT_RASTER_HOST_DEFERRED (sharded: this rank's window of them)
-
     if ((flags & BT_RUN_PROFILE) != 0 && p->profiled_runs >= kMaxProfiledRuns) {
         set_error("BT_RUN_PROFILE: %u profiled runs are pending; read them with bt_preprocessor_profile() first", kMaxProfiledRuns);
         return BT_ERR_INVALID_ARGUMENT;
     }
+    // every argument check comes before the first profile event and before the atlas bookkeeping: an early error return leaves neither an
+    // orphan event (the rows of p->events would no longer line up with profiled_phases) nor layers marked written by launches that never ran
+    const bool sharded = p->shard_world > 1;
+    if (sharded && (flags & BT_RUN_SHARD_DISTRIBUTED)) {
+        // the finest LOD stays on its owners: possible when nothing after the exchange reads finest tiles of other
+        // ranks, i.e. not for cube jobs (their face seams are stitched from the neighbour face's finest tiles)
+        for (const bt_shard_piece& piece : p->shard_pieces)
+            if (piece.side != p->shard_pieces[0].side) {
+                set_error("BT_RUN_SHARD_DISTRIBUTED needs a one-sided (planar) job: cube seams read finest tiles of other ranks");
+                return BT_ERR_UNSUPPORTED;
+            }
+    }
+    if (sharded && !(flags & (BT_RUN_SHARD_LOCAL | BT_RUN_SHARD_FINISH))) {
+        set_error("a sharded preprocessor runs with BT_RUN_SHARD_LOCAL and / or BT_RUN_SHARD_FINISH");
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    if (sharded) p->shard_distributed = (flags & BT_RUN_SHARD_DISTRIBUTED) != 0 && !p->shard_pieces.empty();
+    if (bt_status s = upload_pending_rasters(p)) return s;  // rasters handed over with BT_RASTER_HOST_DEFERRED (sharded: this rank's window of them)
+
     const bool profile = (flags & BT_RUN_PROFILE) != 0;
     auto record = [&](void) -> bt_status {
         hipEvent_t e;
@@ -210,22 +228,8 @@ extern "C" bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* a, uint32
     };
     if (profile)
         if (bt_status s = record()) return s;
-
-    const bool sharded = p->shard_world > 1;
-    if (sharded && (flags & BT_RUN_SHARD_DISTRIBUTED)) {
-        // the finest LOD stays on its owners: possible when nothing after the exchange reads finest tiles of other
-        // ranks, i.e. not for cube jobs (their face seams are stitched from the neighbour face's finest tiles)
-        for (const bt_shard_piece& piece : p->shard_pieces)
-            if (piece.side != p->shard_pieces[0].side) {
-                set_error("BT_RUN_SHARD_DISTRIBUTED needs a one-sided (planar) job: cube seams read finest tiles of other ranks");
-                return BT_ERR_UNSUPPORTED;
-            }
-    }
-    if (sharded) p->shard_distributed = (flags & BT_RUN_SHARD_DISTRIBUTED) != 0 && !p->shard_pieces.empty();
-    if (sharded && !(flags & (BT_RUN_SHARD_LOCAL | BT_RUN_SHARD_FINISH))) {
-        set_error("a sharded preprocessor runs with BT_RUN_SHARD_LOCAL and / or BT_RUN_SHARD_FINISH");
-        return BT_ERR_INVALID_ARGUMENT;
-    }
+    // (a sharded step's finishing half alone launches no split: the flags of its local half stand)
+    if (!sharded || (flags & BT_RUN_SHARD_LOCAL)) p->stats.prev_zero_launches = fused_begin_run(p, a);
     for (const Launch& l : p->plan) {
         if (sharded && !(flags & (l.phase == 2 ? BT_RUN_SHARD_FINISH : BT_RUN_SHARD_LOCAL))) {
             if (profile)

@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _ffi
 from .terrain import AttachmentFormat
-from .tile_atlas import TileAtlas
+from .tile_atlas import TileAtlas, device_open
 
 
 class AssetServer:
@@ -119,6 +119,12 @@ def _raster_struct(raster, fmt: AttachmentFormat, keep: list, defer_upload: bool
     return r
 
 
+def _stream_stats(st) -> dict:
+    d = {k: getattr(st, k) for k, _ in st._fields_}
+    d["streamed"] = bool(d["streamed"])
+    return d
+
+
 class Preprocessor:
     def __init__(self, device=None):
         self._device = device
@@ -198,13 +204,27 @@ class Preprocessor:
     def run_streamed(self, tile_atlas: TileAtlas, assets_root: str = "assets", *, generic: bool = False, keep_queue: bool = False,
                      reference_dispatch: bool = False) -> dict:
         """run() + save() as one overlapped pipeline (bt_preprocessor_run_streamed): upload of deferred host rasters, kernels,
-        downloads and file writes at the same time where the plan allows it.  Returns {"streamed": bool, "bands": n}."""
+        downloads and file writes at the same time — every fused job of the queue is banded (several attachments, the six faces of a
+        cube job).  Returns bt_stream_stats as a dict: streamed, bands, banded_launches, early_tiles, uploaded_bytes, saved_bytes."""
         st = _ffi.StreamStatsC()
         flags = (_ffi.RUN_GENERIC if generic else 0) | (_ffi.RUN_KEEP_QUEUE if keep_queue else 0) | (_ffi.RUN_REFERENCE_DISPATCH if reference_dispatch else 0)
         _ffi.check(_ffi.lib().bt_preprocessor_run_streamed(self._handle(tile_atlas), tile_atlas._h, assets_root.encode(), flags, C.byref(st)))
         if not keep_queue:
             self._keep.clear()
-        return {"streamed": bool(st.streamed), "bands": st.bands}
+        return _stream_stats(st)
+
+    def run_streamed_sharded(self, tile_atlas: TileAtlas, assets_root: str = "assets", *, comm=None, local: bool = True, finish: bool = True,
+                             keep_queue: bool = False) -> dict:
+        """The end-to-end span of one rank of a sharded job with a distributed result (bt_preprocessor_run_streamed_sharded): this rank's
+        source window uploads band by band, its finest tiles leave band by band, the two parent LODs are exchanged (`comm`: a
+        shard.Communicator handle; None: the caller exchanges between a local=True, finish=False call and a local=False, finish=True
+        call), the finishing kernels run and the rank's share of the lower LODs is written."""
+        st = _ffi.StreamStatsC()
+        flags = (_ffi.RUN_SHARD_LOCAL if local else 0) | (_ffi.RUN_SHARD_FINISH if finish else 0) | (_ffi.RUN_KEEP_QUEUE if keep_queue else 0)
+        _ffi.check(_ffi.lib().bt_preprocessor_run_streamed_sharded(self._handle(tile_atlas), tile_atlas._h, comm, assets_root.encode(), flags, C.byref(st)))
+        if not keep_queue and finish:
+            self._keep.clear()
+        return _stream_stats(st)
 
     def stats(self) -> Dict[str, int]:
         s = _ffi.RunStatsC()
@@ -227,7 +247,9 @@ class Preprocessor:
 
     def close(self):
         if self._h is not None:
-            _ffi.lib().bt_preprocessor_destroy(self._h)
+            # (cyclic garbage collection finalises objects in any order: a preprocessor whose context is gone already must not touch it)
+            if device_open(self._device):
+                _ffi.lib().bt_preprocessor_destroy(self._h)
             self._h = None
 
     def __del__(self):

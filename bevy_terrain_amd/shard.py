@@ -26,7 +26,7 @@ from typing import List, Optional
 
 from . import _ffi
 from .preprocess import AssetServer, PreprocessDataset, Preprocessor
-from .tile_atlas import TileAtlas
+from .tile_atlas import TileAtlas, device_open
 
 
 class _DeviceBytes:
@@ -227,7 +227,7 @@ class ShardedPreprocess:
         return self.pre.profile()
 
     def close(self):
-        if self._comm is not None and self._owns_comm:
+        if self._comm is not None and self._owns_comm and device_open(getattr(self.atlas, "device", None)):
             _ffi.lib().bt_comm_destroy(self._comm)
         self._comm = None
 

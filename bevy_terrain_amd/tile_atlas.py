@@ -11,6 +11,13 @@ from . import _ffi
 from .terrain import AttachmentFormat, TerrainConfig, TileCoordinate
 
 
+def device_open(device) -> bool:
+    """False once the Device (bt_ctx) behind a dependent object has been closed.  Python's cyclic garbage collector finalises the objects of a
+    cycle in any order (an exception traceback that holds an atlas, its preprocessor and the device is such a cycle): a dependent object whose
+    context was destroyed first must not call into the library with it — its native half is then left to the process's exit."""
+    return device is not None and bool(getattr(device, "_h", None))
+
+
 class Device:
     """One GPU + one HIP stream (bt_ctx).  With PyTorch present the context runs on torch's current
     stream of that device, so torch.cuda.Event timing and torch.distributed collectives order with it."""
@@ -253,7 +260,8 @@ class TileAtlas:
 
     def close(self):
         if getattr(self, "_h", None):
-            _ffi.lib().bt_atlas_destroy(self._h)
+            if device_open(getattr(self, "device", None)):
+                _ffi.lib().bt_atlas_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -11,7 +11,7 @@ import numpy as np
 
 from . import _ffi
 from .terrain import TerrainModel, TerrainViewConfig, TileCoordinate
-from .tile_atlas import TileAtlas
+from .tile_atlas import TileAtlas, device_open
 
 
 def model_c(model: TerrainModel) -> _ffi.TerrainModelC:
@@ -132,7 +132,8 @@ class TileTree:
 
     def close(self):
         if getattr(self, "_h", None):
-            _ffi.lib().bt_tile_tree_destroy(self._h)
+            if device_open(getattr(getattr(self, "atlas", None), "device", None)):
+                _ffi.lib().bt_tile_tree_destroy(self._h)
             self._h = None
 
     def __del__(self):

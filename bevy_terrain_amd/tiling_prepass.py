@@ -20,7 +20,7 @@ import numpy as np
 
 from . import _ffi
 from .terrain import C_SQR, TerrainModel, TerrainViewConfig, TileCoordinate
-from .tile_atlas import Device
+from .tile_atlas import Device, device_open
 
 # SideInfo tables of coordinate.rs:27-42 (0 = Fixed0, 1 = Fixed1, 's' / 't')
 _EVEN = [("s", "t"), (0, "t"), (0, "s"), ("t", "s"), ("t", 0), ("s", 0)]
@@ -107,7 +107,8 @@ class TilingPrepass:
 
     def close(self):
         if getattr(self, "_h", None):
-            _ffi.lib().bt_tiling_prepass_destroy(self._h)
+            if device_open(getattr(self, "device", None)):
+                _ffi.lib().bt_tiling_prepass_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -29,14 +29,22 @@
 extern "C" {
 #endif
 
-/* 5 (round 5): + bt_ctx_set_io_threads / bt_ctx_io_threads (writer / reader threads of the save and load paths follow the CPUs the
+/* 6 (round 6): bt_preprocessor_run_streamed pipelines every fused job of a queue (several attachments, the six rasters of a cube job) and
+ * bt_preprocessor_run_streamed_sharded does the same for a BT_RUN_SHARD_DISTRIBUTED rank; bt_stream_stats and bt_run_stats GREW (new
+ * trailing fields: callers must be rebuilt against this header); a split onto layers nothing has written since bt_atlas_create takes
+ * the "previous value" of a no-data pixel as 0 without fetching it (bt_run_stats.prev_zero_launches) — same bytes;
+ * bt_atlas_attachment_storage now counts as a write to every layer of the attachment.  Two BEHAVIOUR CHANGES (not additions): a borrowed
+ * unaligned device raster (on_device = 1) is copied into the library's padded buffer by EVERY run of a kept queue, not only the first
+ * (round 5 froze it at the first run); and the rows of a BT_RASTER_HOST_DEFERRED raster must stay alive until the queue is RELEASED,
+ * not merely until its first run (a kept queue that is re-planned for another rank / mode reads what the device does not hold yet).
+ * 5 (round 5): + bt_ctx_set_io_threads / bt_ctx_io_threads (writer / reader threads of the save and load paths follow the CPUs the
  * process may use), bt_comm_preflight (tile-sized health check of the communicator before the first sharded step) — additions only.
  * 4 (round 4): + bt_frame_update / bt_frame_info, BT_RUN_SHARD_OVERLAP + bt_preprocessor_finish_sharded, bt_preprocessor_source_window, BT_RUN_REFERENCE_DISPATCH, bt_ctx_trim; the fused plan no longer has a fused_todo launch (kind 6 of bt_launch_profile
  * does not occur any more) — additions only.
  * 3 (round 3): + bt_preprocessor_run_streamed, BT_RASTER_HOST_DEFERRED, BT_RUN_SHARD_EXCHANGE, bt_tiling_prepass_run_plain /
  * _run_unordered / _set_window, launch kind 6 (fused todo) in bt_launch_profile — additions only, every version-2 call keeps its
  * meaning. */
-#define BT_ABI_VERSION 5u
+#define BT_ABI_VERSION 6u
 
 typedef int32_t bt_status;
 enum {
@@ -101,14 +109,14 @@ typedef struct bt_raster {
     uint64_t row_pitch;  /* bytes; 0 = tightly packed */
     uint32_t format;     /* BT_FORMAT_R16 or BT_FORMAT_RGBA8; must equal the attachment's */
     uint32_t on_device;  /* 0: host memory (copied to the GPU by the call), 1: device pointer (borrowed
-                            until the preprocessor has run; an R16 raster whose base or pitch is not a multiple of 16 bytes
-                            is copied into a padded buffer by the queue's FIRST run — a kept queue does not see later
-                            changes of it), BT_RASTER_HOST_DEFERRED: host memory that stays the
-                            caller's until the queue has run — copied by bt_preprocessor_run (all at once) or by
+                            until the preprocessor has run and read at run time, on EVERY run of a kept queue; an R16
+                            raster whose base or pitch is not a multiple of 16 bytes is copied device-to-device into a
+                            padded buffer of the library's at the start of each run — up to width x height x 2 bytes of
+                            device memory, 0.15 ms for 0.5 GB), BT_RASTER_HOST_DEFERRED: host memory that stays the
+                            caller's until the queue is RELEASED — copied by bt_preprocessor_run (all at once) or by
                             bt_preprocessor_run_streamed (band by band, beside the kernels and the downloads).  A queue kept
                             with BT_RUN_KEEP_QUEUE may read the rows again (only the window a sharded rank needs travels;
-                            a later bt_preprocessor_set_shard / other run flags fetch what is missing): keep them alive
-                            until the queue is released */
+                            a later bt_preprocessor_set_shard / other run flags fetch what the device does not hold yet) */
 } bt_raster;
 #define BT_RASTER_HOST_DEFERRED 2u
 
@@ -213,7 +221,8 @@ uint32_t bt_atlas_pending_loads(const bt_atlas* atlas);
 /* existing_tiles in atlas-index (= allocation) order. Returns the tile count; fills up to `cap`. */
 uint32_t bt_atlas_tiles(const bt_atlas* atlas, bt_tile_coordinate* coords, uint32_t* atlas_indices, uint32_t cap);
 /* Device storage of one attachment: layer `i` starts at ptr + i*tile_bytes; rows are T*pixel_size
- * bytes, tightly packed, texel layout = the `.bin` tile file layout. */
+ * bytes, tightly packed, texel layout = the `.bin` tile file layout.  The caller may write through the pointer (a host-side
+ * collective does): asking for it (device_ptr != NULL) counts as a write to every layer (bt_run_stats.prev_zero_launches). */
 bt_status bt_atlas_attachment_storage(const bt_atlas* atlas, uint32_t attachment_index, void** device_ptr,
                                       uint64_t* tile_bytes, uint32_t* layers);
 /* download + de-pad (gpu_tile_atlas.rs:338-412): `count` consecutive layers into host memory. */
@@ -310,14 +319,22 @@ bt_status bt_preprocessor_run(bt_preprocessor* p, bt_atlas* atlas, uint32_t flag
  * select_ready_tasks on completion (:358-371), "{assets_root}/{config.path}/config.tc". */
 bt_status bt_preprocessor_save(bt_preprocessor* p, bt_atlas* atlas, const char* assets_root);
 /* The reference's whole span (preprocessor.rs:363,419: all sources loaded -> all saves done) as one overlapped pipeline:
- * = bt_preprocessor_run + bt_preprocessor_save, but for a queue whose plan is one fused job over one
- * BT_RASTER_HOST_DEFERRED raster the source travels to the GPU in bands of tile rows, each band's kernels start when its
- * rows have landed, and its finished tiles are downloaded and written while later bands upload and run (three HIP queues,
- * one extra host thread).  Other queues run the legs one after the other.  Files are byte-identical either way.
- * Synchronous: returns when every file is written.  flags: BT_RUN_GENERIC / BT_RUN_KEEP_QUEUE. */
+ * = bt_preprocessor_run + bt_preprocessor_save, but every fused main / direct launch of the plan whose sources are
+ * BT_RASTER_HOST_DEFERRED rasters runs in bands of tile rows: a band's source rows travel to the GPU, its kernels start when they
+ * have landed, and its finished tiles are downloaded and written while later bands (of the same raster, of the next cube face, of the
+ * next attachment) upload and run — three HIP queues, one extra host thread.  Since ABI 6 that covers both of the reference's examples:
+ * several attachments in one queue (examples/preprocess_planar.rs:16-60: height R16 + albedo Rgba8, one dataset each) and the six face
+ * rasters of a cube job (examples/preprocess_spherical.rs:20-48; the finest tiles on a face edge wait for the seam stitch at the end,
+ * all others leave with their band).  Launches that cannot be banded (generic plan, device rasters) run whole, in plan order; a queue
+ * without any bandable launch runs the legs one after the other.  Files are byte-identical either way.
+ * Synchronous: returns when every file is written.  flags: BT_RUN_GENERIC / BT_RUN_KEEP_QUEUE / BT_RUN_REFERENCE_DISPATCH. */
 typedef struct bt_stream_stats {
     uint32_t streamed; /* 1: the overlapped pipeline ran; 0: upload, kernels and save ran one after the other */
-    uint32_t bands;
+    uint32_t bands;    /* bands of all banded launches together */
+    uint32_t banded_launches; /* fused main / direct launches that ran band by band (ABI 6) */
+    uint32_t early_tiles;     /* tiles downloaded and written before the last launch was issued (ABI 6) */
+    uint64_t uploaded_bytes;  /* source bytes that travelled in this call (a sharded rank: its windows only) (ABI 6) */
+    uint64_t saved_bytes;     /* tile bytes this call downloaded and wrote (a sharded rank: its share) (ABI 6) */
 } bt_stream_stats;
 bt_status bt_preprocessor_run_streamed(bt_preprocessor* p, bt_atlas* atlas, const char* assets_root, uint32_t flags, bt_stream_stats* out);
 /* Launch statistics of the last bt_preprocessor_run: kernels launched, algorithmic bytes
@@ -327,6 +344,10 @@ typedef struct bt_run_stats {
     uint32_t tiles;
     uint64_t algorithmic_bytes;
     uint32_t fused_jobs, generic_jobs;
+    uint32_t prev_zero_launches; /* (ABI 6) fused main / direct launches of the LAST run whose finest tiles nothing had written since
+                                  * bt_atlas_create: "the previous value" of a no-data pixel (split.wgsl:34-42) was taken as the
+                                  * atlas's initial 0 instead of fetched — same bytes, no atlas reads.  0 for re-runs of a kept queue */
+    uint32_t reserved;
 } bt_run_stats;
 bt_status bt_preprocessor_last_run_stats(const bt_preprocessor* p, bt_run_stats* out);
 /* Multi-GPU: tiles shard by column strips of the finest LODs (new design, the reference is single-GPU;
@@ -379,7 +400,9 @@ bt_status bt_comm_check(bt_comm* comm);
 /* The same with slots of `slot_bytes` each (one atlas tile, say): ONE grouped collective — an in-place all-gather of one slot per rank
  * and an in-place broadcast from the last rank — on the context's stream, every byte verified on the host.  Meant to run once before the
  * first sharded step: a communicator that cannot move a tile fails HERE with RCCL's error string (or, if the collective hangs, under
- * the caller's watchdog) instead of inside a timed step.  `elapsed_ms` (may be NULL): device time of the collective. */
+ * the caller's watchdog) instead of inside a timed step.  `elapsed_ms` (may be NULL): device time of the collective.
+ * slot_bytes: 1 .. 64 MiB (world + 1 slots are allocated on the device and on the host).  A HANG IS NOT DETECTED: when the collective
+ * fails on some ranks only, the others block in the stream synchronisation — run it under a watchdog (bench.py --preflight-timeout). */
 bt_status bt_comm_preflight(bt_comm* comm, uint64_t slot_bytes, float* elapsed_ms);
 /* One step of a sharded job, entirely on the context's stream and without host synchronisation: this rank's strip
  * (BT_RUN_SHARD_LOCAL), ONE grouped collective (in-place ncclAllGather per LOD for the regular planar layout, in-place
@@ -390,6 +413,17 @@ bt_status bt_preprocessor_run_sharded(bt_preprocessor* p, bt_atlas* atlas, bt_co
 /* Second half of a BT_RUN_SHARD_OVERLAP step: the context's stream waits for that step's collective, then the finishing kernels
  * run.  flags: BT_RUN_GENERIC / BT_RUN_SHARD_DISTRIBUTED as in the first half, BT_RUN_PROFILE, BT_RUN_KEEP_QUEUE. */
 bt_status bt_preprocessor_finish_sharded(bt_preprocessor* p, bt_atlas* atlas, bt_comm* comm, uint32_t flags);
+/* The end-to-end span of a SHARDED job with a distributed result (BT_RUN_SHARD_DISTRIBUTED is implied; planar jobs): every rank is one
+ * PCIe link.  Rank r uploads only its source window band by band (bt_preprocessor_source_window), runs its units, writes its finest
+ * tiles band by band while later bands upload and run, exchanges the two parent LODs (the grouped collective of
+ * bt_preprocessor_run_sharded, on the context's stream), runs the finishing kernels and writes its share of the lower LODs (every
+ * world-th tile; config.tc from rank 0): the ranks together produce the reference's directory, one writer per file.
+ * `comm` may be NULL for hosts that bring their own collective: call once with BT_RUN_SHARD_LOCAL (upload + local kernels + this rank's
+ * finest files), exchange bt_preprocessor_shard_ranges / _pieces below the finest LOD yourself, call again with BT_RUN_SHARD_FINISH
+ * (finishing kernels + the rest of this rank's files).  With `comm`: pass both flags (or neither) — one call does everything.
+ * Other flags: BT_RUN_KEEP_QUEUE.  A preprocessor that is not sharded (world 1) behaves like bt_preprocessor_run_streamed. */
+bt_status bt_preprocessor_run_streamed_sharded(bt_preprocessor* p, bt_atlas* atlas, bt_comm* comm, const char* assets_root, uint32_t flags,
+                                               bt_stream_stats* out);
 
 /* Per-launch device time of the runs made with BT_RUN_PROFILE since the last call (hipEvents on the
  * context's stream, averaged over those runs).  `kind`: 0 split, 1 downsample, 2 stitch, 3 fused main,

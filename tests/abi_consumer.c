@@ -21,7 +21,8 @@ STATIC_ASSERT(sizeof(bt_raster) == 32 && offsetof(bt_raster, row_pitch) == 16 &&
 STATIC_ASSERT(sizeof(bt_preprocess_dataset) == 32 && offsetof(bt_preprocess_dataset, lod_begin) == 24, preprocess_dataset);
 STATIC_ASSERT(sizeof(bt_spherical_dataset) == 12, spherical_dataset);
 STATIC_ASSERT(sizeof(bt_tile_lookup) == 16, tile_lookup);
-STATIC_ASSERT(sizeof(bt_run_stats) == 24 && offsetof(bt_run_stats, algorithmic_bytes) == 8, run_stats);
+STATIC_ASSERT(sizeof(bt_run_stats) == 32 && offsetof(bt_run_stats, algorithmic_bytes) == 8 && offsetof(bt_run_stats, prev_zero_launches) == 24, run_stats);
+STATIC_ASSERT(sizeof(bt_stream_stats) == 32 && offsetof(bt_stream_stats, uploaded_bytes) == 16, stream_stats);
 STATIC_ASSERT(sizeof(bt_shard_range) == 20, shard_range);
 STATIC_ASSERT(sizeof(bt_launch_profile) == 24 && offsetof(bt_launch_profile, avg_ms) == 16, launch_profile);
 STATIC_ASSERT(sizeof(bt_side_parameter) == 16, side_parameter);
@@ -58,7 +59,8 @@ int main(int argc, char** argv) {
     BEGIN(bt_preprocess_dataset); FIELD(bt_preprocess_dataset, attachment_index); FIELD(bt_preprocess_dataset, side); FIELD(bt_preprocess_dataset, top_left); FIELD(bt_preprocess_dataset, bottom_right); FIELD(bt_preprocess_dataset, lod_begin); FIELD(bt_preprocess_dataset, lod_end); END(bt_preprocess_dataset);
     BEGIN(bt_spherical_dataset); FIELD(bt_spherical_dataset, attachment_index); FIELD(bt_spherical_dataset, lod_begin); FIELD(bt_spherical_dataset, lod_end); END(bt_spherical_dataset);
     BEGIN(bt_tile_tree_entry); FIELD(bt_tile_tree_entry, atlas_index); FIELD(bt_tile_tree_entry, atlas_lod); END(bt_tile_tree_entry);
-    BEGIN(bt_run_stats); FIELD(bt_run_stats, kernel_launches); FIELD(bt_run_stats, tiles); FIELD(bt_run_stats, algorithmic_bytes); FIELD(bt_run_stats, fused_jobs); FIELD(bt_run_stats, generic_jobs); END(bt_run_stats);
+    BEGIN(bt_run_stats); FIELD(bt_run_stats, kernel_launches); FIELD(bt_run_stats, tiles); FIELD(bt_run_stats, algorithmic_bytes); FIELD(bt_run_stats, fused_jobs); FIELD(bt_run_stats, generic_jobs); FIELD(bt_run_stats, prev_zero_launches); FIELD(bt_run_stats, reserved); END(bt_run_stats);
+    BEGIN(bt_stream_stats); FIELD(bt_stream_stats, streamed); FIELD(bt_stream_stats, bands); FIELD(bt_stream_stats, banded_launches); FIELD(bt_stream_stats, early_tiles); FIELD(bt_stream_stats, uploaded_bytes); FIELD(bt_stream_stats, saved_bytes); END(bt_stream_stats);
     BEGIN(bt_shard_range); FIELD(bt_shard_range, attachment_index); FIELD(bt_shard_range, side); FIELD(bt_shard_range, lod); FIELD(bt_shard_range, first_layer); FIELD(bt_shard_range, layers_per_rank); END(bt_shard_range);
     BEGIN(bt_launch_profile); FIELD(bt_launch_profile, kind); FIELD(bt_launch_profile, tasks); FIELD(bt_launch_profile, algorithmic_bytes); FIELD(bt_launch_profile, avg_ms); FIELD(bt_launch_profile, samples); END(bt_launch_profile);
     BEGIN(bt_side_parameter); FIELD(bt_side_parameter, view_xy); FIELD(bt_side_parameter, view_uv); END(bt_side_parameter);

@@ -603,7 +603,8 @@ def test_streamed_run_writes_the_same_files(device, tmp_path, holes):
                             defer_upload=streamed)
         if streamed:
             st = pre.run_streamed(atlas, root)
-            assert st == {"streamed": True, "bands": 4}
+            assert st["streamed"] and st["bands"] == 4 and st["banded_launches"] == 1 and st["early_tiles"] == 256
+            assert st["uploaded_bytes"] == size * size * 2 and st["saved_bytes"] == 341 * 512 * 512 * 2
         else:
             pre.run(atlas)
             pre.save(atlas, root)
@@ -809,7 +810,7 @@ def test_streamed_run_pads_a_deferred_raster_of_unaligned_pitch(device, tmp_path
                             defer_upload=streamed)
         if streamed:
             st = pre.run_streamed(atlas, root)
-            assert st["streamed"] and st["bands"] == 2
+            assert st["streamed"] and st["bands"] == 4  # (8 tile rows: bands of 2)
         else:
             pre.run(atlas)
             pre.save(atlas, root)
@@ -863,3 +864,218 @@ def test_32k_job_seven_lods_beyond_the_bench_size(device):
     picked = sorted(set(range(0, n_tiles, 11)) | set(range(n_tiles - 341, n_tiles)))  # a sample of the two finest LODs + LODs 0 .. 4 completely
     for i in picked:
         assert np.array_equal(atlas.download_tiles(0, i, 1)[0], oracle.tile(0, i)), (i, oracle.tiles()[i])
+
+
+def _files_equal(dir_a, dir_b, count):
+    names = sorted(os.listdir(dir_a))
+    assert names == sorted(os.listdir(dir_b)) and len(names) == count, (len(names), count)
+    for n in names:
+        assert open(os.path.join(dir_a, n), "rb").read() == open(os.path.join(dir_b, n), "rb").read(), n
+
+
+@pytest.mark.parametrize("holes", [False, True])
+def test_streamed_run_two_attachments_like_preprocess_planar(device, tmp_path, holes):
+    """examples/preprocess_planar.rs:16-60 end to end: height (R16) + albedo (Rgba8) of 4096^2 in ONE queue, both rasters handed over
+    deferred.  The streamed pipeline bands fused_main AND fused_direct (4 bands of 2 tile rows each), interleaves the two attachments'
+    uploads, kernels and saves; its files are byte-identical to run() + save() and its atlas to the oracle's (both attachments)."""
+    W, lods = 4096, 4
+    height = K.smooth_raster(W, W, seed=1234, device=device)
+    rng = np.random.default_rng(1235)
+    albedo = rng.integers(1, 256, size=(W, W, 4), dtype=np.uint8)
+    albedo[..., 3] = 255
+    if holes:
+        height[1000:1100, 500:2500] = 0  # across the band seam between tile rows 1 | 2 (mosaic row 1016)
+        height[4000:4096, 0:300] = 0
+        albedo[2020:2050, 100:4000, 0] = 0  # across tile rows 3 | 4
+        albedo[0:40, 4000:4096, 0] = 0
+    cfg = bt.TerrainConfig(lod_count=lods, path="terrains/planar", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=512, border_size=2, format=bt.AttachmentFormat.R16))
+    cfg.add_attachment(bt.AttachmentConfig(name="albedo", texture_size=512, border_size=2, format=bt.AttachmentFormat.Rgba8))
+    server = bt.AssetServer().insert("h", height).insert("a", albedo)
+    roots = []
+    for streamed in (False, True):
+        root = str(tmp_path / ("streamed" if streamed else "serial"))
+        atlas = bt.TileAtlas.new(cfg, device)
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas, root).clear_attachment(1, atlas, root)
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="h", lod_range=range(0, lods)), server, atlas, defer_upload=streamed)
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=1, path="a", lod_range=range(0, lods)), server, atlas, defer_upload=streamed)
+        if streamed:
+            st = pre.run_streamed(atlas, root)
+            assert st["streamed"] and st["banded_launches"] == 2 and st["bands"] == 8 and st["early_tiles"] == 128
+            assert st["uploaded_bytes"] == W * W * 6 and st["saved_bytes"] == 85 * 512 * 512 * 6
+        else:
+            pre.run(atlas)
+            pre.save(atlas, root)
+        roots.append((root, atlas))
+    for ai in (0, 1):
+        _files_equal(roots[0][1].attachment_directory(roots[0][0], ai), roots[1][1].attachment_directory(roots[1][0], ai), 85)
+    assert open(os.path.join(roots[0][0], "terrains/planar/config.tc"), "rb").read() == open(os.path.join(roots[1][0], "terrains/planar/config.tc"), "rb").read()
+    oracle = O.OracleAtlas(lods, 1024, False, [(512, 2, 1, O.FORMAT_R16), (512, 2, 1, O.FORMAT_RGBA8)])
+    oracle.clear_attachment(0).clear_attachment(1)
+    oracle.preprocess_tile(0, height, (0, lods)).preprocess_tile(1, albedo, (0, lods)).run(O.usable_cores())
+    assert K.assert_atlas_equal(roots[1][1], oracle, 0) == 85
+    assert K.assert_atlas_equal(roots[1][1], oracle, 1) == 85
+
+
+@pytest.mark.parametrize("fmt", [O.FORMAT_R16, O.FORMAT_RGBA8])
+def test_streamed_run_cube_job_like_preprocess_spherical(device, tmp_path, fmt):
+    """examples/preprocess_spherical.rs:20-48 end to end: six deferred face rasters (2048^2, T = 512, lod_count 3 -> 4 x 4 finest tiles
+    per face, 126 tiles).  A face's bands upload while the previous face's kernels and downloads run; the finest tiles on a face edge
+    wait for the seam stitch behind the last face (12 of 16 per face), the interior ones leave with their band.  Files byte-identical
+    to the serial path's, atlas identical to the oracle's."""
+    W, lods, T = 2048, 3, 512
+    faces = []
+    for s in range(6):
+        h = K.smooth_raster(W, W, seed=300 + s, device=device)
+        if fmt == O.FORMAT_R16:
+            h[500 + 37 * s:560 + 37 * s, 0:700] = 0  # no data up to a face edge (the seam copies what the neighbour's centre holds)
+            faces.append(h)
+        else:
+            rgba = np.empty((W, W, 4), np.uint8)
+            rgba[..., 0] = np.maximum(h >> 8, 1)
+            rgba[..., 1] = h & 255
+            rgba[..., 2] = (h >> 3) & 255
+            rgba[..., 3] = 255
+            rgba[1500:1530, 1200 + 11 * s:2048, 0] = 0
+            faces.append(rgba)
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=256, path="terrains/spherical")
+    cfg.add_attachment(bt.AttachmentConfig(name="att", texture_size=T, border_size=2, format=K.FMT[fmt]))
+    server = bt.AssetServer()
+    paths = [f"face{s}" for s in range(6)]
+    for pth, f in zip(paths, faces):
+        server.insert(pth, f)
+    roots = []
+    for streamed in (False, True):
+        root = str(tmp_path / ("streamed" if streamed else "serial"))
+        atlas = bt.TileAtlas.new(cfg, device)
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas, root).preprocess_spherical(
+            bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lods)), server, atlas, defer_upload=streamed)
+        if streamed:
+            st = pre.run_streamed(atlas, root)
+            assert st["streamed"] and st["banded_launches"] == 1 and st["bands"] == 24 and st["early_tiles"] == 6 * 4
+            px = 2 if fmt == O.FORMAT_R16 else 4
+            assert st["uploaded_bytes"] == 6 * W * W * px and st["saved_bytes"] == 126 * T * T * px
+        else:
+            pre.run(atlas)
+            pre.save(atlas, root)
+        roots.append((root, atlas))
+    _files_equal(roots[0][1].attachment_directory(roots[0][0], 0), roots[1][1].attachment_directory(roots[1][0], 0), 126)
+    assert open(os.path.join(roots[0][0], "terrains/spherical/config.tc"), "rb").read() == open(os.path.join(roots[1][0], "terrains/spherical/config.tc"), "rb").read()
+    oracle = O.OracleAtlas(lods, 256, True, [(T, 2, 1, fmt)])
+    oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(O.usable_cores())
+    assert K.assert_atlas_equal(roots[1][1], oracle) == 126
+
+
+def test_streamed_run_bands_what_it_can_and_runs_the_rest_whole(device, tmp_path):
+    """One queue, two jobs: the first raster is handed over deferred (its fused_main launch is banded, its finest tiles leave early), the
+    second was uploaded by preprocess_tile (nothing to stream: its launch runs whole, in plan order, its tiles leave behind it).
+    Files == serial path, atlas == oracle."""
+    W, lods = 2048, 3
+    a_src = K.smooth_raster(W, W, seed=5, device=device)
+    b_src = K.smooth_raster(W, W, seed=6, device=device)
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=64, path="terrains/mixed", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="one", texture_size=512, border_size=2, format=bt.AttachmentFormat.R16))
+    cfg.add_attachment(bt.AttachmentConfig(name="two", texture_size=512, border_size=2, format=bt.AttachmentFormat.R16))
+    server = bt.AssetServer().insert("a", a_src).insert("b", b_src)
+    roots = []
+    for streamed in (False, True):
+        root = str(tmp_path / ("streamed" if streamed else "serial"))
+        atlas = bt.TileAtlas.new(cfg, device)
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas, root).clear_attachment(1, atlas, root)
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="a", lod_range=range(0, lods)), server, atlas, defer_upload=streamed)
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=1, path="b", lod_range=range(0, lods)), server, atlas, defer_upload=False)
+        if streamed:
+            st = pre.run_streamed(atlas, root)
+            assert st["streamed"] and st["banded_launches"] == 1 and st["bands"] == 4 and st["early_tiles"] == 16
+            assert st["uploaded_bytes"] == W * W * 2 and st["saved_bytes"] == 2 * 21 * 512 * 512 * 2
+        else:
+            pre.run(atlas)
+            pre.save(atlas, root)
+        roots.append((root, atlas))
+    for ai in (0, 1):
+        _files_equal(roots[0][1].attachment_directory(roots[0][0], ai), roots[1][1].attachment_directory(roots[1][0], ai), 21)
+    oracle = O.OracleAtlas(lods, 64, False, [(512, 2, 1, O.FORMAT_R16), (512, 2, 1, O.FORMAT_R16)])
+    oracle.clear_attachment(0).clear_attachment(1).preprocess_tile(0, a_src, (0, lods)).preprocess_tile(1, b_src, (0, lods)).run(O.usable_cores())
+    assert K.assert_atlas_equal(roots[1][1], oracle, 0) == 21 and K.assert_atlas_equal(roots[1][1], oracle, 1) == 21
+
+
+def test_streamed_run_of_an_overlay_keeps_its_tiles_until_the_last_job(device, tmp_path):
+    """Two datasets onto the SAME tiles of one attachment (the second overlays the first where it has data): a tile must not leave
+    with the first job's band — the second job writes it again.  Early saves are off for such an attachment; files == serial path."""
+    W, lods = 2048, 3
+    base = K.smooth_raster(W, W, seed=11, device=device)
+    over = K.smooth_raster(W, W, seed=12, device=device)
+    over[:, 1000:] = 0
+    over[300:900, 200:700] = 0
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=64, path="terrains/overlay", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=512, border_size=2, format=bt.AttachmentFormat.R16))
+    server = bt.AssetServer().insert("base", base).insert("over", over)
+    roots = []
+    for streamed in (False, True):
+        root = str(tmp_path / ("streamed" if streamed else "serial"))
+        atlas = bt.TileAtlas.new(cfg, device)
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas, root)
+        for name in ("base", "over"):
+            pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path=name, lod_range=range(0, lods)), server, atlas, defer_upload=streamed)
+        if streamed:
+            st = pre.run_streamed(atlas, root)
+            assert st["streamed"] and st["banded_launches"] == 2 and st["early_tiles"] == 0
+            assert pre.stats()["prev_zero_launches"] == 1  # the first job only: the second finds its tiles written
+        else:
+            pre.run(atlas)
+            assert pre.stats()["prev_zero_launches"] == 1
+            pre.save(atlas, root)
+        roots.append((root, atlas))
+    _files_equal(roots[0][1].attachment_directory(roots[0][0], 0), roots[1][1].attachment_directory(roots[1][0], 0), 21)
+    oracle = O.OracleAtlas(lods, 64, False, [(512, 2, 1, O.FORMAT_R16)])
+    oracle.clear_attachment(0).preprocess_tile(0, base, (0, lods)).preprocess_tile(0, over, (0, lods)).run(O.usable_cores())
+    assert K.assert_atlas_equal(roots[1][1], oracle) == 21
+
+
+@pytest.mark.parametrize("fmt,T,W,lods", [(O.FORMAT_R16, 512, 2048, 3), (O.FORMAT_R16, 64, 520, 4), (O.FORMAT_RGBA8, 512, 2048, 3), (O.FORMAT_RGBA8, 36, 300, 4)])
+def test_fresh_atlas_takes_the_previous_value_as_zero_without_fetching(device, fmt, T, W, lods):
+    """A job onto layers nothing has written since bt_atlas_create runs with FusedArgs::prev_zero (no-data pixels become 0 without the
+    fetch of split.wgsl:34-42's previous value): same tiles as the oracle; the re-run of the kept queue, an overlay onto written
+    tiles, a tile uploaded by the host and a handed-out storage pointer all take the fetching path — same tiles again."""
+    src = K.random_raster(fmt, W, W, seed=T + W, holes=0.04)
+    if fmt == O.FORMAT_R16:
+        src[W // 3:W // 3 + 40, :] = 0  # whole rows without data, across tile seams
+    else:
+        src[W // 3:W // 3 + 40, :, 0] = 0
+    tiles = sum(4 ** l for l in range(lods))
+    oracle = K.oracle_planar(src, lods, T, 2, fmt, atlas_size=128)
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=128, path="terrains/test", model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="att", texture_size=T, border_size=2, format=K.FMT[fmt]))
+    ds = bt.PreprocessDataset(attachment_index=0, path="src", lod_range=range(0, lods))
+    server = bt.AssetServer().insert("src", src)
+    # fresh: flagged; the kept queue's second run is not (its tiles are written now) and rewrites the same bytes
+    atlas = bt.TileAtlas.new(cfg, device)
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_tile(ds, server, atlas)
+    pre.run(atlas, keep_queue=True)
+    assert pre.stats()["prev_zero_launches"] == 1 and pre.stats()["fused_jobs"] == 1
+    assert K.assert_atlas_equal(atlas, oracle) == tiles
+    pre.run(atlas)
+    assert pre.stats()["prev_zero_launches"] == 0
+    assert K.assert_atlas_equal(atlas, oracle) == tiles
+    # a host upload into one finest layer of a fresh atlas: not flagged, and the no-data pixels of that tile keep the uploaded texels
+    atlas = bt.TileAtlas.new(cfg, device)
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_tile(ds, server, atlas)
+    finest = [i for c, i in oracle.tiles() if c[1] == lods - 1]
+    marker = np.full((T, T) if fmt == O.FORMAT_R16 else (T, T, 4), 7, np.uint16 if fmt == O.FORMAT_R16 else np.uint8)
+    atlas.upload_tile(0, finest[3], marker)
+    pre.run(atlas)
+    assert pre.stats()["prev_zero_launches"] == 0
+    ours = atlas.download_tiles(0, finest[3], 1)[0]
+    theirs = oracle.tile(0, finest[3])
+    nodata = (theirs == 0) if fmt == O.FORMAT_R16 else (theirs[..., 0] == 0)  # (a blend of texels >= 1 never rounds to 0)
+    centre = np.zeros((T, T), bool)
+    centre[2:T - 2, 2:T - 2] = True
+    assert nodata[centre].any()
+    assert (ours[centre & nodata] == 7).all() and np.array_equal(ours[centre & ~nodata], theirs[centre & ~nodata])
+    # the storage pointer handed out (the caller may write through it): not flagged either
+    atlas = bt.TileAtlas.new(cfg, device)
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_tile(ds, server, atlas)
+    atlas.attachment_storage(0)
+    pre.run(atlas)
+    assert pre.stats()["prev_zero_launches"] == 0
+    assert K.assert_atlas_equal(atlas, oracle) == tiles

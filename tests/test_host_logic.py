@@ -123,7 +123,7 @@ def test_c99_consumer_of_the_header_and_ctypes_mirror_layouts(tmp_path):
     mirror = {"bt_tile_coordinate": _ffi.TileCoordinateC, "bt_atlas_tile": _ffi.AtlasTileC, "bt_attachment_config": _ffi.AttachmentConfigC,
               "bt_terrain_config": _ffi.TerrainConfigC, "bt_raster": _ffi.RasterC, "bt_preprocess_dataset": _ffi.PreprocessDatasetC,
               "bt_spherical_dataset": _ffi.SphericalDatasetC, "bt_tile_tree_entry": _ffi.TileTreeEntryC, "bt_run_stats": _ffi.RunStatsC,
-              "bt_shard_range": _ffi.ShardRangeC, "bt_launch_profile": _ffi.LaunchProfileC, "bt_side_parameter": _ffi.SideParameterC,
+              "bt_stream_stats": _ffi.StreamStatsC, "bt_shard_range": _ffi.ShardRangeC, "bt_launch_profile": _ffi.LaunchProfileC, "bt_side_parameter": _ffi.SideParameterC,
               "bt_view_state": _ffi.ViewStateC, "bt_indirect": _ffi.IndirectC, "bt_terrain_model": _ffi.TerrainModelC,
               "bt_terrain_view_config": _ffi.TerrainViewConfigC}
     checked = 0

@@ -919,3 +919,102 @@ def test_profile_of_a_sharded_step_counts_each_launch_once():
     prof = pre.profile()
     assert len(prof) >= 3 and prof[0]["kind"] == "fused_main"
     assert all(l["samples"] == steps and l["avg_ms"] > 0 for l in prof), prof
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,T,W,lods", [(2, 64, 1100, 6), (4, 64, 1100, 6), (8, 64, 1100, 6), (2, 512, 4096, 4)])
+def test_sharded_streamed_distributed_end_to_end_over_emulated_ranks(world, T, W, lods, tmp_path):
+    """bt_preprocessor_run_streamed_sharded with a host-side exchange (comm = NULL): every emulated rank (its own atlas) uploads only its
+    window of the deferred source band by band, runs its units and writes its finest tiles while later bands run (BT_RUN_SHARD_LOCAL);
+    the two parent LODs are moved between the atlases by the test; the finishing call (BT_RUN_SHARD_FINISH) runs the finishing kernels and
+    writes the rank's share of the lower LODs.  Together the ranks write every tile file exactly once, byte-identical to the oracle's
+    tiles, + config.tc from rank 0; a rank uploads about 1 / world of the source and saves about 1 / world of the bytes."""
+    import bevy_terrain_amd as bt
+    from bevy_terrain_amd import _ffi
+    from bevy_terrain_amd.shard import shard_pieces
+
+    device = bt.Device(0)
+    L = _ffi.lib()
+    b = 2
+    n_tiles = sum(4 ** l for l in range(lods))
+    src = K.random_raster(O.FORMAT_R16, W, W, seed=36 + world, holes=0.01)
+    src[W // 2 - 9:W // 2 + 9, :] = 0  # no data across every rank's strip (and a band seam)
+    oracle = K.oracle_planar(src, lods, T, b, O.FORMAT_R16, atlas_size=2048)
+    root = str(tmp_path)
+    jobs, stats = [], []
+    for rank in range(world):
+        cfg = bt.TerrainConfig(lod_count=lods, atlas_size=2048, path="terrains/dist", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+        cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=T, border_size=b))
+        atlas = bt.TileAtlas.new(cfg, device)
+        pre = bt.Preprocessor.new()
+        if rank == 0:
+            pre.clear_attachment(0, atlas, root)
+        pre.preprocess_tile(bt.PreprocessDataset(path="s", lod_range=range(0, lods)), bt.AssetServer().insert("s", src), atlas, defer_upload=True)
+        _ffi.check(L.bt_preprocessor_set_shard(pre._h, rank, world))
+        jobs.append((atlas, pre))
+    directory = jobs[0][0].attachment_directory(root, 0)
+    seen = set()
+    for rank, (atlas, pre) in enumerate(jobs):
+        st = pre.run_streamed_sharded(atlas, root, local=True, finish=False)
+        assert st["streamed"] and st["banded_launches"] == 1 and st["bands"] >= 2, st
+        assert st["early_tiles"] == 4 ** (lods - 1) // world and st["saved_bytes"] == st["early_tiles"] * T * T * 2
+        assert st["uploaded_bytes"] < 1.35 * src.nbytes / world + 64 * W * 2, (st, src.nbytes)
+        assert pre.stats()["prev_zero_launches"] == 1
+        now = set(os.listdir(directory))
+        assert len(now - seen) == st["early_tiles"]  # this rank's finest files, none of them written before
+        seen = now
+        stats.append(st)
+    pieces = shard_pieces(jobs[0][1])
+    finest = max(p["lod"] for p in pieces)
+    for p in pieces:
+        if p["lod"] == finest:
+            continue  # stays on its owner
+        data = jobs[p["owner_rank"]][0].download_tiles(0, p["first_layer"], p["layers"])
+        for r, (atlas, _) in enumerate(jobs):
+            if r != p["owner_rank"]:
+                for k in range(p["layers"]):
+                    atlas.upload_tile(0, p["first_layer"] + k, data[k])
+    total_saved = 0
+    for rank, (atlas, pre) in enumerate(jobs):
+        st = pre.run_streamed_sharded(atlas, root, local=False, finish=True)
+        now = set(os.listdir(directory))
+        total_saved += len(now - seen)
+        seen = now
+    assert len(seen) == n_tiles and total_saved == n_tiles - 4 ** (lods - 1)
+    assert os.path.exists(os.path.join(root, "terrains/dist", "config.tc"))
+    for c, i in oracle.tiles():
+        tile = np.fromfile(os.path.join(directory, f"{c[0]}_{c[1]}_{c[2]}_{c[3]}.bin"), dtype=np.uint16).reshape(T, T)
+        assert np.array_equal(tile, oracle.tile(0, i)), c
+    assert sum(s["uploaded_bytes"] for s in stats) < 1.35 * src.nbytes + world * 64 * W * 2
+
+
+@pytest.mark.gpu
+def test_sharded_streamed_with_the_library_communicator_single_rank(tmp_path):
+    """the one-call form (communicator given, both halves): a world of one through bt_preprocessor_run_streamed_sharded behaves like
+    bt_preprocessor_run_streamed; a sharded preprocessor is refused by the unsharded entry point, cube jobs by the sharded one."""
+    import bevy_terrain_amd as bt
+    from bevy_terrain_amd import _ffi
+
+    device = bt.Device(0)
+    L = _ffi.lib()
+    T, b, lods, W = 64, 2, 5, 700
+    src = K.random_raster(O.FORMAT_R16, W, W, seed=77, holes=0.02)
+    oracle = K.oracle_planar(src, lods, T, b, O.FORMAT_R16, atlas_size=512)
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=512, path="terrains/one", model=bt.TerrainModel.planar((0, 0, 0), 1.0, 0.0, 1.0))
+    cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=T, border_size=b))
+    atlas = bt.TileAtlas.new(cfg, device)
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas, str(tmp_path)).preprocess_tile(
+        bt.PreprocessDataset(path="s", lod_range=range(0, lods)), bt.AssetServer().insert("s", src), atlas, defer_upload=True)
+    st = pre.run_streamed_sharded(atlas, str(tmp_path), keep_queue=True)
+    assert st["streamed"] and st["early_tiles"] == 256
+    directory = atlas.attachment_directory(str(tmp_path), 0)
+    for c, i in oracle.tiles():
+        tile = np.fromfile(os.path.join(directory, f"{c[0]}_{c[1]}_{c[2]}_{c[3]}.bin"), dtype=np.uint16).reshape(T, T)
+        assert np.array_equal(tile, oracle.tile(0, i)), c
+    _ffi.check(L.bt_preprocessor_set_shard(pre._h, 1, 2))
+    with pytest.raises(_ffi.BtError) as e:
+        pre.run_streamed(atlas, str(tmp_path), keep_queue=True)
+    assert e.value.status == -5 and "run_streamed_sharded" in str(e.value)
+    with pytest.raises(_ffi.BtError) as e:  # both halves in one call need the communicator
+        pre.run_streamed_sharded(atlas, str(tmp_path), keep_queue=True)
+    assert e.value.status == -1
