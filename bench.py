@@ -254,6 +254,127 @@ def end_to_end(device, src_ptr):
                     "buffers + writer threads -> 1365 .bin files + config.tc (preprocessor.rs:363,419)"}
 
 
+def closure_record(device, reps=20, rounds=3):
+    """fused_main's two yardsticks measured in THIS process on the context's stream (tools/closure/bt_closure.hip): a linear copy of the
+    job's byte mix (0.537 GB read + 0.705 GB written), plain and non-temporal, and the memory skeleton of the kernel (same bytes through
+    the same addresses in the same workgroup order, LDS-DMA ring) with 24 packed FMAs per output row and without arithmetic.  Each is the
+    best of `rounds` interleaved round averages of `reps` launches; the means stand beside them."""
+    import ctypes
+
+    path = os.path.join(ROOT, "tools", "closure", "libbt_closure.so")
+    if not os.path.exists(path):
+        return {"error": f"{os.path.relpath(path, ROOT)} is not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    lib = ctypes.CDLL(path)
+    lib.bt_closure_run.restype = ctypes.c_int
+    lib.bt_closure_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint64)]
+    ms = (ctypes.c_float * 8)()
+    nbytes = (ctypes.c_uint64 * 2)()
+    rc = lib.bt_closure_run(ctypes.c_void_p(device.torch_stream.cuda_stream), reps, rounds, ms, nbytes)
+    if rc != 0:
+        return {"error": f"bt_closure_run: hipError {rc}"}
+    names = ("copy_floor_ms", "copy_floor_nt_ms", "skeleton_ms", "skeleton_no_arith_ms")
+    out = {n: float(ms[i]) for i, n in enumerate(names)}
+    out.update({n + "_mean": float(ms[4 + i]) for i, n in enumerate(names)})
+    out["copy_bytes"] = {"read": int(nbytes[0]), "written": int(nbytes[1])}
+    out["method"] = (f"tools/closure: best of {rounds} interleaved round averages of {reps} launches between HIP events on the context's stream, "
+                     "in this process, after the timed steps")
+    return out
+
+
+def end_to_end_sharded(args, device, cfg, job, rank, world, collective, src_ptr, dist, fence):
+    """N > 1: the reference's span (preprocessor.rs:363,419: sources loaded -> all saves done) with EVERY rank a PCIe link — the one
+    configuration that wins by construction.  Distributed result: rank r uploads only its window of the host raster band by band, runs
+    its units, writes its finest tiles while later bands run, exchanges the two parent LODs (0.17 GB per rank), runs the finishing
+    kernels and writes its share of the lower LODs: together the ranks write the reference's directory, one writer per file.  Span = barrier
+    -> every rank's call returned -> barrier, max over ranks; median of 3 passes into fresh directories.  Beside it: the unsharded
+    streamed pipeline on rank 0 (the other ranks wait), same invocation."""
+    import shutil
+    import tempfile
+
+    import numpy as np
+    import torch
+
+    import bevy_terrain_amd as bt
+    from bevy_terrain_amd.shard import ShardedPreprocess
+
+    host = device.download(src_ptr, (SIZE, SIZE), np.uint16)  # this rank's window of the source (zero = no data elsewhere), in host memory
+    parent = ram_directory() or tempfile.gettempdir()
+
+    def shared_dir():
+        box = [tempfile.mkdtemp(prefix="bt_e2e_sharded_", dir=parent) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def one_pass():
+        root = shared_dir()
+        atlas = bt.TileAtlas.new(cfg, device)
+        pre = bt.Preprocessor.new()
+        if rank == 0:
+            pre.clear_attachment(0, atlas, root)
+        j = ShardedPreprocess(pre, atlas, bt.AssetServer().insert("host", host), "host", range(0, LOD_COUNT), rank, world, collective=collective,
+                              result="distributed", comm=(job._comm if collective == "library" else None), defer_upload=True)
+        fence()
+        t0 = time.perf_counter()
+        st = j.run_streamed(root)
+        device.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64)
+        if world > 1:
+            t = t.cuda() if dist.get_backend() == "nccl" else t
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        files = len(os.listdir(atlas.attachment_directory(root, 0))) if rank == 0 else 0
+        has_tc = os.path.exists(os.path.join(root, cfg.path, "config.tc")) if rank == 0 else False
+        fence()
+        if rank == 0:
+            shutil.rmtree(root, ignore_errors=True)
+        pre.close()
+        atlas.close()
+        return float(t.item()), st, files, has_tc
+
+    one_pass()  # warm: pinned staging buffers, side streams, writer threads' paths
+    passes = [one_pass() for _ in range(3)]
+    times = sorted(p[0] for p in passes)
+    st, files, has_tc = passes[-1][1], passes[-1][2], passes[-1][3]
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, {"rank": rank, "uploaded_bytes": st["uploaded_bytes"], "saved_bytes": st["saved_bytes"], "early_tiles": st["early_tiles"],
+                                      "bands": st["bands"], "streamed": st["streamed"]})
+    out = {"ms": times[1] * 1e3, "ms_min": times[0] * 1e3, "ms_max": times[2] * 1e3, "tiles_per_s": files / times[1] if files else None, "files": files,
+           "config_tc": has_tc, "per_rank": per_rank, "result": "distributed", "collective": collective,
+           "span": "barrier -> every rank: deferred window upload in bands || kernels || its finest tiles D2H + written; exchange of the two parent LODs; "
+                   "finishing kernels; its share of the lower LODs written -> barrier (max over ranks)"}
+    # the N = 1 end-to-end span of the same invocation: the unsharded streamed pipeline on rank 0's GPU while the others wait
+    n1 = None
+    if rank == 0:
+        try:
+            full_ptr = device.synth_fbm_r16(SIZE, SIZE, SEED)
+            full = device.download(full_ptr, (SIZE, SIZE), np.uint16)
+            device.free(full_ptr)
+            ts = []
+            for _ in range(4):
+                root = tempfile.mkdtemp(prefix="bt_e2e_n1_", dir=parent)
+                atlas = bt.TileAtlas.new(cfg, device)
+                pre = bt.Preprocessor.new().clear_attachment(0, atlas, root)
+                t0 = time.perf_counter()
+                pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="host", lod_range=range(0, LOD_COUNT)), bt.AssetServer().insert("host", full), atlas,
+                                    defer_upload=True)
+                pre.run_streamed(atlas, root)
+                ts.append(time.perf_counter() - t0)
+                shutil.rmtree(root, ignore_errors=True)
+                pre.close()
+                atlas.close()
+            ts = sorted(ts[1:])
+            n1 = {"ms": ts[1] * 1e3, "tiles_per_s": 1365 / ts[1]}
+        except Exception as e:
+            n1 = {"error": repr(e)}
+    fence()
+    out["n1_same_invocation"] = n1
+    if n1 and "ms" in n1:
+        out["speedup_vs_n1_same_invocation"] = n1["ms"] / out["ms"]
+    return out
+
+
 def verify_against(atlas, oracle, shape, held=None):
     """Byte-compare the GPU atlas with the oracle's (same coordinates at the same atlas indices).  held: the atlas layers
     this rank is expected to hold (distributed result), default all."""
@@ -305,6 +426,8 @@ def main():
                     help="skip the extra passes (N = 1: two jobs in flight; N > 1: kernels only, collective only, the other result mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host raster -> files on disk measurement")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="N = 1: skip config.workloads (config 2 height / albedo, the masked 16k job re-run and fresh, config 5 height: each timed by events in this process)")
     ap.add_argument("--verify", action="store_true", help="byte-compare all tiles with the checker's run of the same job (oracle/_ref when built)")
     args = ap.parse_args()
 
@@ -583,6 +706,14 @@ def main():
         fence()
         two_in_flight_ms = max(start.elapsed_time(e) for e in ends) / args.steps
 
+    # N = 1: fused_main's yardsticks (linear copy of the byte mix, memory skeleton) in this process, right behind the timed steps
+    closure = None
+    if job is None and world == 1 and extras and not cube and not args.generic:
+        try:
+            closure = closure_record(device)
+        except Exception as e:  # never lose the headline over a side measurement
+            closure = {"error": repr(e)}
+
     # N = 1 with several jobs in flight: the same K steps once more on ONE stream — the step time without overlap, and the
     # undisturbed per-launch durations the roofline is computed from (HIP events on that stream, every 4th step)
     one_stream_ms = None
@@ -754,6 +885,11 @@ def main():
                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                             "traffic_source": traffic_source,
                             "avg_launch_ms": dominant["avg_ms"], "algorithmic_bytes_per_launch": dominant["algorithmic_bytes"],
+                            # the closure record (same process, same stream): a linear copy of the same byte mix and the kernel's memory skeleton
+                            "copy_floor_ms": (closure or {}).get("copy_floor_ms"), "skeleton_ms": (closure or {}).get("skeleton_ms"),
+                            "frac_of_copy": ((closure["copy_floor_ms"] / dominant["avg_ms"]) if closure and closure.get("copy_floor_ms") and dominant["kind"] == "fused_main" else None),
+                            "kernel_over_skeleton": ((dominant["avg_ms"] / closure["skeleton_ms"]) if closure and closure.get("skeleton_ms") and dominant["kind"] == "fused_main" else None),
+                            "closure": closure,
                             "launch_timing": ("HIP events on the launching stream, every 4th step of the timed K steps" if depth == 1 else
                                               f"HIP events on the launching stream, every 4th step of the one-stream pass of the same K steps "
                                               f"(in the timed pass {depth} jobs share the GPU: a launch's span there is not the kernel's duration)")}
@@ -765,6 +901,41 @@ def main():
             line["end_to_end"] = end_to_end(device, src_ptr)
         except Exception as e:  # never lose the headline line over a side measurement
             line["end_to_end"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_workloads and not cube:
+        # every other fraction DESIGN.md claims, timed by events in this process (outside the headline's timed steps)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import workloads
+
+            line["config"]["workloads"] = workloads.all_workloads(device)
+        except Exception as e:
+            line["config"]["workloads"] = {"error": repr(e)}
+        if not args.no_end_to_end and isinstance(line.get("end_to_end"), dict) and "error" not in line["end_to_end"]:
+            # the reference's own two examples end to end (preprocessor.rs:363,419), streamed with the serial legs beside them
+            try:
+                line["end_to_end"]["reference_examples"] = {
+                    "config2_planar_height_albedo": workloads.end_to_end_config2(device, passes=3),
+                    "config5_cube_height": workloads.end_to_end_config5(device, passes=3)}
+            except Exception as e:
+                line["end_to_end"]["reference_examples"] = {"error": repr(e)}
+    if world > 1 and not cube and extras and not args.no_end_to_end:
+        import threading
+
+        def bail_e2e():  # these passes end in collectives too: a rank that fails inside one must not cost the line
+            if rank == 0:
+                line["end_to_end_sharded"] = {"error": f"did not finish within {args.extras_timeout} s"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        watchdog_e2e = threading.Timer(args.extras_timeout, bail_e2e)
+        watchdog_e2e.daemon = True
+        watchdog_e2e.start()
+        try:
+            line["end_to_end_sharded"] = end_to_end_sharded(args, device, cfg, job, rank, world, collective, src_ptr, dist, fence)
+        except Exception as e:  # (an exception every rank raises at the same point)
+            line["end_to_end_sharded"] = {"error": repr(e)}
+        finally:
+            watchdog_e2e.cancel()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(device, src_ptr)  # reported at N = 1 only
     if rank == 0 and args.verify:

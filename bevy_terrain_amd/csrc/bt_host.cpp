@@ -291,7 +291,7 @@ void bt_ctx_destroy(bt_ctx* ctx) {
     if (ctx->ev_begin) hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) hipEventDestroy(ctx->ev_end);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
-    if (ctx->spare_raster) hipFree(ctx->spare_raster);
+    for (auto& kept : ctx->spare_rasters) hipFree(kept.first);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     if (ctx->save_stream) hipStreamDestroy(ctx->save_stream);
     delete ctx;
@@ -321,12 +321,11 @@ bt_status bt_ctx_trim(bt_ctx* ctx, uint64_t* freed_bytes) {
     if (ctx->copy_stream) BT_HIP(hipStreamSynchronize(ctx->copy_stream));
     if (ctx->save_stream) BT_HIP(hipStreamSynchronize(ctx->save_stream));
     uint64_t freed = 0;
-    if (ctx->spare_raster) {
-        BT_HIP(hipFree(ctx->spare_raster));
-        freed += ctx->spare_raster_bytes;
-        ctx->spare_raster = nullptr;
-        ctx->spare_raster_bytes = 0;
+    for (auto& kept : ctx->spare_rasters) {
+        BT_HIP(hipFree(kept.first));
+        freed += kept.second;
     }
+    ctx->spare_rasters.clear();
     for (void*& s : ctx->staging)
         if (s) {
             BT_HIP(hipHostFree(s));
@@ -612,6 +611,17 @@ bt_status bt_atlas_upload_tile(bt_atlas* a, uint32_t ai, uint32_t layer, const v
 
 namespace {
 
+#ifdef BT_DEBUG_HOOKS
+// tools build: BT_STREAM_TRACE=1 prints host time stamps of the streamed run's launcher, its saver thread and the TileSaver underneath
+std::chrono::steady_clock::time_point g_trace_start;
+bool g_trace = false;
+void trace_stamp(const char* what, size_t k) {
+    if (g_trace) fprintf(stderr, "[stream] %7.3f ms %s %zu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_trace_start).count(), what, k);
+}
+#else
+inline void trace_stamp(const char*, size_t) {}
+#endif
+
 // fs::write for a batch of files on a few threads (the reference spawns one AsyncComputeTaskPool task per tile,
 // tile_atlas.rs:77-116): jobs are (path, bytes) pairs; a chunk's pinned buffer is reused once its jobs are done.
 class FileWriters {
@@ -780,7 +790,9 @@ class TileSaver {
             if (taper && n - lo <= 2 * size_t(chunk)) step = std::max<size_t>(std::min<size_t>(8, chunk), (n - lo) / 2);
             const size_t hi = std::min(n, lo + step);
             const uint32_t k = uint32_t(chunks_++ % kBuffers);
+            trace_stamp("  saver chunk: tiles", hi - lo);
             writers_->wait_buffer(k);
+            trace_stamp("  saver chunk: buffer free", k);
             // runs of consecutive layers; equally long runs at a constant layer stride (a band of tile rows in the x-major
             // atlas order: 4 layers every 32) travel as ONE pitched copy instead of one call per run
             std::vector<std::pair<size_t, size_t>> runs;  // (first tile of the chunk, length)
@@ -807,7 +819,9 @@ class TileSaver {
             }
             hipError_t e = hipEventRecord(copied_[k], stream_);
             if (e != hipSuccess) return hip_fail(e, "tile download");
+            trace_stamp("  saver chunk: copy issued", k);
             if (bt_status s = hand_over()) return s;  // the chunk enqueued BEFORE this one: wait for its copies, queue its files
+            trace_stamp("  saver chunk: previous chunk handed over", k);
             in_flight_.assign(tiles.begin() + lo, tiles.begin() + hi);
             in_flight_buffer_ = k;
             in_flight_ai_ = ai;
@@ -1226,16 +1240,7 @@ static void release_rasters(bt_preprocessor* p) {
             synced = true;
         }
     for (Raster& r : p->rasters)
-        if (r.owned && r.dev.data) {
-            // keep the largest released buffer for the next queue's raster (bt_ctx::spare_raster)
-            if (r.alloc_bytes > p->ctx->spare_raster_bytes) {
-                if (p->ctx->spare_raster) hipFree(p->ctx->spare_raster);
-                p->ctx->spare_raster = (void*)r.dev.data;
-                p->ctx->spare_raster_bytes = r.alloc_bytes;
-            } else {
-                hipFree((void*)r.dev.data);
-            }
-        }
+        if (r.owned && r.dev.data) p->ctx->park_raster((void*)r.dev.data, r.alloc_bytes);  // kept for the next queue's rasters (bt_ctx::spare_rasters)
     p->rasters.clear();
 }
 
@@ -1317,11 +1322,10 @@ bt_status add_raster(bt_preprocessor* p, const bt_atlas* a, uint32_t ai, const b
     const uint64_t row_bytes = uint64_t(src->width) * px, padded_pitch = (row_bytes + 15u) & ~uint64_t(15);
     const bool r16 = fmt == BT_FORMAT_R16;
     auto take_buffer = [&](uint64_t need, void** dev) -> bt_status {
-        if (p->ctx->spare_raster && p->ctx->spare_raster_bytes >= need) {  // the buffer the previous queue released
-            *dev = p->ctx->spare_raster;
-            p->ctx->spare_raster = nullptr;
-            r.alloc_bytes = p->ctx->spare_raster_bytes;
-            p->ctx->spare_raster_bytes = 0;
+        uint64_t kept_bytes = 0;
+        if (void* kept = p->ctx->take_spare_raster(need, &kept_bytes)) {  // a buffer an earlier queue released
+            *dev = kept;
+            r.alloc_bytes = kept_bytes;
         } else {
             BT_HIP(hipMalloc(dev, need));
             r.alloc_bytes = need;
@@ -1729,9 +1733,13 @@ bt_status run_streamed_impl(bt_preprocessor* p, bt_atlas* a, bt_comm* comm, cons
             if (finish)
                 if (bt_status s = bt_preprocessor_run(p, a, keep | BT_RUN_SHARD_FINISH | BT_RUN_SHARD_DISTRIBUTED)) return s;
         }
-        if (finish)
-            if (bt_status s = bt_preprocessor_save(p, a, assets_root)) return s;
         bt_stream_stats none{};
+        if (finish) {
+            for (const AtlasTileAttachment& t : a->to_save)  // what bt_preprocessor_save is about to write (a sharded rank: its share)
+                if (t.atlas_index != BT_INVALID_ATLAS_INDEX && (!sharded || shard_holder(p, t.attachment_index, t.coordinate.lod, t.atlas_index) == p->shard_rank))
+                    none.saved_bytes += a->attachments[t.attachment_index].tile_bytes;
+            if (bt_status s = bt_preprocessor_save(p, a, assets_root)) return s;
+        }
         if (out) *out = none;
         return ((flags & BT_RUN_KEEP_QUEUE) || !finish) ? BT_OK : release_queue(p);
     }
@@ -1798,14 +1806,10 @@ bt_status run_streamed_impl(bt_preprocessor* p, bt_atlas* a, bt_comm* comm, cons
     if (rc == BT_OK && hipEventCreateWithFlags(&uploaded, hipEventDisableTiming) != hipSuccess) rc = BT_ERR_DEVICE;
 
 #ifdef BT_DEBUG_HOOKS
-    const bool trace = getenv("BT_STREAM_TRACE") != nullptr;
-    const auto t_start = std::chrono::steady_clock::now();
-    auto stamp = [&](const char* what, size_t k) {
-        if (trace) fprintf(stderr, "[stream] %7.3f ms %s %zu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(), what, k);
-    };
-#else
-    auto stamp = [](const char*, size_t) {};
+    g_trace = getenv("BT_STREAM_TRACE") != nullptr;
+    g_trace_start = std::chrono::steady_clock::now();
 #endif
+    auto stamp = [](const char* what, size_t k) { trace_stamp(what, k); };
     // the saver: step after step as their kernels are enqueued (host handshake), ordered on the GPU by events
     std::mutex m;
     std::condition_variable cv;
@@ -1818,19 +1822,32 @@ bt_status run_streamed_impl(bt_preprocessor* p, bt_atlas* a, bt_comm* comm, cons
         hipSetDevice(p->ctx->device);
         TileSaver ts(a, p->ctx->save_stream);
         bt_status s = ts.begin();
-        for (size_t k = 0; k < ns && s == BT_OK; k++) {
-            if (steps[k].early.empty() && steps[k].rest.empty()) continue;
+        for (size_t k = 0; k < ns && s == BT_OK;) {
+            if (steps[k].early.empty() && steps[k].rest.empty()) {
+                k++;
+                continue;
+            }
+            // The saver takes what is ready: step k and every following step of the same attachment that the launcher has enqueued by
+            // now travel as ONE hand-over (sorted by layer, cut into 32 MB chunks).  When the download + write side is the slower one — it
+            // is, on PCIe — the bands it falls behind on merge into full-size chunks instead of paying the per-chunk latencies band by band
+            // (config 2's 8 MB and 16 MB bands: 0.6 / 0.9 ms each, i.e. 13 - 17 GB/s; merged 32 MB chunks move at 45).
+            size_t last = k;
             {
                 std::unique_lock<std::mutex> lock(m);
                 cv.wait(lock, [&] { return launched > k || abort_run; });
                 if (abort_run) break;
+                while (last + 1 < ns && launched > last + 1 && steps[last + 1].attachment == steps[k].attachment) last++;
             }
-            if (hipStreamWaitEvent(p->ctx->save_stream, computed[k], 0) != hipSuccess) s = BT_ERR_DEVICE;
-            stamp("saver: step enqueued by the launcher", k);
-            const std::string dir = dir_of(steps[k].attachment);
-            if (s == BT_OK && !steps[k].early.empty()) s = ts.add(steps[k].attachment, dir, std::move(steps[k].early), k == last_saving && steps[k].rest.empty());
-            if (s == BT_OK && !steps[k].rest.empty()) s = ts.add(steps[k].attachment, dir, std::move(steps[k].rest), k == last_saving);
-            stamp("saver: step's copies issued, previous chunks handed to the writers", k);
+            if (hipStreamWaitEvent(p->ctx->save_stream, computed[last], 0) != hipSuccess) s = BT_ERR_DEVICE;
+            stamp("saver: steps taken up to", last);
+            TileSaver::Tiles tiles;
+            for (size_t q = k; q <= last; q++) {
+                tiles.insert(tiles.end(), steps[q].early.begin(), steps[q].early.end());
+                tiles.insert(tiles.end(), steps[q].rest.begin(), steps[q].rest.end());
+            }
+            if (s == BT_OK && !tiles.empty()) s = ts.add(steps[k].attachment, dir_of(steps[k].attachment), std::move(tiles), last >= last_saving);
+            stamp("saver: copies issued, previous chunks handed to the writers", last);
+            k = last + 1;
         }
         if (s == BT_OK) s = ts.finish();
         saved_bytes = ts.saved_bytes();

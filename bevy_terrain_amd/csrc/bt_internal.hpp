@@ -164,10 +164,36 @@ struct bt_ctx {
     size_t staging_bytes = 0;
     // streamed runs: uploads and downloads on their own queues beside the kernels' stream (created on first use)
     hipStream_t copy_stream = nullptr, save_stream = nullptr;
-    // one released raster allocation is kept for the next queue (hipMalloc + hipFree of a 512 MB source cost ~1.5 ms of the
-    // end-to-end span; a host that preprocesses dataset after dataset pays them once)
-    void* spare_raster = nullptr;
-    uint64_t spare_raster_bytes = 0;
+    // released raster allocations are kept for the next queue (hipMalloc + hipFree of a 512 MB source cost ~1.5 ms of the
+    // end-to-end span; a host that preprocesses dataset after dataset pays them once; a cube job has six): at most kSpareRasters buffers
+    // and kSpareRasterBytes in all, the smallest goes first (bt_ctx_trim gives them all back)
+    static constexpr size_t kSpareRasters = 8;
+    static constexpr uint64_t kSpareRasterBytes = 4ull << 30;
+    std::vector<std::pair<void*, uint64_t>> spare_rasters;  // (device pointer, bytes)
+    void* take_spare_raster(uint64_t need, uint64_t* bytes) {  // the smallest kept buffer that holds `need` bytes, or nullptr
+        size_t best = spare_rasters.size();
+        for (size_t i = 0; i < spare_rasters.size(); i++)
+            if (spare_rasters[i].second >= need && (best == spare_rasters.size() || spare_rasters[i].second < spare_rasters[best].second)) best = i;
+        if (best == spare_rasters.size()) return nullptr;
+        void* ptr = spare_rasters[best].first;
+        *bytes = spare_rasters[best].second;
+        spare_rasters.erase(spare_rasters.begin() + long(best));
+        return ptr;
+    }
+    void park_raster(void* ptr, uint64_t bytes) {  // keeps it, or frees what does not fit any more (the smallest first)
+        spare_rasters.push_back({ptr, bytes});
+        for (;;) {
+            uint64_t total = 0;
+            size_t smallest = 0;
+            for (size_t i = 0; i < spare_rasters.size(); i++) {
+                total += spare_rasters[i].second;
+                if (spare_rasters[i].second < spare_rasters[smallest].second) smallest = i;
+            }
+            if (spare_rasters.size() <= kSpareRasters && total <= kSpareRasterBytes) break;
+            hipFree(spare_rasters[smallest].first);
+            spare_rasters.erase(spare_rasters.begin() + long(smallest));
+        }
+    }
     uint32_t io_threads = 0;  // writer / reader threads of the save and load paths; 0 = automatic (bt_ctx_set_io_threads)
 };
 

@@ -263,16 +263,7 @@ bt_status release_queue(bt_preprocessor* p) {
     BT_HIP(hipStreamSynchronize(p->ctx->stream));  // borrowed rasters may be released by the caller afterwards
     p->queue.clear();
     for (Raster& r : p->rasters)
-        if (r.owned && r.dev.data) {
-            // keep the largest released buffer for the next queue's raster (bt_ctx::spare_raster)
-            if (r.alloc_bytes > p->ctx->spare_raster_bytes) {
-                if (p->ctx->spare_raster) hipFree(p->ctx->spare_raster);
-                p->ctx->spare_raster = (void*)r.dev.data;
-                p->ctx->spare_raster_bytes = r.alloc_bytes;
-            } else {
-                hipFree((void*)r.dev.data);
-            }
-        }
+        if (r.owned && r.dev.data) p->ctx->park_raster((void*)r.dev.data, r.alloc_bytes);  // kept for the next queue's rasters (bt_ctx::spare_rasters)
     p->rasters.clear();
     p->jobs = 0;
     p->compiled = false;

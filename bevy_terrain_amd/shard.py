@@ -102,9 +102,10 @@ class ShardedPreprocess:
             pre.preprocess_tile(PreprocessDataset(attachment_index=attachment_index, path=path, lod_range=lod_range),
                                 asset_server, tile_atlas, defer_upload=defer_upload)
         _ffi.check(_ffi.lib().bt_preprocessor_set_shard(pre._handle(tile_atlas), rank, world))
-        ptr, tile_bytes, layers = tile_atlas.attachment_storage(attachment_index)
-        self.tile_bytes = tile_bytes
-        self.storage = torch.as_tensor(_DeviceBytes(ptr, tile_bytes * layers), device=f"cuda:{tile_atlas.device.index}")
+        a = tile_atlas.config.attachments[attachment_index]
+        self.tile_bytes = a.texture_size * a.texture_size * a.format.pixel_size()
+        self._attachment_index = attachment_index
+        self._storage = None  # the atlas as a flat torch tensor: taken when a torch collective first needs it (handing the pointer out counts as a write to every layer)
         self.stream = tile_atlas.device.torch_stream
         self._ranges: Optional[List[dict]] = None
         self._pieces: Optional[List[dict]] = None
@@ -130,6 +131,41 @@ class ShardedPreprocess:
             _ffi.check(_ffi.lib().bt_comm_create(tile_atlas.device._h, world, rank, uid, C.byref(h)))
             self._comm = h
             self._owns_comm = True
+
+    @property
+    def storage(self):
+        import torch
+
+        if self._storage is None:
+            ptr, tile_bytes, layers = self.atlas.attachment_storage(self._attachment_index)
+            assert tile_bytes == self.tile_bytes
+            self._storage = torch.as_tensor(_DeviceBytes(ptr, tile_bytes * layers), device=f"cuda:{self.atlas.device.index}")
+        return self._storage
+
+    def run_streamed(self, assets_root: str) -> dict:
+        """This rank's end-to-end span of the job (bt_preprocessor_run_streamed_sharded; result="distributed", rasters queued with
+        defer_upload=True): its source window uploads band by band, its finest tiles leave band by band, the two parent LODs are
+        exchanged (the library's communicator inside the one call; torch.distributed between the two halves otherwise), the finishing
+        kernels run and its share of the lower LODs is written.  Returns the stream stats of the call(s), summed."""
+        import torch
+
+        assert self.result == "distributed", "a streamed sharded run writes each rank's share: result='distributed'"
+        if self._comm is not None:
+            st = self.pre.run_streamed_sharded(self.atlas, assets_root, comm=self._comm, keep_queue=True)
+            self._layout()
+            return st
+        st = self.pre.run_streamed_sharded(self.atlas, assets_root, local=True, finish=False)
+        self._layout()
+        if self.world > 1:
+            with torch.cuda.stream(self.stream):  # same queue as the kernels: ordered without host syncs
+                if self._ranges:
+                    all_gather_ranges(self.storage, self.tile_bytes, self._ranges, self.rank, self.world, self.dist)
+                else:
+                    broadcast_pieces(self.storage, self.tile_bytes, self._pieces, self.dist)
+        st2 = self.pre.run_streamed_sharded(self.atlas, assets_root, local=False, finish=True, keep_queue=True)
+        for k in ("uploaded_bytes", "saved_bytes", "early_tiles", "bands", "banded_launches"):
+            st[k] += st2[k]
+        return st
 
     def _run(self, flags):
         _ffi.check(_ffi.lib().bt_preprocessor_run(self.pre._h, self.atlas._h, self.flags | flags))

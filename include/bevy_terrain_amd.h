@@ -165,8 +165,9 @@ void bt_ctx_destroy(bt_ctx* ctx);
 bt_status bt_ctx_set_stream(bt_ctx* ctx, void* stream);
 void* bt_ctx_stream(const bt_ctx* ctx);
 bt_status bt_ctx_synchronize(bt_ctx* ctx);
-/* Gives back what the context keeps between queues: the device raster a finished queue released (kept so that the next queue's
- * source need not be allocated again: 0.5 GB for a 16k R16 raster) and the pinned staging buffers of the save / load paths.
+/* Gives back what the context keeps between queues: the device rasters finished queues released (kept so that the next queue's
+ * sources need not be allocated again: 0.5 GB for a 16k R16 raster, six of 128 MB for a cube job; at most 8 buffers and 4 GiB) and
+ * the pinned staging buffers of the save / load paths.
  * Synchronises the context's stream first.  `freed_bytes` (may be NULL): device + pinned bytes released. */
 bt_status bt_ctx_trim(bt_ctx* ctx, uint64_t* freed_bytes);
 /* Host threads that write (bt_preprocessor_save / _run_streamed) and read (bt_atlas_load_tiles) tile files for this context.

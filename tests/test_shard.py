@@ -213,6 +213,13 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(result, held_tiles):
     assert sc["headline"]["speedup"] > 0 and abs(sc["headline"]["efficiency"] - sc["headline"]["speedup"] / 2) < 1e-12
     assert f"{result}_overlapped" in sc and "kernels_only" in sc
     assert other["all_gather_bytes_per_rank"] == (quarter if result == "replicated" else full)
+    # round 6: the end-to-end span with every rank a PCIe link (distributed result, streamed): the two ranks together wrote the reference's
+    # directory once, each uploaded about half of the source and saved its half of the finest tiles + every second lower tile
+    e2e = line["end_to_end_sharded"]
+    assert e2e["files"] == 1365 and e2e["config_tc"] and e2e["ms"] > 0 and e2e["n1_same_invocation"]["ms"] > 0
+    assert len(e2e["per_rank"]) == 2 and all(r["streamed"] and r["early_tiles"] == 512 for r in e2e["per_rank"])
+    assert sum(r["saved_bytes"] for r in e2e["per_rank"]) == 1365 * 512 * 512 * 2
+    assert all(0.5 * 2**29 <= r["uploaded_bytes"] < 0.56 * 2**29 for r in e2e["per_rank"])
 
 
 def _unit_pieces(tiles, sides, lod_hi, world):
