@@ -149,3 +149,90 @@ def test_run_flags_of_the_binding_are_the_header_s():
     assert len(header) == 10 and header["REFERENCE_DISPATCH"] == 256
     for name, value in header.items():
         assert getattr(_ffi, "RUN_" + name) == value, name
+
+
+def _rust_layout(rust_text):
+    """Parse integration/hip.rs back: {struct: [(field, offset, size)], "__size__"} by the repr(C) rules, the extern fn signatures and the
+    constants — written against the generated text only (no import of the generator's parser)."""
+    import re
+
+    scalars = {"u8": (1, 1), "i8": (1, 1), "u16": (2, 2), "i16": (2, 2), "u32": (4, 4), "i32": (4, 4), "f32": (4, 4), "u64": (8, 8), "i64": (8, 8), "f64": (8, 8),
+               "usize": (8, 8), "c_char": (1, 1), "bt_status": (4, 4)}
+    structs, sizes = {}, {}
+
+    def size_align(t):
+        t = t.strip()
+        if t.startswith("*"):
+            return 8, 8
+        m = re.fullmatch(r"\[(.+);\s*(\d+)\]", t)
+        if m:
+            s, a = size_align(m.group(1))
+            return s * int(m.group(2)), a
+        if t in scalars:
+            return scalars[t]
+        return sizes[t]
+
+    for m in re.finditer(r"#\[repr\(C\)\]\s*(?:#\[derive\([^)]*\)\]\s*)?pub struct (\w+) \{(.*?)\n\}", rust_text, flags=re.S):
+        name, body = m.group(1), m.group(2)
+        fields, offset, align = [], 0, 1
+        for fm in re.finditer(r"^\s*(?:pub )?(?:r#)?(\w+): (.+?),\s*$", body, flags=re.M):
+            fname, ftype = fm.group(1), fm.group(2)
+            s, a = size_align(ftype)
+            offset = (offset + a - 1) // a * a
+            fields.append((fname, offset, s))
+            offset += s
+            align = max(align, a)
+        sizes[name] = ((offset + align - 1) // align * align, align)
+        structs[name] = fields
+    block = re.search(r'extern "C" \{(.*?)\n\}', rust_text, flags=re.S).group(1)
+    fns = {}
+    for fm in re.finditer(r"pub fn (\w+)\((.*?)\)( -> [^;]+)?;", block):
+        args = [a for a in fm.group(2).split(", ") if a.strip()]
+        fns[fm.group(1)] = (len(args), (fm.group(3) or "").replace(" -> ", ""))
+    consts = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"pub const (\w+): \w+ = (-?(?:0x[0-9a-f]+|\d+));", rust_text)}
+    return structs, sizes, fns, consts
+
+
+def test_generated_rust_binding_is_complete_and_current():
+    """integration/hip.rs (tools/gen_rust_ffi.py) is the WHOLE boundary as Rust: regenerating it from the header gives the committed file;
+    parsed back it declares exactly the header's functions with the argument counts of the ctypes prototypes, every #[repr(C)] struct has
+    the size and the field offsets of the ctypes mirror, the opaque handles are zero-sized, and the constants carry the header's values."""
+    import ctypes as C
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", os.path.join(ROOT, "tools", "gen_rust_ffi.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(os.path.join(ROOT, "integration", "hip.rs")).read()
+    assert gen.generate(open(_ffi.HEADER_PATH).read()) == committed, "integration/hip.rs is stale: python tools/gen_rust_ffi.py"
+    structs, sizes, fns, consts = _rust_layout(committed)
+    assert set(fns) == _ffi.header_symbols() == set(_ffi.PROTOTYPES)
+    for name, (restype, argtypes) in _ffi.PROTOTYPES.items():
+        assert fns[name][0] == len(argtypes), (name, fns[name], len(argtypes))
+        assert (fns[name][1] == "") == (restype is None), (name, fns[name])
+    mirror = {"bt_tile_coordinate": _ffi.TileCoordinateC, "bt_atlas_tile": _ffi.AtlasTileC, "bt_attachment_config": _ffi.AttachmentConfigC,
+              "bt_terrain_config": _ffi.TerrainConfigC, "bt_raster": _ffi.RasterC, "bt_preprocess_dataset": _ffi.PreprocessDatasetC,
+              "bt_spherical_dataset": _ffi.SphericalDatasetC, "bt_tile_tree_entry": _ffi.TileTreeEntryC, "bt_run_stats": _ffi.RunStatsC,
+              "bt_stream_stats": _ffi.StreamStatsC, "bt_shard_range": _ffi.ShardRangeC, "bt_launch_profile": _ffi.LaunchProfileC,
+              "bt_side_parameter": _ffi.SideParameterC, "bt_view_state": _ffi.ViewStateC, "bt_indirect": _ffi.IndirectC,
+              "bt_terrain_model": _ffi.TerrainModelC, "bt_terrain_view_config": _ffi.TerrainViewConfigC}
+    checked = 0
+    for name, cls in mirror.items():
+        assert sizes[name][0] == C.sizeof(cls), (name, sizes[name], C.sizeof(cls))
+        assert [f[0] for f in structs[name]] == [f[0] for f in cls._fields_], name
+        for fname, offset, size in structs[name]:
+            d = getattr(cls, fname)
+            assert (d.offset, d.size) == (offset, size), (name, fname)
+            checked += 1
+    assert checked > 80
+    # every struct and handle of the header is there (mirrored in ctypes or not)
+    import re
+
+    header = re.sub(r"/\*.*?\*/", "", open(_ffi.HEADER_PATH).read(), flags=re.S)
+    declared = set(re.findall(r"\}\s*(bt_\w+)\s*;", header))
+    opaque = set(re.findall(r"typedef\s+struct\s+(bt_\w+)\s+\1\s*;", header))
+    assert declared | opaque == set(structs), (declared | opaque) ^ set(structs)
+    assert all(sizes[o][0] == 0 for o in opaque) and len(opaque) == 6
+    assert sizes["bt_tile_coordinate"][0] == 16 and sizes["bt_atlas_tile"][0] == 32 and sizes["bt_indirect"][0] == 16  # the reference's GPU layouts
+    assert consts["BT_ABI_VERSION"] == _ffi.header_abi_version() and consts["BT_ERR_ATLAS_OUT_OF_INDICES"] == -2
+    assert consts["BT_RUN_REFERENCE_DISPATCH"] == _ffi.RUN_REFERENCE_DISPATCH and consts["BT_INVALID_ATLAS_INDEX"] == 0xFFFFFFFF
