@@ -460,7 +460,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     const uint32_t tid = threadIdx.x;
 #ifdef BT_DEBUG_HOOKS
     // (134217728: real-time (100 MHz) stamps per WORKGROUP — entry, prologue done, chunk loop done, end — behind the per-tile stamps in
-    // the atlas's last layer; tools/experiments/main_probe.py)
+    // the atlas's last layer; git history, tools/experiments/main_probe.py)
     auto wg_stamp = [&](uint32_t slot) {
         if (BT_ABLATE(A, 134217728u) && tid == 0 && blockIdx.x < 4096u)
             reinterpret_cast<unsigned long long*>(A.atlas + uint64_t(A.m.atlas_size - 1u) * T * T)[16384u + blockIdx.x * 4u + slot] = __builtin_amdgcn_s_memrealtime();
@@ -624,7 +624,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         static_assert(!kDma || kP == 528, "the DMA variant assumes 1056-byte LDS rows");
         const lds_bytes dst = (lds_bytes)reinterpret_cast<uint8_t*>(s_dst);
         // (the wave index through v_readfirstlane: as a function of tid the row pointer was computed per lane — two 64-bit vector
-        // multiply-adds per row; every instruction, scalar or vector, takes a turn of the SIMD's one issue port: tools/experiments/issue_probe.hip)
+        // multiply-adds per row; every instruction, scalar or vector, takes a turn of the SIMD's one issue port: git history, tools/experiments/issue_probe.hip)
         for (uint32_t slot = uint32_t(__builtin_amdgcn_readfirstlane(int(tid >> 6))); slot < slots; slot += 4u) {
             const global_bytes row = data + uint64_t(uint32_t(ymin) + slot) * raster.pitch;
             if (BT_ABLATE(A, 32768u))  // (32768: the non-temporal policy on the source stream — timing experiment)
@@ -758,8 +758,8 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         for (uint32_t q = 0; q < nrows; q += 4) {
             uint32_t va[4], vb[4];
             uint32_t zany = 1;
-            // the redo of a flagged chunk (fast variants): the previous atlas values of the quad are requested BEFORE the rows are shaded
-            // — fetched only where a footprint turned out to have no data they were a round trip in the middle of every quad
+            // (kGeneric == false never reaches this function since round 5 — the fast variants fix a no-data quad inside their own loops — but
+            // the form is kept compilable: there the previous atlas values of the quad are requested BEFORE the rows are shaded)
             uint32_t prev_a[4], prev_b[4];
             if constexpr (!kGeneric) {
 #pragma unroll
@@ -855,7 +855,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
 
         // Wave priority rotating with the chunk index, offset by the workgroup's dispatch rank on its CU.  The CU's arbiters serve
         // the highest-priority wave first and, among equals, the OLDEST — strictly: without this the four resident workgroups
-        // of a CU finish their tiles after 190 / 215 / 243 / 272 us in dispatch order (tools/experiments/drift_probe.py; static priorities by
+        // of a CU finish their tiles after 190 / 215 / 243 / 272 us in dispatch order (git history, tools/experiments/drift_probe.py; static priorities by
         // rank reverse the staircase exactly).  Giving every workgroup a quarter of its chunks at each level makes them finish
         // within 10 us of each other and the kernel 2.3 % shorter (283.4 -> 276.9 us).  Two jobs in flight on two contexts lose
         // ~3 % with it (the staircase lets the next job's workgroups move in early): the single job is what is optimised.
@@ -1647,7 +1647,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint32_t tile_texels = T * T;
     uint32_t* tile = atlas + uint64_t(it.atlas_index) * tile_texels;
 #ifdef BT_DEBUG_HOOKS
-    // (134217728: real-time (100 MHz) stamps per workgroup — entry, set-up done, after each sweep, end — into the atlas's last layer; tools/experiments/direct_probe.py)
+    // (134217728: real-time (100 MHz) stamps per workgroup — entry, set-up done, after each sweep, end — into the atlas's last layer; git history, tools/experiments/direct_probe.py)
     auto stamp = [&](uint32_t slot) {
         if (BT_ABLATE(A, 134217728u) && tid == 0)
             reinterpret_cast<unsigned long long*>(atlas + uint64_t(A.m.atlas_size - 1u) * tile_texels)[work * 8u + slot] = __builtin_amdgcn_s_memrealtime();
@@ -1711,7 +1711,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const bool aprons_in_sweep = last_cx0 + 256u >= c + 2u * b;
     // A wave's priority falls as it gets on: the arbiter serves the OLDEST wave of a SIMD first, so on a one-generation launch the four
     // waves of a SIMD finish one after the other and the last runs alone at a single wave's issue rate (stamps of
-    // tools/experiments/direct_probe.py: workgroups ended 26 .. 62 us after the launch).  Waves that are behind overtake instead.
+    // git history, tools/experiments/direct_probe.py: workgroups ended 26 .. 62 us after the launch).  Waves that are behind overtake instead.
     const uint32_t prio_step = max(1u, (last_cx0 / 256u + 1u) * (blk_end - blk_begin) / 4u);
     uint32_t prio_left = prio_step, prio_level = 0;
     __builtin_amdgcn_s_setprio(3);
@@ -1740,7 +1740,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         const uint32_t half_sh = (tid & 1u) * 16u;  // the channel pair this lane finishes in the lane-split reductions
         const uint32_t off0 = uint32_t(ax.i0) * 4u, off1 = uint32_t(ax.i1) * 4u;  // (host: raster rows shorter than 2^32 bytes)
-        // Every instruction a wave issues — scalar ones too — takes a turn of its SIMD's one issue port (tools/experiments/issue_probe.hip): the
+        // Every instruction a wave issues — scalar ones too — takes a turn of its SIMD's one issue port (git history, tools/experiments/issue_probe.hip): the
         // per-row address steps are lane offsets computed once per sweep instead of scalar additions per row and block.
         uint32_t lo0[kRows + 1], lo1[kRows + 1], so[kRows];
 #pragma unroll
@@ -2226,7 +2226,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                 return a.side != b2.side ? a.side < b2.side : (a.y != b2.y ? a.y < b2.y : a.x < b2.x);
             });
 #ifdef BT_DEBUG_HOOKS
-        // workgroup -> tile experiments (tools/experiments/order_search.py): a file of item_count u32, position i of the (XCD-contiguous)
+        // workgroup -> tile experiments (git history, tools/experiments/order_search.py): a file of item_count u32, position i of the (XCD-contiguous)
         // work order runs the tile at that position of the tile-row order
         if (const char* e = getenv("BT_FUSED_ORDER")) {
             std::vector<uint32_t> perm(items.size());

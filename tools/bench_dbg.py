@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py against the profiling build of the library (tools/libbevy_terrain_amd_dbg.so, `make -C
 bevy_terrain_amd/csrc debug`), whose fused kernels honour the BT_FUSED_* ablation variables.  Results of ablated
-runs are NOT valid tiles; this exists only for tools/experiments/ablate_sweep.sh."""
+runs are NOT valid tiles; this exists only for git history, tools/experiments/ablate_sweep.sh."""
 import os
 import sys
 

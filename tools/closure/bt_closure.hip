@@ -3,7 +3,7 @@
 //   (i)  a LINEAR copy of the 16k job's byte mix: 536 870 912 bytes read, 704 643 072 written (1024 finest + 320 parent tiles of 512 KiB:
 //        every 16-byte vector goes to the first destination, 5 of every 16 also to a second one), grid-stride, 4 x 16 bytes in flight per
 //        lane, plain and non-temporal;
-//   (ii) the MEMORY SKELETON of fused_main ("V1" of tools/experiments/dma_skeleton.hip, rounds 3-5): the same bytes through the same addresses in
+//   (ii) the MEMORY SKELETON of fused_main ("V1" of git history, tools/experiments/dma_skeleton.hip, rounds 3-5): the same bytes through the same addresses in
 //        the same workgroup -> tile order — LDS-DMA of the 1056-byte source rows into a 32-row ring two chunks ahead, one dword per lane
 //        for the finest rows (4-byte shifted like the b = 2 apron), a quarter-size parent row per two tile rows — with 24 packed FMAs per
 //        output row standing in for the arithmetic (and with none).

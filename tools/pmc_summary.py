@@ -24,7 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KINDS = ("fused_main", "fused_tail2", "fused_tail", "fused_direct_rgba8", "fused_corner", "stitch_region", "split", "downsample", "stitch")
 ALIAS = {"fused_tail2": "fused_tail", "fused_direct_rgba8": "fused_direct", "stitch_region": "stitch"}
 WORKLOADS = {"headline_16k": "synthetic 16384^2 fBm R16 (seed 42), lod_count 6, 1365 tiles (bench.py)",
-             "config3_masked_16k": "the same with the 5 % no-data mask (seed 43)",
+             "config3_masked_16k": "the same with the 5 % no-data mask (seed 43), re-runs of a kept queue (previous values are fetched)",
+             "config3_masked_16k_fresh": "the same, every run on an atlas nothing has written since bt_atlas_create (prev_zero: no previous-value fetches)",
              "config2_height_4k": "4096^2 R16, lod_count 4, 85 tiles",
              "config2_albedo_4k": "4096^2 Rgba8, lod_count 4, 85 tiles",
              "config5_cube_height_8k": "6 x 8192^2 R16 faces, lod_count 5, 2046 tiles"}
@@ -66,7 +67,7 @@ def traffic(c):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     # algorithmic bytes per (workload, kernel) from the benches' own launch profiles
@@ -77,10 +78,10 @@ def main():
             algorithmic["headline_16k"][l["kind"]] = l["algorithmic_bytes"]
     except (OSError, ValueError, KeyError):
         pass
-    for name in ("config_bench.json", "masked16k.json"):
+    for name in ("config_bench.json", "masked16k.json", "end_to_end_examples.json"):
         try:
             for w, rec in json.load(open(os.path.join(src, name))).items():
-                for l in rec["launches"]:
+                for l in rec.get("launches") or []:
                     algorithmic[w][l[0]] = l[2]
         except (OSError, ValueError, KeyError, IndexError):
             pass
@@ -124,7 +125,8 @@ def main():
         files = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
         if files:
             shutil.copy(files[0], os.path.join(dst, f"{tag}_{name}"))
-    for name in ("bench_n1_verified.json", "bench_under_rocprofv3.json", "config_bench.json", "masked16k.json", "refine_bench.json"):
+    for name in ("bench_n1_verified.json", "bench_under_rocprofv3.json", "config_bench.json", "masked16k.json", "refine_bench.json", "end_to_end_examples.json",
+                 "closure.json"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
     for w, rec in workloads.items():

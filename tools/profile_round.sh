@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collect the judged profile artefacts of one round on the GPU box:
-#   tools/profile_round.sh r05       (run through gpurun from the repo root)
+#   tools/profile_round.sh r06       (run through gpurun from the repo root)
 # writes gpurun_out/<tag>/...; tools/pmc_summary.py then condenses them into profiles/<tag>_*.
 # Counters are collected in their own passes (one --pmc group per run, kernel trace only), for FIVE workloads: the headline job and
-# the four parity configurations whose roofline fractions DESIGN.md quotes (masked 16k, config 2 height / albedo, config 5 cube).
+# the parity configurations whose roofline fractions DESIGN.md quotes (masked 16k re-run and fresh, config 2 height / albedo, config 5 cube).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
@@ -29,11 +29,19 @@ pmc() {  # workload name, then the command
   rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d $O/pmc/$w/wrreq -o p -- "$@" > /dev/null 2> $O/pmc_${w}_wrreq.log
 }
 pmc headline_16k $B --steps 3 --warmup 1 --spinup-ms 0
-for w in config3_masked_16k config2_height_4k config2_albedo_4k config5_cube_height_8k; do
+for w in config3_masked_16k config3_masked_16k_fresh config2_height_4k config2_albedo_4k config5_cube_height_8k; do
   pmc $w $C --only $w --steps 3
 done
 # the non-headline BASELINE configs (parity cases) with durations, and the tiling prepass, for the record
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/config_stats -o cfg -- $C > $O/config_bench.json 2> $O/config_bench.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/masked_stats -o cfg -- $C --masked16k > $O/masked16k.json 2> $O/masked16k.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/masked_stats -o cfg -- $C --masked16k --fresh > $O/masked16k.json 2> $O/masked16k.log
+# the reference's two examples end to end (sources in host memory -> files written), streamed with the serial legs beside them
+$C --end-to-end > $O/end_to_end_examples.json 2> $O/end_to_end_examples.log
+# the closure record of fused_main: kernel, memory skeleton and linear copy of the byte mix from ONE process (the bench line's roofline block)
+python - "$O" <<'PY'
+import json, sys
+line = json.load(open(sys.argv[1] + "/bench_n1_verified.json"))
+json.dump({"ms_per_step": line["ms_per_step"], "roofline": line["roofline"]}, open(sys.argv[1] + "/closure.json", "w"), indent=1)
+PY
 python $R/tools/refine_bench.py --sweep > $O/refine_bench.json 2> $O/refine_bench.log
 find $O -name '*.csv' | sort | head -60
