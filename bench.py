@@ -896,7 +896,7 @@ def main():
     if cube:
         args.no_cpu_baseline = args.no_end_to_end = True  # the side measurements belong to the headline workload
         args.verify = False
-    if rank == 0 and world == 1 and not args.no_end_to_end:
+    if rank == 0 and world == 1 and not args.no_end_to_end and not os.environ.get("BT_BENCH_SKIP_16K_E2E"):
         try:
             line["end_to_end"] = end_to_end(device, src_ptr)
         except Exception as e:  # never lose the headline line over a side measurement
@@ -907,15 +907,16 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import workloads
 
-            line["config"]["workloads"] = workloads.all_workloads(device)
+            line["config"]["workloads"] = workloads.all_workloads(device) if not os.environ.get("BT_BENCH_SKIP_WORKLOADS") else None
         except Exception as e:
             line["config"]["workloads"] = {"error": repr(e)}
-        if not args.no_end_to_end and isinstance(line.get("end_to_end"), dict) and "error" not in line["end_to_end"]:
+        if not args.no_end_to_end:
+            line.setdefault("end_to_end", {})
             # the reference's own two examples end to end (preprocessor.rs:363,419), streamed with the serial legs beside them
             try:
                 line["end_to_end"]["reference_examples"] = {
-                    "config2_planar_height_albedo": workloads.end_to_end_config2(device, passes=3),
-                    "config5_cube_height": workloads.end_to_end_config5(device, passes=3)}
+                    "config2_planar_height_albedo": workloads.end_to_end_config2(device, passes=9),  # (7 ms a pass; the first pass behind the serial ones is an outlier)
+                    "config5_cube_height": workloads.end_to_end_config5(device, passes=5)}
             except Exception as e:
                 line["end_to_end"]["reference_examples"] = {"error": repr(e)}
     if world > 1 and not cube and extras and not args.no_end_to_end:

@@ -58,9 +58,11 @@ def main():
     if "--masked16k" in sys.argv or (ONLY or "").startswith("config3_masked_16k"):
         # --fresh (or --only config3_masked_16k_fresh): also each run on an atlas nothing has written since bt_atlas_create (6 of them)
         fresh = "--fresh" in sys.argv or ONLY == "config3_masked_16k_fresh"
-        print(json.dumps(W.masked16k(device, STEPS or 20, fresh_atlases=(max(4, STEPS or 6) if fresh else 0), rerun=ONLY != "config3_masked_16k_fresh")))
+        # (--clean: the same passes over the raster WITHOUT the mask — what a fresh, memset atlas alone does to the counters)
+        print(json.dumps(W.masked16k(device, STEPS or 20, fresh_atlases=(max(4, STEPS or 6) if fresh else 0), rerun=ONLY != "config3_masked_16k_fresh", mask="--clean" not in sys.argv)))
         return
-    out.update(W.config2(device, STEPS or 50, only=ONLY if (ONLY or "").startswith("config2") else None))
+    if not ONLY or ONLY.startswith("config2"):  # (--only config5_...: no config 2 launch in the process — counter passes average per kernel name)
+        out.update(W.config2(device, STEPS or 50, only=ONLY))
     if "--config2" in sys.argv or (ONLY and ONLY.startswith("config2")):
         print(json.dumps(out))
         return

@@ -12,7 +12,7 @@ mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 # the profiled command runs every job on ONE stream (--pipeline 1): a kernel that shares the GPU with another job's has no
 # duration of its own; the roofline of the default (pipelined) bench line is computed from its one-stream pass too
-B="python $R/bench.py --no-cpu-baseline --no-end-to-end --no-extras"
+B="python $R/bench.py --no-cpu-baseline --no-end-to-end --no-extras --no-workloads"  # (only the headline job's kernels in the profiled process)
 C="python $R/tools/config_bench.py"
 
 python $R/bench.py --verify > $O/bench_n1_verified.json 2> $O/bench.log

@@ -86,9 +86,11 @@ def config2(device, steps=50, only=None):
     return out
 
 
-def masked_source(device, size=16384):
+def masked_source(device, size=16384, mask=True):
     """the 16k fBm raster with the 5 % no-data mask of tests/test_gpu_preprocess.py (seed 43: 37 x 53 texel cells + single texels)"""
     ptr = device.synth_fbm_r16(size, size, 42)
+    if not mask:
+        return ptr
     src = device.download(ptr, (size, size), np.uint16)
     rng = np.random.default_rng(43)
     cells = rng.random((size // 37 + 1, size // 53 + 1)) < 0.05
@@ -100,10 +102,10 @@ def masked_source(device, size=16384):
     return device.upload(src)
 
 
-def masked16k(device, steps=20, fresh_atlases=6, rerun=True):
+def masked16k(device, steps=20, fresh_atlases=6, rerun=True, mask=True):
     """-> {"config3_masked_16k": re-run on a written atlas, "config3_masked_16k_fresh": each run on an atlas nothing has written}"""
     size, lods = 16384, 6
-    ptr = masked_source(device, size)
+    ptr = masked_source(device, size, mask)
     cfg = planar_cfg(lods, 2048, "terrains/masked16k", [("height", bt.AttachmentFormat.R16)])
     server = bt.AssetServer().insert("m", (ptr, size, size))
     ds = bt.PreprocessDataset(attachment_index=0, path="m", lod_range=range(0, lods))
