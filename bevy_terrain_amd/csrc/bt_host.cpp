@@ -810,6 +810,13 @@ class TileSaver {
                 hipError_t e = hipMemcpy2DAsync(pinned[k], at.tile_bytes * runs[0].second, (const uint8_t*)at.level0 + at.tile_bytes * tiles[lo].first,
                                                 at.tile_bytes * stride, at.tile_bytes * runs[0].second, runs.size(), hipMemcpyDeviceToHost, stream_);
                 if (e != hipSuccess) return hip_fail(e, "tile download");
+            } else if (runs.size() > 2 && hi - lo <= 64 && at.tile_bytes % 16u == 0) {
+                // an irregular chunk (the lower LODs behind a band's tiles, a cube's face-edge tiles, merged hand-overs): ONE gather kernel that
+                // writes the pinned buffer over PCIe instead of one copy-engine call per run — a burst of small copy calls stalled the issuing
+                // thread for 15 - 20 ms now and then (config 2's 37-tile chunk: 2.2 -> 21.0 ms between two stamps, round 6 traces), the kernel never
+                uint32_t layers[64];
+                for (size_t i = lo; i < hi; i++) layers[i - lo] = tiles[i].first;
+                if (bt_status s = launch_gather_layers(stream_, at.level0, layers, uint32_t(hi - lo), pinned[k], at.tile_bytes)) return s;
             } else {
                 for (const auto& [i, run] : runs) {
                     hipError_t e = hipMemcpyAsync((uint8_t*)pinned[k] + at.tile_bytes * (i - lo), (const uint8_t*)at.level0 + at.tile_bytes * tiles[i].first,
@@ -1720,6 +1727,10 @@ bt_status run_streamed_impl(bt_preprocessor* p, bt_atlas* a, bt_comm* comm, cons
             st.bands += uint32_t(bands.size());
         }
     }
+    // (a sharded one-call run whose plan has no finishing launch — a single-LOD job — still owes the step its collective)
+    bool exchange_scheduled = false;
+    for (const StreamStep& sp : steps) exchange_scheduled = exchange_scheduled || sp.exchange_before;
+    const bool exchange_at_end = sharded && comm && local && finish && !exchange_scheduled;
     const bool streamable = st.bands > 1;
     if (!streamable) {  // the same result, one leg after the other
         const uint32_t keep = mode | BT_RUN_KEEP_QUEUE;
@@ -1918,6 +1929,7 @@ bt_status run_streamed_impl(bt_preprocessor* p, bt_atlas* a, bt_comm* comm, cons
         if (rc == BT_OK && hipEventRecord(computed[k], p->ctx->stream) != hipSuccess) rc = BT_ERR_DEVICE;
         if (rc == BT_OK) publish(k + 1);
     }
+    if (rc == BT_OK && exchange_at_end) rc = shard_exchange(p, a, comm, p->ctx->stream, true);
     // a raster counts as uploaded only when every band of it went out; after a failure a later run of the kept queue uploads it whole
     if (rc == BT_OK)
         for (size_t i = 0; i < p->rasters.size(); i++)

@@ -241,6 +241,7 @@ bt_status launch_stitch(bt_ctx* ctx, const AttachmentMeta& m, void* atlas, const
 bt_status launch_sample(bt_ctx* ctx, const AttachmentMeta& m, const void* atlas, const bt_tile_lookup* lookups, uint32_t count, float* out);
 bt_status launch_mip_level(bt_ctx* ctx, uint32_t format, const void* parent, void* child, uint32_t parent_size,
                            uint32_t layers);
+bt_status launch_gather_layers(hipStream_t stream, const void* atlas, const uint32_t* layers, uint32_t count, void* pinned_dst, uint64_t tile_bytes);
 bt_status launch_synth_fbm(bt_ctx* ctx, void* dst, uint32_t w, uint32_t h, uint64_t pitch, uint32_t x0, uint32_t y0,
                            uint32_t base_cell, uint32_t octaves, uint32_t seed);
 

@@ -619,6 +619,32 @@ bt_status launch_mip_level(bt_ctx* ctx, uint32_t format, const void* parent, voi
     return check_launch("mip kernel");
 }
 
+// Tile download as ONE kernel per chunk: the layers of a chunk gathered straight into a pinned host buffer (16-byte vectors, the GPU writes
+// host memory over PCIe) — instead of one copy-engine call per run of consecutive layers.  tile_bytes % 16 == 0 (rows are whole dwords, T even).
+struct GatherLayers {
+    uint32_t layer[64];
+};
+typedef uint32_t gather_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gather_layers_kernel(const gather_u32x4* __restrict__ atlas, GatherLayers list, gather_u32x4* __restrict__ dst, uint32_t vec_per_tile) {
+    const uint32_t tile = blockIdx.y;
+    const gather_u32x4* src = atlas + uint64_t(list.layer[tile]) * vec_per_tile;
+    gather_u32x4* out = dst + uint64_t(tile) * vec_per_tile;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < vec_per_tile; i += gridDim.x * 256u) out[i] = __builtin_nontemporal_load(src + i);
+}
+bt_status launch_gather_layers(hipStream_t stream, const void* atlas, const uint32_t* layers, uint32_t count, void* pinned_dst, uint64_t tile_bytes) {
+    if (!count) return BT_OK;
+    if (count > 64 || tile_bytes % 16u) {
+        set_error("gather of %u layers of %llu bytes", count, (unsigned long long)tile_bytes);
+        return BT_ERR_INVALID_ARGUMENT;
+    }
+    GatherLayers list{};
+    for (uint32_t i = 0; i < count; i++) list.layer[i] = layers[i];
+    const uint32_t vec = uint32_t(tile_bytes / 16u);
+    const uint32_t bx = std::max(1u, std::min(32u, vec / 1024u));  // >= 4 vectors per thread
+    gather_layers_kernel<<<dim3(bx, count), 256, 0, stream>>>((const gather_u32x4*)atlas, list, (gather_u32x4*)pinned_dst, vec);
+    return check_launch("gather_layers_kernel");
+}
+
 bt_status launch_synth_fbm(bt_ctx* ctx, void* dst, uint32_t w, uint32_t h, uint64_t pitch, uint32_t x0, uint32_t y0,
                            uint32_t base_cell, uint32_t octaves, uint32_t seed) {
     const uint64_t total = uint64_t(w) * h;
