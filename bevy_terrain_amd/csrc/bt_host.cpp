@@ -1622,9 +1622,16 @@ bt_status upload_pending_rasters(bt_preprocessor* p, const std::vector<uint8_t>*
 }  // namespace bt
 
 namespace {
+// The upload and download queues of the streamed run.  They get NON-DEFAULT PRIORITIES — not for the priority's sake: the runtime maps HIP
+// streams onto a handful of hardware queues round-robin PER PRIORITY CLASS, and a process that owns a few other default-priority streams
+// (a host application does; bench.py's second lane does) can land the download stream on the kernels' own hardware queue, where every copy
+// then waits behind the next bands' kernels: config 2 end to end 6.6 -> 8.9 ms with exactly one extra stream in the process (round 6
+// probe).  A class of their own keeps the three queues apart whatever else the process has created.
 bt_status ctx_side_streams(bt_ctx* ctx) {
-    if (!ctx->copy_stream) BT_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    if (!ctx->save_stream) BT_HIP(hipStreamCreateWithFlags(&ctx->save_stream, hipStreamNonBlocking));
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+    if (!ctx->copy_stream) BT_HIP(hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, greatest));
+    if (!ctx->save_stream) BT_HIP(hipStreamCreateWithPriority(&ctx->save_stream, hipStreamNonBlocking, least));
     return BT_OK;
 }
 
