@@ -42,7 +42,7 @@ def draw_case(seed):
 
 
 @pytest.mark.parametrize("seed", range(FUZZ, FUZZ + 160))
-def test_random_job_matches_oracle(device, seed):
+def test_random_job_matches_oracle(device, seed, tmp_path):
     p = draw_case(seed)
     T, b, lods, fmt = p["T"], p["b"], p["lods"], p["fmt"]
     if p["cube"]:
@@ -57,10 +57,21 @@ def test_random_job_matches_oracle(device, seed):
             server.insert(path, f)
         pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_spherical(
             bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lods)), server, atlas)
-        pre.run(atlas)
+        pre.run(atlas, keep_queue=True)
         oracle = O.OracleAtlas(lods, 2100, True, [(T, b, 1, fmt)])
         oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(16)
-        assert K.assert_atlas_equal(atlas, oracle) == 6 * sum(4 ** l for l in range(lods)), p
+        n_tiles = 6 * sum(4 ** l for l in range(lods))
+        assert K.assert_atlas_equal(atlas, oracle) == n_tiles, p
+        # round 6: the first run found the atlas unwritten (previous values of no-data pixels taken as 0 without a fetch); the re-run of the kept
+        # queue finds it written and FETCHES them — the same tiles; and the streamed pipeline (six deferred faces, band by band) writes the same files
+        pre.run(atlas)
+        assert K.assert_atlas_equal(atlas, oracle) == n_tiles, (p, "re-run")
+        atlas2 = bt.TileAtlas.new(cfg, device)
+        pre2 = bt.Preprocessor.new().clear_attachment(0, atlas2, str(tmp_path)).preprocess_spherical(
+            bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lods)), server, atlas2, defer_upload=True)
+        pre2.run_streamed(atlas2, str(tmp_path))
+        assert K.assert_atlas_equal(atlas2, oracle) == n_tiles, (p, "streamed")
+        assert len(os.listdir(atlas2.attachment_directory(str(tmp_path), 0))) == n_tiles
         return
     src = K.random_raster(fmt, p["H"], p["W"], seed, holes=p["holes"])
     over = K.random_raster(fmt, max(p["H"] // 2, 8), max(p["W"] // 3, 8), seed + 5000, holes=0.25)
@@ -80,5 +91,18 @@ def test_random_job_matches_oracle(device, seed):
             bt.PreprocessDataset(attachment_index=0, path="src", lod_range=range(*lod_range), **p["ds"]), server, atlas)
         if p["overlay"]:
             pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="over", lod_range=range(*lod_range), **over_ds), server, atlas)
-        pre.run(atlas, generic=generic)
-        assert K.assert_atlas_equal(atlas, oracle) > 0, (p, generic)
+        pre.run(atlas, generic=generic, keep_queue=not p["overlay"])
+        n_tiles = K.assert_atlas_equal(atlas, oracle)
+        assert n_tiles > 0, (p, generic)
+        if not p["overlay"]:  # the kept queue once more, onto written tiles: no-data pixels now FETCH their previous value (round 6: the first run did not)
+            pre.run(atlas, generic=generic)
+            assert K.assert_atlas_equal(atlas, oracle) == n_tiles, (p, generic, "re-run")
+    # ... and the same queue through the streamed pipeline (deferred rasters, band by band where the plan is a fused one): same atlas, same file count
+    atlas = bt.TileAtlas.new(cfg, device)
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas, str(tmp_path)).preprocess_tile(
+        bt.PreprocessDataset(attachment_index=0, path="src", lod_range=range(*lod_range), **p["ds"]), server, atlas, defer_upload=True)
+    if p["overlay"]:
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="over", lod_range=range(*lod_range), **over_ds), server, atlas, defer_upload=True)
+    pre.run_streamed(atlas, str(tmp_path))
+    assert K.assert_atlas_equal(atlas, oracle) == n_tiles, (p, "streamed")
+    assert len(os.listdir(atlas.attachment_directory(str(tmp_path), 0))) == n_tiles
