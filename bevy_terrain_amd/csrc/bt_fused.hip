@@ -924,6 +924,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                     // smallest raw texel this thread read for the rows of a quad (source rows 4 * quad .. 4 * quad + 4), per column pair half
                     u16x2 zmin[2] = {__builtin_elementwise_min(ta, tb), u16x2{0xFFFFu, 0xFFFFu}};
                     uint32_t zq[2] = {1u, 1u};
+                    uint32_t sink[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // (ablation 1073741824 only)
                     uint32_t* dst5 = tile5_u32 + (((b + cr0) * T + px0) >> 1);
 #pragma unroll
                     for (uint32_t quad = 0; quad < 2; quad++) {
@@ -969,6 +970,16 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                     for (uint32_t i = 0; i < 4; i++) {
                                         if (min(z[i].x, z[i + 1].x) == 0) ua[i] = 0;
                                         if (min(z[i].y, z[i + 1].y) == 0) ub[i] = 0;
+                                    }
+                                } else if (BT_ABLATE(A, 1073741824u)) {
+                                    // (1073741824, timing only, WRONG tiles: the fetches are issued but nobody waits for them before the chunk's
+                                    // barrier — the bound of any scheme that defers a no-data quad: profiles/r06_masked16k.txt)
+#pragma unroll
+                                    for (uint32_t i = 0; i < 4; i++) {
+                                        if (min(z[i].x, z[i + 1].x) == 0) ua[i] = 0;
+                                        if (min(z[i].y, z[i + 1].y) == 0) ub[i] = 0;
+                                        asm volatile("global_load_ushort %0, %1, off" : "=v"(sink[2 * i]) : "v"(h + i * T + rxa) : "memory");
+                                        asm volatile("global_load_ushort %0, %1, off" : "=v"(sink[2 * i + 1]) : "v"(h + i * T + rxb) : "memory");
                                     }
                                 } else {
 #pragma unroll
@@ -1059,6 +1070,11 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                     for (uint32_t e = 1; e < x3_count; e++) t[e] = uint16_t(w3);
                             }
                         }
+                    }
+                    if (BT_ABLATE(A, 1073741824u)) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the chunk barrier's own wait, a few instructions early)
+#pragma unroll
+                        for (uint32_t i = 0; i < 8; i++) asm volatile("" ::"v"(sink[i]));
                     }
                 } else {
                 uint32_t zrow = 1;  // smallest raw texel of the row hblend converted last
