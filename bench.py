@@ -667,6 +667,39 @@ def main():
                 n1_reference = {"error": repr(e)}
         fence()
 
+    # N > 1: every rank preprocesses a WHOLE 16k job of its own at the same time — no strip, no collective: what a host with one terrain per GPU
+    # gets ("independent terrain tiles shard naturally"); aggregate tiles/s = N x tiles / the slowest rank's step.  Not the headline (that is ONE
+    # job shared by the ranks); reported so that the line holds the collective-free end of the range next to the replicated one.
+    independent = None
+    if world > 1 and not cube and not args.no_extras:
+        try:
+            d2 = bt.Device(local_rank)
+            full2 = d2.synth_fbm_r16(SIZE, SIZE, SEED + rank)
+            a2 = bt.TileAtlas.new(cfg, d2)
+            q2 = bt.Preprocessor.new().clear_attachment(0, a2).preprocess_tile(
+                bt.PreprocessDataset(attachment_index=0, path="own", lod_range=range(0, lod_count)), bt.AssetServer().insert("own", (full2, SIZE, SIZE)), a2)
+            for _ in range(max(10, args.warmup)):
+                q2.run(a2, generic=args.generic, keep_queue=True, sync=False)
+            d2.synchronize()
+            fence()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(d2.torch_stream)
+            for _ in range(args.steps):
+                q2.run(a2, generic=args.generic, keep_queue=True, sync=False)
+            e1.record(d2.torch_stream)
+            d2.synchronize()
+            t2 = torch.tensor([e0.elapsed_time(e1) / args.steps], device="cuda")
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            t2 = float(t2.item())
+            independent = {"ms_per_step": t2, "tiles_per_s": world * q2.stats()["tiles"] / (t2 / 1e3), "jobs": world,
+                           "note": "one whole 16k job per rank at the same time (seeds 42 + rank), no collective; max over ranks"}
+            q2.close()
+            d2.free(full2)
+            del a2
+        except Exception as e:
+            independent = {"error": repr(e)}
+        fence()
+
     def timed_pass(fn, on_stream=None):
         """K calls of fn between two events on `on_stream`, fenced on both sides, max over ranks; ms per call"""
         st = on_stream or stream
@@ -766,6 +799,7 @@ def main():
                    "all_gather_bytes_per_rank": (job.gather_bytes if job is not None else 0),
                    "rccl_preflight": preflight if world > 1 else None,  # N > 1: the one-tile-per-rank collective that ran before anything was timed
                    "n1_same_invocation": n1_reference,  # N > 1: the unsharded step on rank 0's GPU, this invocation
+                   "independent_jobs": independent,  # N > 1: one whole job per rank at the same time, no collective (aggregate tiles/s)
                    "source_window_rank0": source_window,  # N > 1: the part of the source rank 0 generated (its strips + halo); the rest stays zero
                    "result": (None if job is None else
                               "replicated: every rank ends with the full atlas" if job.held is None else

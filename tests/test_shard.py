@@ -209,6 +209,7 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(result, held_tiles):
     # scaling of every mode against it
     assert cfg["rccl_preflight"]["ranks"] == 2 and cfg["rccl_preflight"]["slot_bytes"] == 512 * 512 * 2 and "gloo" in cfg["rccl_preflight"]["through"]
     assert cfg["n1_same_invocation"]["ms_per_step"] > 0
+    assert cfg["independent_jobs"]["jobs"] == 2 and cfg["independent_jobs"]["tiles_per_s"] > 0
     sc = cfg["scaling_vs_n1_same_invocation"]
     assert sc["headline"]["speedup"] > 0 and abs(sc["headline"]["efficiency"] - sc["headline"]["speedup"] / 2) < 1e-12
     assert f"{result}_overlapped" in sc and "kernels_only" in sc
