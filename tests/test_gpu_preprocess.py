@@ -1079,3 +1079,44 @@ def test_fresh_atlas_takes_the_previous_value_as_zero_without_fetching(device, f
     pre.run(atlas)
     assert pre.stats()["prev_zero_launches"] == 0
     assert K.assert_atlas_equal(atlas, oracle) == tiles
+
+
+def test_config5_streamed_at_full_size_writes_the_serial_path_s_files(device, tmp_path):
+    """BASELINE config 5's height job at full size (6 faces of 8192^2 R16, lod_count 5, 2046 tiles, 0.8 GB in / 1.07 GB out) through the streamed
+    pipeline: 24 bands of 4 tile rows, 1176 interior finest tiles leave with their bands, the 360 face-edge ones and the 510 parents behind
+    the seam stitch.  Every file equals the serial path's (whose atlas test_config5_* compares with the executed WGSL)."""
+    import hashlib
+
+    W, lods = 8192, 5
+    faces = [K.smooth_raster(W, W, seed=7 + s, device=device) for s in range(6)]
+    for s in range(6):
+        faces[s][4000 + 13 * s:4100 + 13 * s, 0:900] = 0  # no data up to a face edge, across a band seam (tile rows 7 | 8: mosaic row 4064)
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=2048, path="terrains/spherical")
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=512, border_size=2, format=bt.AttachmentFormat.R16))
+    server = bt.AssetServer()
+    paths = [f"face{s}" for s in range(6)]
+    for pth, f in zip(paths, faces):
+        server.insert(pth, f)
+    digests = []
+    for streamed in (False, True):
+        root = str(tmp_path / ("streamed" if streamed else "serial"))
+        atlas = bt.TileAtlas.new(cfg, device)
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas, root).preprocess_spherical(
+            bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lods)), server, atlas, defer_upload=streamed)
+        if streamed:
+            st = pre.run_streamed(atlas, root)
+            assert st["streamed"] and st["bands"] == 24 and st["early_tiles"] == 6 * 14 * 14
+            assert st["uploaded_bytes"] == 6 * W * W * 2 and st["saved_bytes"] == 2046 * 512 * 512 * 2
+        else:
+            pre.run(atlas)
+            pre.save(atlas, root)
+        d = atlas.attachment_directory(root, 0)
+        names = sorted(os.listdir(d))
+        assert len(names) == 2046
+        digests.append({n: hashlib.sha256(open(os.path.join(d, n), "rb").read()).hexdigest() for n in names})
+        digests[-1]["config.tc"] = hashlib.sha256(open(os.path.join(root, "terrains/spherical/config.tc"), "rb").read()).hexdigest()
+        atlas.close()
+        import shutil
+
+        shutil.rmtree(root, ignore_errors=True)
+    assert digests[0] == digests[1]
