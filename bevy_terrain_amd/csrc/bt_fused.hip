@@ -80,7 +80,12 @@ struct FusedArgs {
     // instead of waiting for a launch of their own behind it.  seam_skip: the tail's own apron-row workgroups leave those regions alone.
     const TaskDev* seam_tasks;
     uint32_t seam_count, seam_skip;
-    uint32_t tail_extras;  // fused_tail: extra workgroups per side (apron blocks of the LODs above + that side's share of the seam regions)
+    // round 6: the cross-face regions of the LODs the tail ITSELF produces ride in it too — not as copies of the neighbour face's centre (another
+    // workgroup of this launch is still writing it) but PULLED: evaluated from the tail's input LOD on the neighbour face with the tail's own
+    // reduction (TaskDev::raster = LODs below the input, rel_index[region] = the neighbour tile's x << 16 | y).  seam_pull: the tail's pushes then
+    // leave a region beyond exactly one face edge alone instead of clamping into it (a pull workgroup writes it) — and no stitch launch follows.
+    uint32_t seam_pull;
+    uint32_t tail_extras;  // fused_tail: apron blocks per side (the top / bottom apron rows — Rgba8: and columns — of the LODs above)
     float tlx, tly, brx, bry;
     uint32_t lod;         // finest LOD of this launch (fused_main) / input LOD (fused_tail)
     uint32_t levels;      // LODs produced by this launch: main 1..3 (lod, lod-1, lod-2); tail 1..3 below lod
@@ -191,10 +196,14 @@ __device__ __forceinline__ void push_pixel(const FusedArgs& A, uint32_t side, ui
     const int ix = int(tx), iy = int(ty);
     // a neighbour at offset (dx, dy) sees our centre (cx, cy) at texture (b + cx - dx*c, b + cy - dy*c)
     const uint32_t ax = uint32_t(int(b + cx) - ex * int(c)), ay = uint32_t(int(b + cy) - ey * int(c));
+    // (cube, A.seam_pull: a neighbour beyond exactly ONE face edge lives on another face and a pull workgroup of this launch writes that region)
+    const int nn = int(1u << lod);
+    auto cross_face = [&](int x, int y) { return A.seam_pull != 0 && ((x < 0 || x >= nn) != (y < 0 || y >= nn)); };
     if (ex != 0) {
         const uint32_t n = grid_lookup(A, side, lod, ix + ex, iy);
         if (n != kInvalid) {
             atlas[uint64_t(n) * tile_texels + uint64_t(b + cy) * T + ax] = v;
+        } else if (cross_face(ix + ex, iy)) {
         } else if (cx == 0 || cx == c - 1) {  // absent: our outermost column is replicated into our own apron
             const uint32_t x0 = ex < 0 ? 0u : o;
             for (uint32_t j = 0; j < b; j++) self[uint64_t(b + cy) * T + x0 + j] = v;
@@ -204,6 +213,7 @@ __device__ __forceinline__ void push_pixel(const FusedArgs& A, uint32_t side, ui
         const uint32_t n = grid_lookup(A, side, lod, ix, iy + ey);
         if (n != kInvalid) {
             atlas[uint64_t(n) * tile_texels + uint64_t(ay) * T + b + cx] = v;
+        } else if (cross_face(ix, iy + ey)) {
         } else if (cy == 0 || cy == c - 1) {
             const uint32_t y0 = ey < 0 ? 0u : o;
             for (uint32_t j = 0; j < b; j++) self[uint64_t(y0 + j) * T + b + cx] = v;
@@ -213,6 +223,7 @@ __device__ __forceinline__ void push_pixel(const FusedArgs& A, uint32_t side, ui
         const uint32_t n = grid_lookup(A, side, lod, ix + ex, iy + ey);
         if (n != kInvalid) {
             atlas[uint64_t(n) * tile_texels + uint64_t(ay) * T + ax] = v;
+        } else if (cross_face(ix + ex, iy + ey)) {
         } else if ((cx == 0 || cx == c - 1) && (cy == 0 || cy == c - 1)) {  // corner region clamps both axes
             const uint32_t x0 = ex < 0 ? 0u : o, y0 = ey < 0 ? 0u : o;
             for (uint32_t j = 0; j < b; j++)
@@ -229,16 +240,22 @@ __device__ __forceinline__ void push_pixel(const FusedArgs& A, uint32_t side, ui
 struct PushNb {
     int ex, ey;
     uint32_t nx, ny, nxy;
+    uint32_t skip;  // bit 0 / 1 / 2: the x / y / diagonal neighbour lies beyond exactly one face edge of a cube and a pull workgroup writes that region (A.seam_pull)
 };
 __device__ __forceinline__ PushNb push_targets(const FusedArgs& A, uint32_t side, uint32_t lod, uint32_t tx, uint32_t ty, uint32_t cx, uint32_t cy, bool active) {
     const uint32_t b = A.m.border_size, c = A.m.center_size;
-    PushNb t{0, 0, kInvalid, kInvalid, kInvalid};
+    PushNb t{0, 0, kInvalid, kInvalid, kInvalid, 0u};
     if (!active) return t;
     t.ex = cx < b ? -1 : (cx >= c - b ? 1 : 0);
     t.ey = cy < b ? -1 : (cy >= c - b ? 1 : 0);
     if (t.ex != 0) t.nx = grid_lookup(A, side, lod, int(tx) + t.ex, int(ty));
     if (t.ey != 0) t.ny = grid_lookup(A, side, lod, int(tx), int(ty) + t.ey);
     if (t.ex != 0 && t.ey != 0) t.nxy = grid_lookup(A, side, lod, int(tx) + t.ex, int(ty) + t.ey);
+    if (A.seam_pull) {
+        const int nn = int(1u << lod), x = int(tx) + t.ex, y = int(ty) + t.ey;
+        const bool out_x = x < 0 || x >= nn, out_y = y < 0 || y >= nn;
+        t.skip = (t.ex != 0 && out_x ? 1u : 0u) | (t.ey != 0 && out_y ? 2u : 0u) | (t.ex != 0 && t.ey != 0 && out_x != out_y ? 4u : 0u);
+    }
     return t;
 }
 template <typename TT = uint16_t>
@@ -252,6 +269,7 @@ __device__ __forceinline__ void push_store(const FusedArgs& A, const PushNb& t, 
     if (t.ex != 0) {
         if (t.nx != kInvalid) {
             atlas[uint64_t(t.nx) * tile_texels + uint64_t(b + cy) * T + ax] = v;
+        } else if (t.skip & 1u) {
         } else if (cx == 0 || cx == c - 1) {
             const uint32_t x0 = t.ex < 0 ? 0u : o;
             for (uint32_t j = 0; j < b; j++) self[uint64_t(b + cy) * T + x0 + j] = v;
@@ -260,6 +278,7 @@ __device__ __forceinline__ void push_store(const FusedArgs& A, const PushNb& t, 
     if (t.ey != 0) {
         if (t.ny != kInvalid) {
             atlas[uint64_t(t.ny) * tile_texels + uint64_t(ay) * T + b + cx] = v;
+        } else if (t.skip & 2u) {
         } else if (cy == 0 || cy == c - 1) {
             const uint32_t y0 = t.ey < 0 ? 0u : o;
             for (uint32_t j = 0; j < b; j++) self[uint64_t(y0 + j) * T + b + cx] = v;
@@ -268,6 +287,7 @@ __device__ __forceinline__ void push_store(const FusedArgs& A, const PushNb& t, 
     if (t.ex != 0 && t.ey != 0) {
         if (t.nxy != kInvalid) {
             atlas[uint64_t(t.nxy) * tile_texels + uint64_t(ay) * T + ax] = v;
+        } else if (t.skip & 4u) {
         } else if ((cx == 0 || cx == c - 1) && (cy == 0 || cy == c - 1)) {
             const uint32_t x0 = t.ex < 0 ? 0u : o, y0 = t.ey < 0 ? 0u : o;
             for (uint32_t j = 0; j < b; j++)
@@ -1344,6 +1364,84 @@ __device__ __forceinline__ uint32_t down_one_r16(uint32_t t00, uint32_t t01, uin
     return uint32_t(w);
 }
 
+// Pixel (mx, my) of the LOD-`lod` mosaic of face `side`, evaluated from the tail's INPUT LOD (lod + K, complete when the launch starts) with the
+// tail's own reduction in its own order — (x, y), (x, y + 1), (x + 1, y), (x + 1, y + 1), downsample.wgsl:25-39 per level, every level quantised —
+// i.e. bit for bit what the mosaic workgroups of this launch write into that tile's centre (R16).
+template <int K>
+__device__ __forceinline__ uint32_t pull_value_r16(const FusedArgs& A, uint32_t side, uint32_t lod, uint32_t mx, uint32_t my) {
+    if constexpr (K == 0) {
+        const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
+        const uint32_t tx = mx / c, ty = my / c;
+        const uint32_t idx = grid_lookup(A, side, lod, int(tx), int(ty));
+        if (idx == kInvalid) return 0u;  // an absent tile reads as no data, like the mosaic workgroups' loads
+        return A.atlas[uint64_t(idx) * T * T + uint64_t(b + my - ty * c) * T + b + mx - tx * c];
+    } else {
+        const uint32_t t00 = pull_value_r16<K - 1>(A, side, lod + 1u, 2u * mx, 2u * my), t01 = pull_value_r16<K - 1>(A, side, lod + 1u, 2u * mx, 2u * my + 1u);
+        const uint32_t t10 = pull_value_r16<K - 1>(A, side, lod + 1u, 2u * mx + 1u, 2u * my), t11 = pull_value_r16<K - 1>(A, side, lod + 1u, 2u * mx + 1u, 2u * my + 1u);
+        return down_one_r16(t00, t01, t10, t11);
+    }
+}
+
+// ONE cross-face apron region of a tile the tail itself produces (stitch.wgsl:12-51, 79-118), pulled: the texel the reference copies out of
+// the neighbour face's centre is evaluated from the tail's input instead (task.raster = LODs between the tile and the input; the neighbour
+// tile's coordinate rides in rel_index[region] as x << 16 | y).  One workgroup of 256 threads; kPack = 2: two adjacent pixels per dword store.
+template <uint32_t kPack>
+__device__ __forceinline__ void stitch_region_pull_r16(const FusedArgs& A, const TaskDev& task) {
+    const uint32_t Tsz = A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
+    const uint32_t region = uint32_t(__ffs(int(task.regions))) - 1u;  // 0 top, 1 right, 2 bottom, 3 left, 4 TL, 5 TR, 6 BR, 7 BL
+    const uint32_t x0 = (region == 0u || region == 2u) ? b : ((region == 1u || region == 5u || region == 6u) ? o : 0u);
+    const uint32_t y0 = (region == 1u || region == 3u) ? b : ((region == 2u || region == 6u || region == 7u) ? o : 0u);
+    const uint32_t w = (region == 0u || region == 2u) ? c : b, h = (region == 1u || region == 3u) ? c : b;
+    const int rx = (region == 1u || region == 5u || region == 6u) ? 1 : ((region == 3u || region == 4u || region == 7u) ? -1 : 0);
+    const int ry = (region == 2u || region == 6u || region == 7u) ? 1 : ((region == 0u || region == 4u || region == 5u) ? -1 : 0);
+    const uint32_t other = task.rel_side[region], nx = task.rel_index[region] >> 16, ny = task.rel_index[region] & 0xFFFFu;
+    // task.raster = levels | part << 8 | parts << 16: a region is shared out over `parts` workgroups (a thread then evaluates one pixel pair:
+    // the pull workgroups are the longest of the launch — 4^levels dependent-free loads per pixel — and must not outlast the mosaic's)
+    const uint32_t levels = task.raster & 0xFFu, part = (task.raster >> 8) & 0xFFu, parts = max(1u, task.raster >> 16);
+    const uint32_t count = (w / kPack) * h, share = (count + parts - 1u) / parts, i_end = min(count, (part + 1u) * share);
+    // levels <= 2: the 2^levels x 2^levels input block of a pixel lies in ONE input tile (c is a multiple of 4): one tile lookup, one division per axis
+    const uint32_t in_lod = task.lod + levels, cn = c >> levels;  // cn: pixels of this LOD one input tile's centre covers
+    for (uint32_t i = part * share + threadIdx.x; i < i_end; i += 256u) {
+        const uint32_t px = x0 + kPack * (i % (w / kPack)), py = y0 + i / (w / kPack);
+        if (py >= A.m.row_limit) continue;
+        uint32_t v[kPack];
+#pragma unroll
+        for (uint32_t e = 0; e < kPack; e++) {
+            // neighbour_data of stitch.wgsl: the apron texel as a texel of the neighbour tile (its centre: [b, b + c) on both axes), then as a pixel of its face's mosaic
+            const uint2 q = project_to_side(uint32_t(int(px + e) - rx * int(c)), uint32_t(int(py) - ry * int(c)), Tsz, task.side, other);
+            const uint32_t mx = nx * c + (q.x - b), my = ny * c + (q.y - b);
+            if (BT_ABLATE(A, 2147483648u)) {  // (2147483648: pull workgroups store zeros without evaluating anything — timing experiment)
+                v[e] = 0;
+            } else if (levels <= 2u && (c & 3u) == 0) {
+                const uint32_t tx = mx / cn, ty = my / cn;  // the input tile, and the block's first pixel in it
+                const uint32_t idx = grid_lookup(A, other, in_lod, int(tx), int(ty));
+                const uint16_t* src = A.atlas + uint64_t(idx == kInvalid ? 0u : idx) * Tsz * Tsz + uint64_t(b + ((my - ty * cn) << levels)) * Tsz + b + ((mx - tx * cn) << levels);
+                // every load unconditional and issued before the first use (a conditional load becomes its own divergent block with a wait behind it:
+                // sixteen dependent round trips per pixel made these the longest workgroups of the launch); an absent tile reads as no data
+                const uint32_t keep = idx == kInvalid ? 0u : 0xFFFFFFFFu;
+                if (levels == 1u) {
+                    const uint32_t t00 = src[0], t01 = src[Tsz], t10 = src[1], t11 = src[Tsz + 1u];
+                    v[e] = down_one_r16(t00 & keep, t01 & keep, t10 & keep, t11 & keep);
+                } else {
+                    uint32_t t[4][4];  // [dy][dx]
+#pragma unroll
+                    for (uint32_t dy = 0; dy < 4; dy++)
+#pragma unroll
+                        for (uint32_t dx = 0; dx < 4; dx++) t[dy][dx] = uint32_t(src[dy * Tsz + dx]) & keep;
+                    auto two = [&](uint32_t dx, uint32_t dy) -> uint32_t { return down_one_r16(t[dy][dx], t[dy + 1][dx], t[dy][dx + 1], t[dy + 1][dx + 1]); };
+                    v[e] = down_one_r16(two(0u, 0u), two(0u, 2u), two(2u, 0u), two(2u, 2u));
+                }
+            } else {
+                v[e] = levels == 1u ? pull_value_r16<1>(A, other, task.lod, mx, my) : levels == 2u ? pull_value_r16<2>(A, other, task.lod, mx, my) : pull_value_r16<3>(A, other, task.lod, mx, my);
+            }
+        }
+        uint16_t* dst = A.atlas + uint64_t(task.atlas_index) * Tsz * Tsz + uint64_t(py) * Tsz + px;
+        if (BT_ABLATE(A, 4194304u) && (v[0] | v[kPack - 1]) != 0x12345u) continue;  // (4194304: evaluated, not stored — timing experiment)
+        if constexpr (kPack == 2) *reinterpret_cast<uint32_t*>(dst) = v[0] | (v[1] << 16);
+        else *dst = uint16_t(v[0]);
+    }
+}
+
 template <uint32_t kFormat, bool kRegular>
 __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A_in) {
     FusedArgs A = A_in;
@@ -1357,38 +1455,40 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A_in) {
     // workgroups (whole rows of them, neighbours in x back to back on one L2), and in front of those its eighth of the extra workgroups —
     // apron rows (Rgba8: and columns) of the LODs above, on a cube the cross-face seam regions first: short dependent chains that run
     // beside the mosaic work instead of behind the last of it.
-    const uint32_t nx = ((1u << A.lod) * A.m.center_size + 63u) / 64u, per_side_m = nx * nx, per_side_e = A.tail_extras;
-    const uint32_t total_m = A.sides * per_side_m, total_e = A.sides * per_side_e, chunk_m = (total_m + 7u) / 8u, chunk_e = (total_e + 7u) / 8u;
+    // The extras of an XCD, in dispatch order: its share of the cross-face seam regions (task f = j * 8 + xcd: the list's head — the pulled
+    // regions, the launch's longest workgroups — spreads over all eight XCDs; round 6: with all of them on XCD 0 the launch ended 4 us late),
+    // then its eighth of the apron blocks (side-major), then its eighth of the mosaic.
+    const uint32_t nx = ((1u << A.lod) * A.m.center_size + 63u) / 64u, per_side_m = nx * nx, per_side_a = A.tail_extras;
+    const uint32_t total_m = A.sides * per_side_m, total_a = A.sides * per_side_a, chunk_m = (total_m + 7u) / 8u, chunk_a = (total_a + 7u) / 8u;
+    const uint32_t chunk_s = (A.seam_count + 7u) / 8u, chunk_e = chunk_s + chunk_a;
     uint32_t side, block_x, block_y;
     {
-        const bool plain = BT_ABLATE(A, 1024u);  // (1024: dispatch order — extras, then the mosaic row by row — timing experiment)
         const uint32_t xcd = blockIdx.x % 8u, j = blockIdx.x / 8u;
-        const bool is_extra = plain ? blockIdx.x < total_e : j < chunk_e;
-        if (is_extra) {
-            const uint32_t id = plain ? blockIdx.x : xcd * chunk_e + j;
-            if (id >= total_e || BT_ABLATE(A, 268435456u)) return;  // (268435456: no extra workgroups — timing experiment)
-            side = id / per_side_e;
-            uint32_t e = id - side * per_side_e;
-            if constexpr (kR16) {
-                if (A.seam_count) {  // the first ceil(seam_count / sides) extra workgroups of every side: one cross-face region each
-                    const uint32_t per_side = (A.seam_count + A.sides - 1u) / A.sides;
-                    if (e < per_side) {
-                        const uint32_t f = side * per_side + e;
-                        if (f < A.seam_count) {
-                            if ((A.m.border_size & 1u) == 0 && (A.m.texture_size & 1u) == 0) stitch_region_body<uint16_t, 2>(A.m, A.atlas, A.seam_tasks[f]);
-                            else stitch_region_body<uint16_t, 1>(A.m, A.atlas, A.seam_tasks[f]);
-                        }
-                        return;
+        if (j < chunk_e) {
+            if (BT_ABLATE(A, 268435456u)) return;  // (268435456: no extra workgroups — timing experiment)
+            if (j < chunk_s) {  // one cross-face region
+                if constexpr (kR16) {
+                    const uint32_t f = j * 8u + xcd;
+                    if (f < A.seam_count) {
+                        const bool pairs = (A.m.border_size & 1u) == 0 && (A.m.texture_size & 1u) == 0;
+                        if (A.seam_tasks[f].raster != 0u) {  // a region of a tile this launch produces: pulled from the input LOD
+                            if (pairs) stitch_region_pull_r16<2>(A, A.seam_tasks[f]);
+                            else stitch_region_pull_r16<1>(A, A.seam_tasks[f]);
+                        } else if (pairs) stitch_region_body<uint16_t, 2>(A.m, A.atlas, A.seam_tasks[f]);
+                        else stitch_region_body<uint16_t, 1>(A.m, A.atlas, A.seam_tasks[f]);
                     }
-                    e -= per_side;
                 }
-                tail_apron_rows(A, side, e);
-            } else {
-                tail_aprons_rgba8(A, side, e);
+                return;
             }
+            const uint32_t id = xcd * chunk_a + (j - chunk_s);
+            if (id >= total_a) return;
+            side = id / per_side_a;
+            const uint32_t e = id - side * per_side_a;
+            if constexpr (kR16) tail_apron_rows(A, side, e);
+            else tail_aprons_rgba8(A, side, e);
             return;
         }
-        const uint32_t id = plain ? blockIdx.x - total_e : xcd * chunk_m + (j - chunk_e);
+        const uint32_t id = xcd * chunk_m + (j - chunk_e);
         if (id >= total_m) return;
         side = id / per_side_m;
         const uint32_t r = id - side * per_side_m;
@@ -2269,7 +2369,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         FusedArgs args{};
         args.m = m;
 #ifdef BT_DEBUG_HOOKS
-        if (const char* e = getenv("BT_FUSED_ABLATE")) args.ablate = uint32_t(atoi(e));
+        if (const char* e = getenv("BT_FUSED_ABLATE")) args.ablate = uint32_t(strtoul(e, nullptr, 0));
 #endif
         args.atlas = (uint16_t*)at.level0;
         args.rasters = p->rasters_dev;  // (re)allocated by bt_preprocessor_run before the first launch
@@ -2534,7 +2634,9 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         // tail launches: three LODs at a time below the last fused one
         uint32_t in_lod = lod_hi - (main_levels - 1);
         int first_tail_job = -1, first_tail_plan = -1;
+        uint32_t tail_launches = 0;
         while (in_lod > lod_lo) {
+            tail_launches++;
             const uint32_t levels = std::min(3u, in_lod - lod_lo);
             uint64_t lt_extra = 0;
             FusedJobDev tail{args, ai};
@@ -2623,6 +2725,41 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                             }
                     }
             }
+            // Round 6: the cross-face regions of the LODs the tail ITSELF produces ride in it as well, PULLED from the tail's input (FusedArgs::seam_pull) —
+            // when ONE tail launch produces every lower LOD (its input then lies at most three LODs above any of them), every region beyond exactly
+            // one face edge of those tiles has its cross-face neighbour, and every face-edge grid tile of those LODs has a stitch task (the tail's
+            // pushes leave those regions alone).  No stitch launch follows the tail then: the cube job is two launches.
+            bool pull = in_tail && tail_launches == 1 && m.format == BT_FORMAT_R16;
+#ifdef BT_DEBUG_HOOKS
+            if (getenv("BT_FUSED_NO_PULL")) pull = false;
+#endif
+            if (pull) {
+                std::unordered_set<uint32_t> stitched;
+                for (const Task* t : stitches) {
+                    if (!on_face_edge(t) || t->coord.lod >= main_lo) continue;
+                    stitched.insert(t->atlas_index);
+                    const int n = int(1u << t->coord.lod);
+                    static const int off[8][2] = {{0, -1}, {1, 0}, {0, 1}, {-1, 0}, {-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
+                    for (int i = 0; i < 8; i++) {
+                        const int nx = int(t->coord.x) + off[i][0], ny = int(t->coord.y) + off[i][1];
+                        const bool out_x = nx < 0 || nx >= n, out_y = ny < 0 || ny >= n;
+                        const bt_atlas_tile& r = t->rel[i];
+                        if (out_x != out_y && !(r.atlas_index != BT_INVALID_ATLAS_INDEX && r.coordinate.side != t->coord.side && r.coordinate.lod == t->coord.lod &&
+                                                r.coordinate.x < 65536u && r.coordinate.y < 65536u))
+                            pull = false;
+                    }
+                }
+                for (uint32_t side = 0; side < sides && pull; side++)
+                    for (uint32_t lod = lod_lo; lod < main_lo && pull; lod++) {
+                        const uint32_t n = 1u << lod, off = grid_offsets[side * 32 + lod];
+                        for (uint32_t x = 0; x < n && pull; x++)
+                            for (uint32_t y = 0; y < n; y++) {
+                                if (!(x == 0 || y == 0 || x == n - 1 || y == n - 1)) continue;
+                                const uint32_t v = grids[off + (size_t(x) << lod) + y];
+                                if (v != kInvalid && !stitched.count(v)) { pull = false; break; }
+                            }
+                    }
+            }
             uint64_t tail_pixels = 0, late_pixels = 0;
             const uint32_t tail_first = uint32_t(tasks.size());
             for (int pass = 0; pass < 2; pass++) {  // the tail launch's regions first, then the later launch's
@@ -2631,19 +2768,35 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                     tj.seam_first = tail_first;
                     tj.args.seam_count = uint32_t(tasks.size()) - tail_first;
                     tj.args.seam_skip = 1;
+                    tj.args.seam_pull = pull ? 1u : 0u;
                     plan[size_t(first_tail_plan)].algorithmic_bytes += 2 * tail_pixels * bpp;
                 }
                 const uint32_t first = uint32_t(tasks.size());
+                // (pass 0 in two sweeps: the pulled regions FIRST — they are the launch's longest workgroups and the seam list's head is dispatched first)
+                for (int sweep = (pass == 0 && pull) ? 0 : 1; sweep < 2; sweep++)
                 for (const Task* t : stitches) {
                     if (!on_face_edge(t)) continue;
                     if (hybrid && t->coord.lod == lod_hi) continue;  // stitched completely by the batched kernel above
-                    const bool rides = in_tail && t->coord.lod >= main_lo;
+                    const bool pulled = pull && t->coord.lod < main_lo;
+                    const bool rides = in_tail && (t->coord.lod >= main_lo || pulled);
                     if (rides != (pass == 0)) continue;
-                    TaskDev d = seam_task(t);
+                    if (pass == 0 && pull && pulled != (sweep == 0)) continue;
+                    const TaskDev d = seam_task(t);
                     for (int i = 0; i < 8; i++)
                         if (d.rel_index[i] != BT_INVALID_ATLAS_INDEX && d.rel_side[i] != d.side) {
-                            d.regions = 1u << i;
-                            tasks.push_back(d);
+                            TaskDev e = d;
+                            e.regions = 1u << i;
+                            uint32_t parts = 1;
+                            if (pulled) {  // evaluated from the tail's input LOD (main_lo) on the neighbour face: how many LODs up, and where the neighbour tile lies
+                                // an edge region is shared out so that a thread evaluates one pixel pair (256 per workgroup); a corner region is one workgroup
+                                const uint32_t pixels = m.border_size * (i < 4 ? m.center_size : m.border_size), pairs = ((m.border_size | m.texture_size) & 1u) ? pixels : pixels / 2u;
+                                parts = std::max(1u, std::min(255u, (pairs + 255u) / 256u));
+                                e.rel_index[i] = (t->rel[i].coordinate.x << 16) | t->rel[i].coordinate.y;
+                            }
+                            for (uint32_t part = 0; part < parts; part++) {
+                                if (pulled) e.raster = (main_lo - t->coord.lod) | (part << 8) | (parts << 16);
+                                tasks.push_back(e);
+                            }
                             (pass == 0 ? tail_pixels : late_pixels) += uint64_t(m.border_size) * (i < 4 ? cc : m.border_size);
                         }
                 }
@@ -2840,18 +2993,17 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
     } else {
         const uint32_t size = (1u << job.args.lod) * job.args.m.center_size, nx = (size + 63) / 64;
         job.args.seam_tasks = p->tasks_dev + job.seam_first;  // ((re)allocated with the plan: patched at launch like the rasters)
-        uint64_t extras = 0;  // per side
+        uint64_t extras = 0;  // apron blocks per side
         if (job.args.apron_lods) {
             const uint32_t blocks_per_tile = job.args.m.format == BT_FORMAT_R16
                 ? (job.args.m.border_size * job.args.m.texture_size + 255u) / 256u  // texel pairs of the 2b apron rows
                 : (2u * job.args.m.border_size * (job.args.m.texture_size + (job.args.apron_cols ? job.args.m.center_size : 0u)) + 255u) / 256u;
             for (uint32_t k = 0; k < job.args.apron_lods; k++) extras += (1ull << (2 * (job.args.lod + k))) * blocks_per_tile;
-            extras += (job.args.seam_count + job.args.sides - 1) / job.args.sides;  // + the cross-face seam regions, in front of them
         }
         job.args.tail_extras = uint32_t(extras);
-        // a 1-D grid: XCD k (blockIdx.x % 8) takes the k-th eighth of the extras, then the k-th eighth of the mosaic (see the kernel)
-        const uint64_t total_m = uint64_t(job.args.sides) * nx * nx, total_e = uint64_t(job.args.sides) * extras;
-        const uint32_t blocks = uint32_t(8 * ((total_m + 7) / 8 + (total_e + 7) / 8));
+        // a 1-D grid: XCD k (blockIdx.x % 8) takes its share of the seam regions, then the k-th eighth of the apron blocks, then the k-th eighth of the mosaic (see the kernel)
+        const uint64_t total_m = uint64_t(job.args.sides) * nx * nx, total_a = uint64_t(job.args.sides) * extras;
+        const uint32_t blocks = uint32_t(8 * ((total_m + 7) / 8 + (total_a + 7) / 8 + (uint64_t(job.args.seam_count) + 7) / 8));
         if (job.args.m.format == BT_FORMAT_R16) {
             if (job.args.regular) fused_tail_kernel<BT_FORMAT_R16, true><<<blocks, 256, 0, p->ctx->stream>>>(job.args);
             else fused_tail_kernel<BT_FORMAT_R16, false><<<blocks, 256, 0, p->ctx->stream>>>(job.args);
