@@ -1246,38 +1246,49 @@ __global__ __launch_bounds__(64) void fused_corner_kernel(FusedArgs A) { corner_
 // Top / bottom apron rows (whole rows, corners included) of the tiles of the LODs fused_main produced below the
 // finest one: stitch.wgsl:53-118 for same-side neighbours — neighbour's centre rows, or the own centre clamped
 // when it is absent.  (Cube face edges are re-stitched afterwards by the generic kernel.)  One thread per pixel pair.
+constexpr uint32_t kApronPairsPerThread = 4;  // (a workgroup = 1024 pixel pairs: a T = 512, b = 2 tile's four apron rows — a quarter of the extra workgroups of one pair per thread)
 __device__ __forceinline__ void tail_apron_rows(const FusedArgs& A, uint32_t side, uint32_t e) {
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
-    const uint32_t pairs = b * T, blocks_per_tile = (pairs + 255u) / 256u;
+    const uint32_t pairs = b * T, per_block = 256u * kApronPairsPerThread, blocks_per_tile = (pairs + per_block - 1u) / per_block;
     for (uint32_t k = 0; k < A.apron_lods; k++) {
         const uint32_t lod = A.lod + k, n = 1u << lod, blocks = n * n * blocks_per_tile;
         if (e >= blocks) {
             e -= blocks;
             continue;
         }
-        const uint32_t tile = e / blocks_per_tile, i = (e % blocks_per_tile) * 256u + threadIdx.x;
-        if (i >= pairs) return;
+        const uint32_t tile = e / blocks_per_tile, i0 = (e % blocks_per_tile) * per_block + threadIdx.x;
         const uint32_t tx = tile / n, ty = tile % n;
         const uint32_t self = grid_lookup(A, side, lod, int(tx), int(ty));
         if (self == kInvalid) return;
-        const uint32_t r = i / (T / 2u), px = 2u * (i % (T / 2u)), py = r < b ? r : c + r;
-        const int rx = px < b ? -1 : (px >= o ? 1 : 0), ry = r < b ? -1 : 1;
-        if (A.seam_skip) {
-            // cube: a neighbour beyond ONE edge of the face lives on another face and a seam workgroup of this launch writes the region
-            // (beyond two edges — the cube's corner — there is none: clamped below like any absent neighbour)
-            const bool out_x = int(tx) + rx < 0 || int(tx) + rx >= int(n), out_y = int(ty) + ry < 0 || int(ty) + ry >= int(n);
-            if (out_x != out_y) return;
-        }
-        const uint32_t nb = grid_lookup(A, side, lod, int(tx) + rx, int(ty) + ry);
-        uint32_t v[2];
+        // every load first (unconditional, from clamped addresses), then the stores: one round trip for the thread's four pairs
+        uint32_t v[kApronPairsPerThread][2], dst[kApronPairsPerThread];
+        bool live[kApronPairsPerThread];
 #pragma unroll
-        for (uint32_t h = 0; h < 2; h++) {
-            const uint32_t x = px + h;
-            const uint32_t sx = nb != kInvalid ? uint32_t(int(x) - rx * int(c)) : min(max(x, b), o - 1u);
-            const uint32_t sy = nb != kInvalid ? uint32_t(int(py) - ry * int(c)) : min(max(py, b), o - 1u);
-            v[h] = A.atlas[uint64_t(nb != kInvalid ? nb : self) * T * T + sy * T + sx];
+        for (uint32_t q = 0; q < kApronPairsPerThread; q++) {
+            const uint32_t i = i0 + 256u * q;
+            live[q] = i < pairs;
+            const uint32_t ii = live[q] ? i : 0u;
+            const uint32_t r = ii / (T / 2u), px = 2u * (ii % (T / 2u)), py = r < b ? r : c + r;
+            const int rx = px < b ? -1 : (px >= o ? 1 : 0), ry = r < b ? -1 : 1;
+            if (A.seam_skip) {
+                // cube: a neighbour beyond ONE edge of the face lives on another face and a seam workgroup of this launch writes the region
+                // (beyond two edges — the cube's corner — there is none: clamped below like any absent neighbour)
+                const bool out_x = int(tx) + rx < 0 || int(tx) + rx >= int(n), out_y = int(ty) + ry < 0 || int(ty) + ry >= int(n);
+                if (out_x != out_y) live[q] = false;
+            }
+            const uint32_t nb = grid_lookup(A, side, lod, int(tx) + rx, int(ty) + ry);
+#pragma unroll
+            for (uint32_t h = 0; h < 2; h++) {
+                const uint32_t x = px + h;
+                const uint32_t sx = nb != kInvalid ? uint32_t(int(x) - rx * int(c)) : min(max(x, b), o - 1u);
+                const uint32_t sy = nb != kInvalid ? uint32_t(int(py) - ry * int(c)) : min(max(py, b), o - 1u);
+                v[q][h] = A.atlas[uint64_t(nb != kInvalid ? nb : self) * T * T + sy * T + sx];
+            }
+            dst[q] = py * T + px;
         }
-        *reinterpret_cast<uint32_t*>(A.atlas + uint64_t(self) * T * T + py * T + px) = v[0] | (v[1] << 16);
+#pragma unroll
+        for (uint32_t q = 0; q < kApronPairsPerThread; q++)
+            if (live[q]) *reinterpret_cast<uint32_t*>(A.atlas + uint64_t(self) * T * T + dst[q]) = v[q][0] | (v[q][1] << 16);
         return;
     }
 }
@@ -2996,7 +3007,7 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
         uint64_t extras = 0;  // apron blocks per side
         if (job.args.apron_lods) {
             const uint32_t blocks_per_tile = job.args.m.format == BT_FORMAT_R16
-                ? (job.args.m.border_size * job.args.m.texture_size + 255u) / 256u  // texel pairs of the 2b apron rows
+                ? (job.args.m.border_size * job.args.m.texture_size + 256u * kApronPairsPerThread - 1u) / (256u * kApronPairsPerThread)  // texel pairs of the 2b apron rows
                 : (2u * job.args.m.border_size * (job.args.m.texture_size + (job.args.apron_cols ? job.args.m.center_size : 0u)) + 255u) / 256u;
             for (uint32_t k = 0; k < job.args.apron_lods; k++) extras += (1ull << (2 * (job.args.lod + k))) * blocks_per_tile;
         }

@@ -60,7 +60,11 @@ __device__ __forceinline__ void stitch_region_body(const AttachmentMeta& m, void
         for (uint32_t e = 0; e < kPack; e++) {
             uint32_t layer, sx, sy;
             stitch_source(task, px + e, py, Tsz, b, c, layer, sx, sy);
-            v[e] = (layer < m.atlas_size && sx < Tsz && sy < Tsz) ? uint32_t(atlas[uint64_t(layer) * Tsz * Tsz + uint64_t(sy) * Tsz + sx]) : 0u;
+            // (the load unconditional, from a clamped address: a conditional load is a divergent block of its own with a wait behind it — kPack round
+            // trips per thread instead of one)
+            const bool inside = layer < m.atlas_size && sx < Tsz && sy < Tsz;
+            const uint32_t t = uint32_t(atlas[uint64_t(inside ? layer : task.atlas_index) * Tsz * Tsz + uint64_t(inside ? sy : 0u) * Tsz + (inside ? sx : 0u)]);
+            v[e] = inside ? t : 0u;
         }
         T* dst = atlas + uint64_t(task.atlas_index) * Tsz * Tsz + uint64_t(py) * Tsz + px;
         if constexpr (kPack == 2) *reinterpret_cast<uint32_t*>(dst) = v[0] | (v[1] << 16);
