@@ -1150,3 +1150,48 @@ def test_cube_seams_of_the_top_lods_are_pulled_inside_the_tail_launch(device, T,
     assert K.assert_atlas_equal(atlas, oracle) == n
     pre.run(atlas)  # onto the written atlas (previous values fetched): the same tiles
     assert K.assert_atlas_equal(atlas, oracle) == n
+
+
+def test_streamed_run_cube_with_two_attachments_like_the_spherical_example(device, tmp_path):
+    """examples/preprocess_spherical.rs:20-48 in full: height (R16) AND albedo (Rgba8) of a six-face cube in one queue, all twelve rasters deferred.
+    fused_main's and fused_direct's bands (24 + 24) interleave with the saves of both attachments; files == the serial path's, atlas == the oracle's."""
+    W, lods, T = 1024, 3, 256
+    heights = [K.smooth_raster(W, W, seed=500 + s, device=device) for s in range(6)]
+    albedos = []
+    for s, h in enumerate(heights):
+        rgba = np.empty((W, W, 4), np.uint8)
+        rgba[..., 0] = np.maximum(h >> 8, 1)
+        rgba[..., 1] = h & 255
+        rgba[..., 2] = (h >> 5) & 255
+        rgba[..., 3] = 255
+        rgba[700:760, 0:300 + 20 * s, 0] = 0
+        albedos.append(rgba)
+        h[100 + 9 * s:140 + 9 * s, 600:W] = 0
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=256, path="terrains/spherical")
+    cfg.add_attachment(bt.AttachmentConfig(name="height", texture_size=T, border_size=2, format=bt.AttachmentFormat.R16))
+    cfg.add_attachment(bt.AttachmentConfig(name="albedo", texture_size=T, border_size=2, format=bt.AttachmentFormat.Rgba8))
+    server = bt.AssetServer()
+    hp, ap = [f"h{s}" for s in range(6)], [f"a{s}" for s in range(6)]
+    for s in range(6):
+        server.insert(hp[s], heights[s]).insert(ap[s], albedos[s])
+    roots = []
+    for streamed in (False, True):
+        root = str(tmp_path / ("streamed" if streamed else "serial"))
+        atlas = bt.TileAtlas.new(cfg, device)
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas, root).clear_attachment(1, atlas, root)
+        pre.preprocess_spherical(bt.SphericalDataset(attachment_index=0, paths=hp, lod_range=range(0, lods)), server, atlas, defer_upload=streamed)
+        pre.preprocess_spherical(bt.SphericalDataset(attachment_index=1, paths=ap, lod_range=range(0, lods)), server, atlas, defer_upload=streamed)
+        if streamed:
+            st = pre.run_streamed(atlas, root)
+            assert st["streamed"] and st["banded_launches"] == 2 and st["bands"] == 48 and st["early_tiles"] == 2 * 6 * 4
+            assert st["uploaded_bytes"] == 6 * W * W * 6 and st["saved_bytes"] == 126 * T * T * 6
+        else:
+            pre.run(atlas)
+            pre.save(atlas, root)
+        roots.append((root, atlas))
+    for ai in (0, 1):
+        _files_equal(roots[0][1].attachment_directory(roots[0][0], ai), roots[1][1].attachment_directory(roots[1][0], ai), 126)
+    oracle = O.OracleAtlas(lods, 256, True, [(T, 2, 1, O.FORMAT_R16), (T, 2, 1, O.FORMAT_RGBA8)])
+    oracle.clear_attachment(0).clear_attachment(1)
+    oracle.preprocess_spherical(0, heights, (0, lods)).preprocess_spherical(1, albedos, (0, lods)).run(O.usable_cores())
+    assert K.assert_atlas_equal(roots[1][1], oracle, 0) == 126 and K.assert_atlas_equal(roots[1][1], oracle, 1) == 126
