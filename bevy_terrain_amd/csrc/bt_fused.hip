@@ -1325,6 +1325,10 @@ __device__ __forceinline__ void tail_aprons_rgba8(const FusedArgs& A, uint32_t s
             py = b + j / (2u * b);
         }
         const int rx = px < b ? -1 : (px >= o ? 1 : 0), ry = py < b ? -1 : (py >= o ? 1 : 0);
+        if (A.seam_skip) {  // cube: a region beyond exactly ONE face edge belongs to a seam workgroup of this launch (see tail_apron_rows)
+            const bool out_x = int(tx) + rx < 0 || int(tx) + rx >= int(n), out_y = int(ty) + ry < 0 || int(ty) + ry >= int(n);
+            if (out_x != out_y) return;
+        }
         const uint32_t nb = grid_lookup(A, side, lod, int(tx) + rx, int(ty) + ry);
         const uint32_t sx = nb != kInvalid ? uint32_t(int(px) - rx * int(c)) : min(max(px, b), o - 1u);
         const uint32_t sy = nb != kInvalid ? uint32_t(int(py) - ry * int(c)) : min(max(py, b), o - 1u);
@@ -1378,26 +1382,31 @@ __device__ __forceinline__ uint32_t down_one_r16(uint32_t t00, uint32_t t01, uin
 // Pixel (mx, my) of the LOD-`lod` mosaic of face `side`, evaluated from the tail's INPUT LOD (lod + K, complete when the launch starts) with the
 // tail's own reduction in its own order — (x, y), (x, y + 1), (x + 1, y), (x + 1, y + 1), downsample.wgsl:25-39 per level, every level quantised —
 // i.e. bit for bit what the mosaic workgroups of this launch write into that tile's centre (R16).
-template <int K>
-__device__ __forceinline__ uint32_t pull_value_r16(const FusedArgs& A, uint32_t side, uint32_t lod, uint32_t mx, uint32_t my) {
+template <typename TT>
+__device__ __forceinline__ uint32_t tail_down(uint32_t t00, uint32_t t01, uint32_t t10, uint32_t t11) {  // the tail's reduction of one level, per format
+    if constexpr (std::is_same<TT, uint16_t>::value) return down_one_r16(t00, t01, t10, t11);
+    else return downsample4_rgba8(t00, t01, t10, t11);
+}
+template <int K, typename TT>
+__device__ __forceinline__ uint32_t pull_value(const FusedArgs& A, uint32_t side, uint32_t lod, uint32_t mx, uint32_t my) {
     if constexpr (K == 0) {
         const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
         const uint32_t tx = mx / c, ty = my / c;
         const uint32_t idx = grid_lookup(A, side, lod, int(tx), int(ty));
         if (idx == kInvalid) return 0u;  // an absent tile reads as no data, like the mosaic workgroups' loads
-        return A.atlas[uint64_t(idx) * T * T + uint64_t(b + my - ty * c) * T + b + mx - tx * c];
+        return reinterpret_cast<const TT*>(A.atlas)[uint64_t(idx) * T * T + uint64_t(b + my - ty * c) * T + b + mx - tx * c];
     } else {
-        const uint32_t t00 = pull_value_r16<K - 1>(A, side, lod + 1u, 2u * mx, 2u * my), t01 = pull_value_r16<K - 1>(A, side, lod + 1u, 2u * mx, 2u * my + 1u);
-        const uint32_t t10 = pull_value_r16<K - 1>(A, side, lod + 1u, 2u * mx + 1u, 2u * my), t11 = pull_value_r16<K - 1>(A, side, lod + 1u, 2u * mx + 1u, 2u * my + 1u);
-        return down_one_r16(t00, t01, t10, t11);
+        const uint32_t t00 = pull_value<K - 1, TT>(A, side, lod + 1u, 2u * mx, 2u * my), t01 = pull_value<K - 1, TT>(A, side, lod + 1u, 2u * mx, 2u * my + 1u);
+        const uint32_t t10 = pull_value<K - 1, TT>(A, side, lod + 1u, 2u * mx + 1u, 2u * my), t11 = pull_value<K - 1, TT>(A, side, lod + 1u, 2u * mx + 1u, 2u * my + 1u);
+        return tail_down<TT>(t00, t01, t10, t11);
     }
 }
 
 // ONE cross-face apron region of a tile the tail itself produces (stitch.wgsl:12-51, 79-118), pulled: the texel the reference copies out of
 // the neighbour face's centre is evaluated from the tail's input instead (task.raster = LODs between the tile and the input; the neighbour
 // tile's coordinate rides in rel_index[region] as x << 16 | y).  One workgroup of 256 threads; kPack = 2: two adjacent pixels per dword store.
-template <uint32_t kPack>
-__device__ __forceinline__ void stitch_region_pull_r16(const FusedArgs& A, const TaskDev& task) {
+template <typename TT, uint32_t kPack>
+__device__ __forceinline__ void stitch_region_pull(const FusedArgs& A, const TaskDev& task) {
     const uint32_t Tsz = A.m.texture_size, b = A.m.border_size, c = A.m.center_size, o = b + c;
     const uint32_t region = uint32_t(__ffs(int(task.regions))) - 1u;  // 0 top, 1 right, 2 bottom, 3 left, 4 TL, 5 TR, 6 BR, 7 BL
     const uint32_t x0 = (region == 0u || region == 2u) ? b : ((region == 1u || region == 5u || region == 6u) ? o : 0u);
@@ -1426,30 +1435,30 @@ __device__ __forceinline__ void stitch_region_pull_r16(const FusedArgs& A, const
             } else if (levels <= 2u && (c & 3u) == 0) {
                 const uint32_t tx = mx / cn, ty = my / cn;  // the input tile, and the block's first pixel in it
                 const uint32_t idx = grid_lookup(A, other, in_lod, int(tx), int(ty));
-                const uint16_t* src = A.atlas + uint64_t(idx == kInvalid ? 0u : idx) * Tsz * Tsz + uint64_t(b + ((my - ty * cn) << levels)) * Tsz + b + ((mx - tx * cn) << levels);
+                const TT* src = reinterpret_cast<const TT*>(A.atlas) + uint64_t(idx == kInvalid ? 0u : idx) * Tsz * Tsz + uint64_t(b + ((my - ty * cn) << levels)) * Tsz + b + ((mx - tx * cn) << levels);
                 // every load unconditional and issued before the first use (a conditional load becomes its own divergent block with a wait behind it:
                 // sixteen dependent round trips per pixel made these the longest workgroups of the launch); an absent tile reads as no data
                 const uint32_t keep = idx == kInvalid ? 0u : 0xFFFFFFFFu;
                 if (levels == 1u) {
                     const uint32_t t00 = src[0], t01 = src[Tsz], t10 = src[1], t11 = src[Tsz + 1u];
-                    v[e] = down_one_r16(t00 & keep, t01 & keep, t10 & keep, t11 & keep);
+                    v[e] = tail_down<TT>(t00 & keep, t01 & keep, t10 & keep, t11 & keep);
                 } else {
                     uint32_t t[4][4];  // [dy][dx]
 #pragma unroll
                     for (uint32_t dy = 0; dy < 4; dy++)
 #pragma unroll
                         for (uint32_t dx = 0; dx < 4; dx++) t[dy][dx] = uint32_t(src[dy * Tsz + dx]) & keep;
-                    auto two = [&](uint32_t dx, uint32_t dy) -> uint32_t { return down_one_r16(t[dy][dx], t[dy + 1][dx], t[dy][dx + 1], t[dy + 1][dx + 1]); };
-                    v[e] = down_one_r16(two(0u, 0u), two(0u, 2u), two(2u, 0u), two(2u, 2u));
+                    auto two = [&](uint32_t dx, uint32_t dy) -> uint32_t { return tail_down<TT>(t[dy][dx], t[dy + 1][dx], t[dy][dx + 1], t[dy + 1][dx + 1]); };
+                    v[e] = tail_down<TT>(two(0u, 0u), two(0u, 2u), two(2u, 0u), two(2u, 2u));
                 }
             } else {
-                v[e] = levels == 1u ? pull_value_r16<1>(A, other, task.lod, mx, my) : levels == 2u ? pull_value_r16<2>(A, other, task.lod, mx, my) : pull_value_r16<3>(A, other, task.lod, mx, my);
+                v[e] = levels == 1u ? pull_value<1, TT>(A, other, task.lod, mx, my) : levels == 2u ? pull_value<2, TT>(A, other, task.lod, mx, my) : pull_value<3, TT>(A, other, task.lod, mx, my);
             }
         }
-        uint16_t* dst = A.atlas + uint64_t(task.atlas_index) * Tsz * Tsz + uint64_t(py) * Tsz + px;
+        TT* dst = reinterpret_cast<TT*>(A.atlas) + uint64_t(task.atlas_index) * Tsz * Tsz + uint64_t(py) * Tsz + px;
         if (BT_ABLATE(A, 4194304u) && (v[0] | v[kPack - 1]) != 0x12345u) continue;  // (4194304: evaluated, not stored — timing experiment)
         if constexpr (kPack == 2) *reinterpret_cast<uint32_t*>(dst) = v[0] | (v[1] << 16);
-        else *dst = uint16_t(v[0]);
+        else *dst = TT(v[0]);
     }
 }
 
@@ -1478,15 +1487,19 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(FusedArgs A_in) {
         if (j < chunk_e) {
             if (BT_ABLATE(A, 268435456u)) return;  // (268435456: no extra workgroups — timing experiment)
             if (j < chunk_s) {  // one cross-face region
-                if constexpr (kR16) {
-                    const uint32_t f = j * 8u + xcd;
-                    if (f < A.seam_count) {
+                const uint32_t f = j * 8u + xcd;
+                if (f < A.seam_count) {
+                    const bool pulled = A.seam_tasks[f].raster != 0u;  // a region of a tile this launch produces: pulled from the input LOD
+                    if constexpr (kR16) {
                         const bool pairs = (A.m.border_size & 1u) == 0 && (A.m.texture_size & 1u) == 0;
-                        if (A.seam_tasks[f].raster != 0u) {  // a region of a tile this launch produces: pulled from the input LOD
-                            if (pairs) stitch_region_pull_r16<2>(A, A.seam_tasks[f]);
-                            else stitch_region_pull_r16<1>(A, A.seam_tasks[f]);
+                        if (pulled) {
+                            if (pairs) stitch_region_pull<uint16_t, 2>(A, A.seam_tasks[f]);
+                            else stitch_region_pull<uint16_t, 1>(A, A.seam_tasks[f]);
                         } else if (pairs) stitch_region_body<uint16_t, 2>(A.m, A.atlas, A.seam_tasks[f]);
                         else stitch_region_body<uint16_t, 1>(A.m, A.atlas, A.seam_tasks[f]);
+                    } else {
+                        if (pulled) stitch_region_pull<uint32_t, 1>(A, A.seam_tasks[f]);
+                        else stitch_region_body<uint32_t, 1>(A.m, A.atlas, A.seam_tasks[f]);
                     }
                 }
                 return;
@@ -2703,7 +2716,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             };
             // in the tail launch: R16 main plan, unsharded, a tail launch with apron-row workgroups exists, and EVERY region beyond exactly one
             // face edge of the tiles whose apron rows the tail writes has its neighbour (then "skip" and "a seam workgroup writes it" coincide)
-            bool in_tail = !shard && !direct && !hybrid && first_tail_job >= 0 && jobs[size_t(first_tail_job)].args.apron_lods != 0;
+            bool in_tail = !shard && !hybrid && first_tail_job >= 0 && jobs[size_t(first_tail_job)].args.apron_lods != 0;  // (round 6: Rgba8 after fused_direct too)
 #ifdef BT_DEBUG_HOOKS
             if (getenv("BT_FUSED_SEAMS_LATE")) in_tail = false;
 #endif
@@ -2740,7 +2753,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             // when ONE tail launch produces every lower LOD (its input then lies at most three LODs above any of them), every region beyond exactly
             // one face edge of those tiles has its cross-face neighbour, and every face-edge grid tile of those LODs has a stitch task (the tail's
             // pushes leave those regions alone).  No stitch launch follows the tail then: the cube job is two launches.
-            bool pull = in_tail && tail_launches == 1 && m.format == BT_FORMAT_R16;
+            bool pull = in_tail && tail_launches == 1;
 #ifdef BT_DEBUG_HOOKS
             if (getenv("BT_FUSED_NO_PULL")) pull = false;
 #endif
@@ -2800,7 +2813,8 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                             uint32_t parts = 1;
                             if (pulled) {  // evaluated from the tail's input LOD (main_lo) on the neighbour face: how many LODs up, and where the neighbour tile lies
                                 // an edge region is shared out so that a thread evaluates one pixel pair (256 per workgroup); a corner region is one workgroup
-                                const uint32_t pixels = m.border_size * (i < 4 ? m.center_size : m.border_size), pairs = ((m.border_size | m.texture_size) & 1u) ? pixels : pixels / 2u;
+                                const uint32_t pixels = m.border_size * (i < 4 ? m.center_size : m.border_size);
+                                const uint32_t pairs = (m.format != BT_FORMAT_R16 || ((m.border_size | m.texture_size) & 1u)) ? pixels : pixels / 2u;  // what one thread stores
                                 parts = std::max(1u, std::min(255u, (pairs + 255u) / 256u));
                                 e.rel_index[i] = (t->rel[i].coordinate.x << 16) | t->rel[i].coordinate.y;
                             }

@@ -1122,18 +1122,23 @@ def test_config5_streamed_at_full_size_writes_the_serial_path_s_files(device, tm
     assert digests[0] == digests[1]
 
 
+@pytest.mark.parametrize("fmt", [O.FORMAT_R16, O.FORMAT_RGBA8])
 @pytest.mark.parametrize("T,b,lods,W", [(20, 2, 6, 330), (36, 4, 6, 500), (16, 2, 7, 400), (64, 2, 5, 900)])
-def test_cube_seams_of_the_top_lods_are_pulled_inside_the_tail_launch(device, T, b, lods, W):
+def test_cube_seams_of_the_top_lods_are_pulled_inside_the_tail_launch(device, T, b, lods, W, fmt):
     """Round 6: the cross-face apron regions of the LODs the tail launch itself produces are evaluated from the tail's INPUT on the neighbour
     face (one, two or three LODs up) instead of copied by a stitch launch behind it: lod_count 6 = three LODs below fused_main's (a 64-pixel
     input block per LOD-0 apron pixel, the recursive form), lod_count 5 = two (one tile lookup per pixel), lod_count 7 = two tail launches (the
     plan then keeps the stitch launch).  Every tile == the oracle's, with no-data up to the face edges; the launch count says which plan ran."""
-    faces = [K.random_raster(O.FORMAT_R16, W, W, seed=900 + 7 * s + T, holes=0.03) for s in range(6)]
-    for s in range(6):
-        faces[s][: W // 9, :] = 0  # no data along a whole face edge: the pulled texels are valid-averages of partly empty blocks, or 0
-        faces[s][:, W - W // 11:] = 0
+    faces = [K.random_raster(fmt, W, W, seed=900 + 7 * s + T, holes=0.03) for s in range(6)]
+    for s in range(6):  # no data along a whole face edge: the pulled texels are valid-averages of partly empty blocks, or 0
+        if fmt == O.FORMAT_R16:
+            faces[s][: W // 9, :] = 0
+            faces[s][:, W - W // 11:] = 0
+        else:
+            faces[s][: W // 9, :, 0] = 0
+            faces[s][:, W - W // 11:, 0] = 0
     cfg = bt.TerrainConfig(lod_count=lods, atlas_size=6 * sum(4 ** l for l in range(lods)) + 8, path="terrains/pull")
-    cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=T, border_size=b, format=bt.AttachmentFormat.R16))
+    cfg.add_attachment(bt.AttachmentConfig(name="h", texture_size=T, border_size=b, format=K.FMT[fmt]))
     atlas = bt.TileAtlas.new(cfg, device)
     server = bt.AssetServer()
     paths = [f"f{s}" for s in range(6)]
@@ -1143,8 +1148,8 @@ def test_cube_seams_of_the_top_lods_are_pulled_inside_the_tail_launch(device, T,
         bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lods)), server, atlas)
     pre.run(atlas, keep_queue=True)
     st = pre.stats()
-    assert st["fused_jobs"] == 1 and st["kernel_launches"] == (2 if lods <= 6 else 4), st  # main + tail (+ a second tail + the stitch launch for 7 LODs)
-    oracle = O.OracleAtlas(lods, cfg.atlas_size, True, [(T, b, 1, O.FORMAT_R16)])
+    assert st["fused_jobs"] == 1 and st["kernel_launches"] == (2 if lods <= 6 else 4), st  # main / direct + tail (+ a second tail + the stitch launch for 7 LODs)
+    oracle = O.OracleAtlas(lods, cfg.atlas_size, True, [(T, b, 1, fmt)])
     oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(O.usable_cores())
     n = 6 * sum(4 ** l for l in range(lods))
     assert K.assert_atlas_equal(atlas, oracle) == n
