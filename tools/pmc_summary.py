@@ -126,7 +126,7 @@ def main():
         if files:
             shutil.copy(files[0], os.path.join(dst, f"{tag}_{name}"))
     for name in ("bench_n1_verified.json", "bench_under_rocprofv3.json", "config_bench.json", "masked16k.json", "refine_bench.json", "end_to_end_examples.json",
-                 "closure.json"):
+                 "closure_last_run.json"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
     for w, rec in workloads.items():

@@ -41,7 +41,7 @@ $C --end-to-end > $O/end_to_end_examples.json 2> $O/end_to_end_examples.log
 python - "$O" <<'PY'
 import json, sys
 line = json.load(open(sys.argv[1] + "/bench_n1_verified.json"))
-json.dump({"ms_per_step": line["ms_per_step"], "roofline": line["roofline"]}, open(sys.argv[1] + "/closure.json", "w"), indent=1)
+json.dump({"ms_per_step": line["ms_per_step"], "roofline": line["roofline"]}, open(sys.argv[1] + "/closure_last_run.json", "w"), indent=1)
 PY
 python $R/tools/refine_bench.py --sweep > $O/refine_bench.json 2> $O/refine_bench.log
 find $O -name '*.csv' | sort | head -60
