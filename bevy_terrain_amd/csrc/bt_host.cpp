@@ -576,7 +576,7 @@ bt_status bt_atlas_attachment_storage(const bt_atlas* a, uint32_t ai, void** ptr
     if (ptr) {
         *ptr = a->attachments[ai].level0;
         // the caller may write through this pointer (a host-side collective does): no layer counts as "still zero since bt_atlas_create" any more
-        Attachment& at = const_cast<bt_atlas*>(a)->attachments[ai];
+        const Attachment& at = a->attachments[ai];
         at.mark_written(0, uint32_t(at.written.size()));
     }
     if (tile_bytes) *tile_bytes = a->attachments[ai].tile_bytes;

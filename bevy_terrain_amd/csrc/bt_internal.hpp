@@ -88,8 +88,8 @@ struct Attachment {
     // written[layer] == 0: the layer still holds bt_atlas_create's zeros (a wgpu texture starts zeroed) — nothing has run on it, been
     // uploaded or loaded into it, and its device pointer has not been handed out (bt_atlas_attachment_storage marks every layer).  A split of a
     // job whose finest tiles are all unwritten takes "the previous value" of a no-data pixel (split.wgsl:34-42) as 0 without fetching it.
-    std::vector<uint8_t> written;
-    void mark_written(uint32_t first, uint32_t count) {
+    mutable std::vector<uint8_t> written;  // (mutable: handing out the storage pointer of a const atlas counts as a write, bt_atlas_attachment_storage)
+    void mark_written(uint32_t first, uint32_t count) const {
         for (uint64_t i = first; i < uint64_t(first) + count && i < written.size(); i++) written[i] = 1;
     }
 };
