@@ -778,17 +778,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         for (uint32_t q = 0; q < nrows; q += 4) {
             uint32_t va[4], vb[4];
             uint32_t zany = 1;
-            // (kGeneric == false never reaches this function since round 5 — the fast variants fix a no-data quad inside their own loops — but
-            // the form is kept compilable: there the previous atlas values of the quad are requested BEFORE the rows are shaded)
-            uint32_t prev_a[4], prev_b[4];
-            if constexpr (!kGeneric) {
-#pragma unroll
-                for (uint32_t i = 0; i < 4; i++) {
-                    const uint16_t* h = A.atlas + uint64_t(home_col) * tile_texels + (b + cr0 + q + i) * T + b;
-                    prev_a[i] = h[rxa];
-                    prev_b[i] = h[rxb];
-                }
-            }
+            // (only the unstaged variant calls this: the staged ones fix a no-data quad inside their own loops since round 5)
 #pragma unroll
             for (uint32_t i = 0; i < 4; i++) {
                 const int yy = __builtin_amdgcn_readfirstlane(row_y0[q + i]);
@@ -810,14 +800,9 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             if (zany == 0) {  // some footprint had no data: those pixels keep their previous atlas value (split.wgsl:37-42)
 #pragma unroll
                 for (uint32_t i = 0; i < 4; i++) {
-                    if constexpr (!kGeneric) {
-                        if (va[i] & 0x10000u) va[i] = prev_a[i];
-                        if (vb[i] & 0x10000u) vb[i] = prev_b[i];
-                    } else {
-                        const uint16_t* h = A.atlas + uint64_t(home_col) * tile_texels + (b + cr0 + q + i) * T + b;
-                        if (va[i] & 0x10000u) va[i] = A.prev_zero ? 0u : uint32_t(h[rxa]);
-                        if (vb[i] & 0x10000u) vb[i] = A.prev_zero ? 0u : uint32_t(h[rxb]);
-                    }
+                    const uint16_t* h = A.atlas + uint64_t(home_col) * tile_texels + (b + cr0 + q + i) * T + b;
+                    if (va[i] & 0x10000u) va[i] = A.prev_zero ? 0u : uint32_t(h[rxa]);
+                    if (vb[i] & 0x10000u) vb[i] = A.prev_zero ? 0u : uint32_t(h[rxb]);
                 }
             }
             const uint32_t py = b + cr0 + q;

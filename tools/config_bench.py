@@ -66,20 +66,8 @@ def main():
     if "--config2" in sys.argv or (ONLY and ONLY.startswith("config2")):
         print(json.dumps(out))
         return
-    if "--cube-albedo" in sys.argv:  # config 5's second attachment: 6 faces of 8192^2 Rgba8 (1.6 GB of source), lod_count 5
-        rng = np.random.default_rng(77)
-        face = rng.integers(1, 256, size=(8192, 8192, 4), dtype=np.uint8)
-        cfg = bt.TerrainConfig(lod_count=5, atlas_size=2048, path="terrains/spherical")
-        cfg.add_attachment(bt.AttachmentConfig(name="albedo", texture_size=512, border_size=2, format=bt.AttachmentFormat.Rgba8))
-        atlas = bt.TileAtlas.new(cfg, device)
-        server = bt.AssetServer()
-        paths = [f"albedo{s}" for s in range(6)]
-        for i, p in enumerate(paths):
-            server.insert(p, np.roll(face, 997 * i, axis=1))
-        pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_spherical(
-            bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, 5)), server, atlas)
-        ms, prof, st = time_job(device, pre, atlas, steps=20)
-        print(json.dumps({"config5_cube_albedo_8k": W.entry(ms, prof, st)}))
+    if "--cube-albedo" in sys.argv or ONLY == "config5_cube_albedo_8k":  # config 5's second attachment: 6 faces of 8192^2 Rgba8 (1.6 GB of source), lod_count 5
+        print(json.dumps(W.config5_albedo(device, STEPS or 20)))
         return
     out.update(W.config5_height(device, STEPS or 50))
     print(json.dumps(out))

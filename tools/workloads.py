@@ -7,6 +7,7 @@ BENCH line then carries every claimed fraction) and tools/config_bench.py (the s
   config3_masked_16k_fresh                the same on atlases nothing has written since bt_atlas_create (both reference examples: clear_attachment,
                                           then one dataset) — FusedArgs::prev_zero, no previous-value fetches
   config5_cube_height_8k                  BASELINE config 5's height attachment: 6 faces of 8192^2 R16, lod_count 5, 2046 tiles
+  config5_cube_albedo_8k                  ... and its albedo attachment: 6 faces of 8192^2 Rgba8, 2046 tiles of 1 MiB
 
 and the end-to-end span (preprocessor.rs:363,419: sources loaded -> all saves done) of the reference's two examples through
 bt_preprocessor_run_streamed, with the serial legs beside it.  Every job is timed between HIP events on the context's stream."""
@@ -182,12 +183,31 @@ def config5_height(device, steps=50):
     return {"config5_cube_height_8k": entry(ms, prof, st)}
 
 
+def config5_albedo(device, steps=20):
+    """BASELINE config 5's second attachment: 6 faces of 8192^2 Rgba8 (1.6 GB of source), lod_count 5, 2046 tiles of 1 MiB"""
+    rng = np.random.default_rng(77)
+    face = rng.integers(1, 256, size=(8192, 8192, 4), dtype=np.uint8)
+    cfg = bt.TerrainConfig(lod_count=5, atlas_size=2048, path="terrains/spherical")
+    cfg.add_attachment(bt.AttachmentConfig(name="albedo", texture_size=512, border_size=2, format=bt.AttachmentFormat.Rgba8))
+    atlas = bt.TileAtlas.new(cfg, device)
+    server = bt.AssetServer()
+    paths = [f"albedo{s}" for s in range(6)]
+    for i, p in enumerate(paths):
+        server.insert(p, np.roll(face, 997 * i, axis=1))
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas).preprocess_spherical(
+        bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, 5)), server, atlas)
+    ms, prof, st = time_job(device, pre, atlas, steps)
+    pre.close()
+    return {"config5_cube_albedo_8k": entry(ms, prof, st)}
+
+
 def all_workloads(device, steps=None):
     """the five entries of bench.py's `config.workloads` (each job < 1.2 ms; about 15 s in all, most of it building the masked raster)"""
     out = {}
     out.update(config2(device, steps or 50))
     out.update(masked16k(device, steps or 20))
     out.update(config5_height(device, steps or 30))
+    out.update(config5_albedo(device, steps or 20))
     return out
 
 
