@@ -928,6 +928,9 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                     uint32_t q[4];
                     // smallest raw texel this thread read for the rows of a quad (source rows 4 * quad .. 4 * quad + 4), per column pair half
                     u16x2 zmin[2] = {__builtin_elementwise_min(ta, tb), u16x2{0xFFFFu, 0xFFFFu}};
+                    // ... and per source row of the current quad (z[j]: source row 4 * quad + j): computed anyway, kept in registers until the quad's test so
+                    // that a no-data quad derives its per-pixel validity without reading the rows from LDS again (round 6: 20 LDS reads per such quad)
+                    u16x2 z[5] = {zmin[0], zmin[0], zmin[0], zmin[0], zmin[0]};
                     uint32_t zq[2] = {1u, 1u};
                     uint32_t sink[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // (ablation 1073741824 only)
                     uint32_t* dst5 = tile5_u32 + (((b + cr0) * T + px0) >> 1);
@@ -948,6 +951,8 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                 const u16x2 zrow = __builtin_elementwise_min(ta, tb);
                                 zmin[quad] = __builtin_elementwise_min(zmin[quad], zrow);
                                 if (quad == 0 && i == 3) zmin[1] = zrow;  // source row 4 feeds both quads
+                                if (quad == 1 && i == 0) z[0] = z[4];     // (its minimum is the second quad's first row)
+                                z[i + 1] = zrow;
                             }
                             const f2 hnew = conv2p(ta) * gx + conv2p(tb) * fx;
                             // (fy, 1 - fy) of output row r: one 8-byte LDS read at a workgroup-uniform address, the values stay in
@@ -962,13 +967,8 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         if constexpr (kFix) {
                             zq[quad] = min(uint32_t(zmin[quad].x), uint32_t(zmin[quad].y));
                             if (__builtin_expect(zq[quad] == 0, 0)) {
-                                // (rare) this thread read a no-data texel for the quad: per-pixel validity from the rows that are still
-                                // staged, the previous atlas value where a footprint has no data (split.wgsl:34-42) — in place, no redo
-                                u16x2 z[5];
-#pragma unroll
-                                for (uint32_t j = 0; j < 5; j++)
-                                    z[j] = __builtin_elementwise_min(u16x2{pa0[(4 * quad + j) * P], pb0[(4 * quad + j) * P]},
-                                                                     u16x2{pa1[(4 * quad + j) * P], pb1[(4 * quad + j) * P]});
+                                // (rare) this thread read a no-data texel for the quad: per-pixel validity from the rows' minima (kept above), the
+                                // previous atlas value where a footprint has no data (split.wgsl:34-42) — in place, no redo
                                 const uint16_t* h = A.atlas + uint64_t(home_col) * tile_texels + (b + cr0 + 4 * quad) * T + b;
                                 if (A.prev_zero) {  // a fresh atlas: the previous value is bt_atlas_create's 0 — no fetch, no wait
 #pragma unroll
@@ -987,6 +987,11 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                                         asm volatile("global_load_ushort %0, %1, off" : "=v"(sink[2 * i + 1]) : "v"(h + i * T + rxb) : "memory");
                                     }
                                 } else {
+                                    // all eight previous values of the quad, unconditionally and back to back, THEN the selects: a conditional load is a
+                                    // divergent block of its own with a wait behind it — up to eight dependent round trips per no-data quad (round 6)
+                                    // (conditional loads on purpose.  Loading the quad's eight previous values unconditionally and back to back — one wait
+                                    // instead of up to eight — takes 2.5 % off the re-run of the masked 16k job, but the kernel then allocates 125 VGPRs instead
+                                    // of 114 and the CLEAN job comes out 0.5 - 1.6 % slower, same-lease, as 8 x u16, 4 + 4 and 4 x dword loads alike: round 6)
 #pragma unroll
                                     for (uint32_t i = 0; i < 4; i++) {
                                         if (min(z[i].x, z[i + 1].x) == 0) ua[i] = h[i * T + rxa];
@@ -1014,9 +1019,15 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             const f2 wq = quantise_quarter(sum);
                             q[2 * quad] = uint32_t(wq.x);
                             q[2 * quad + 1] = uint32_t(wq.y);
-                            if (kFix && __builtin_expect(zq[quad] == 0, 0)) {  // kept texels may be 0 (no data): the valid-average (downsample.wgsl:25-39)
-                                q[2 * quad] = downsample4(ua[0], ua[1], ub[0], ub[1]);  // OFFSETS order
-                                q[2 * quad + 1] = downsample4(ua[2], ua[3], ub[2], ub[3]);
+                            if (kFix && __builtin_expect(zq[quad] == 0, 0)) {
+                                // kept texels may be 0 (no data): the valid-average (downsample.wgsl:25-39) in the scaled domain, like the tail's down_pair_r16 —
+                                // a zero adds nothing to `sum` (F(0) = 0, and x + 0 is exact), so the sum of the valid texels is already there: one IEEE
+                                // division by their count per pixel (0 / 1 = 0 for a block without data), no second pass over the texels
+                                const uint32_t ca = min(ua[0], 1u) + min(ua[1], 1u) + min(ub[0], 1u) + min(ub[1], 1u), cb = min(ua[2], 1u) + min(ua[3], 1u) + min(ub[2], 1u) + min(ub[3], 1u);
+                                const f2 d = {sum.x / float(max(ca, 1u)), sum.y / float(max(cb, 1u))};
+                                const f2 wv = khalf + kn * d;
+                                q[2 * quad] = uint32_t(wv.x);
+                                q[2 * quad + 1] = uint32_t(wv.y);
                             }
                         }
                     }
@@ -1149,9 +1160,12 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                         const f2 s = ((conv2(ua[0], ua[2]) + conv2(ua[1], ua[3])) + conv2(ub[0], ub[2])) + conv2(ub[1], ub[3]);
                         const f2 wq = quantise_quarter(s);
                         uint32_t q0 = uint32_t(wq.x), q1 = uint32_t(wq.y);
-                        if (fix) {  // kept texels may be 0 (no data): the valid-average (downsample.wgsl:25-39), OFFSETS order
-                            q0 = downsample4(ua[0], ua[1], ub[0], ub[1]);
-                            q1 = downsample4(ua[2], ua[3], ub[2], ub[3]);
+                        if (fix) {  // kept texels may be 0 (no data): the valid-average (downsample.wgsl:25-39) — the scaled sum divided by the count, see the static path
+                            const uint32_t ca = min(ua[0], 1u) + min(ua[1], 1u) + min(ub[0], 1u) + min(ub[1], 1u), cb = min(ua[2], 1u) + min(ua[3], 1u) + min(ub[2], 1u) + min(ub[3], 1u);
+                            const f2 d = {s.x / float(max(ca, 1u)), s.y / float(max(cb, 1u))};
+                            const f2 wv = khalf + kn * d;
+                            q0 = uint32_t(wv.x);
+                            q1 = uint32_t(wv.y);
                         }
                         const uint32_t cy = cr0 + q, cy4 = cy4_base + (cy >> 1);
                         if (is_centre) {
