@@ -957,6 +957,11 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             const f2 hnew = conv2p(ta) * gx + conv2p(tb) * fx;
                             // (fy, 1 - fy) of output row r: one 8-byte LDS read at a workgroup-uniform address, the values stay in
                             // vector registers (no v_readfirstlane, no subtraction: 16 VALU instructions less per chunk)
+                            // (a float2 struct copy on purpose.  It carries no type tag, so the compiler cannot tell this read from the LDS-DMA rows in
+                            // flight into the other staging buffer and puts s_waitcnt vmcnt(0) in front of the first one: every chunk waits for the rows
+                            // it has just requested before it shades.  Read as two typed floats the wait is gone — same instructions otherwise — and
+                            // the 16k job is 0.8 % SLOWER, same lease, 3 + 3 runs: the other waves of the CU cover the wait, and waves that start a
+                            // chunk together keep the row stores of a workgroup together.  profiles/r06_static_wait.txt)
                             const float2 wy = fyt[r];
                             const f2 fy2 = {wy.x, wy.x}, gy2 = {wy.y, wy.y};
                             const f2 w = quantise(hprev * gy2 + hnew * fy2);
