@@ -58,6 +58,7 @@ void tile_children(bt_tile_coordinate c, bt_tile_coordinate out[4]) {
 
 static bt_tile_coordinate neighbour_at(bt_tile_coordinate c, int nx, int ny, bool spherical) {
     const bt_tile_coordinate invalid = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (c.lod > 30u || (spherical && c.side >= 6u)) return invalid;  // (not a tile: TileCoordinate::INVALID and the like have no neighbours)
     const int n = int(1u << c.lod);
     const bool out_x = nx < 0 || nx >= n, out_y = ny < 0 || ny >= n;
     if (!spherical) {
@@ -389,9 +390,11 @@ bt_status bt_memcpy_d2h(bt_ctx* ctx, void* dst, const void* src, size_t bytes) {
 
 // ==============================================================================  TileCoordinate
 
-void bt_tile_children(bt_tile_coordinate c, bt_tile_coordinate out[4]) { tile_children(c, out); }
+void bt_tile_children(bt_tile_coordinate c, bt_tile_coordinate out[4]) {
+    if (out) tile_children(c, out);
+}
 void bt_tile_neighbours(bt_tile_coordinate c, uint32_t spherical, bt_tile_coordinate out[8]) {
-    tile_neighbours(c, spherical != 0, out);
+    if (out) tile_neighbours(c, spherical != 0, out);
 }
 bt_tile_coordinate bt_tile_parent(bt_tile_coordinate c) { return {c.side, c.lod - 1u, c.x >> 1, c.y >> 1}; }
 int32_t bt_tile_name(bt_tile_coordinate c, char* buf, size_t cap) {
@@ -408,20 +411,38 @@ bt_status bt_atlas_create(bt_ctx* ctx, const bt_terrain_config* config, bt_atlas
         return BT_ERR_INVALID_ARGUMENT;
     }
     BT_HIP(hipSetDevice(ctx->device));
+    // everything is checked before anything is allocated, and the device memory comes before the host-side slot list: a nonsensical
+    // atlas_size or mip_level_count is an error status, not gigabytes of host memory followed by one
+    size_t free_bytes = 0, total_bytes = 0;
+    BT_HIP(hipMemGetInfo(&free_bytes, &total_bytes));
+    uint64_t wanted = 0;
+    for (uint32_t i = 0; i < config->attachment_count; i++) {
+        const bt_attachment_config& c = config->attachments[i];
+        if (c.texture_size == 0 || c.texture_size > 65536u || c.border_size >= c.texture_size || 2 * c.border_size >= c.texture_size) {
+            set_error("attachment %u: texture_size %u / border_size %u", i, c.texture_size, c.border_size);
+            return BT_ERR_INVALID_ARGUMENT;
+        }
+        uint32_t most_mips = 1;
+        while ((c.texture_size >> most_mips) != 0) most_mips++;
+        if (c.mip_level_count > most_mips) {  // (wgpu refuses such a texture descriptor: gpu_tile_atlas.rs:233-252)
+            set_error("attachment %u: mip_level_count %u, a %u-texel texture has at most %u", i, c.mip_level_count, c.texture_size, most_mips);
+            return BT_ERR_INVALID_ARGUMENT;
+        }
+        const uint64_t tile_bytes = uint64_t(c.texture_size) * c.texture_size * (c.format == BT_FORMAT_R16 ? 2u : c.format == BT_FORMAT_RGB8 ? 3u : 4u);
+        const bool fits = config->atlas_size <= uint64_t(total_bytes) / tile_bytes;  // (no product that could wrap)
+        if (fits) wanted += tile_bytes * config->atlas_size;
+        if (!fits || wanted > uint64_t(total_bytes)) {
+            set_error("atlas of %u layers does not fit the device (%llu MiB)", config->atlas_size, (unsigned long long)(total_bytes >> 20));
+            return BT_ERR_DEVICE;
+        }
+    }
     bt_atlas* a = new bt_atlas();
     a->ctx = ctx;
     a->config = *config;
-    for (uint32_t i = 0; i < config->atlas_size; i++)  // tile_atlas.rs:307-309
-        a->unused_tiles.push_back({{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, i, {0, 0, 0}});
     for (uint32_t i = 0; i < config->attachment_count; i++) {
         const bt_attachment_config& c = config->attachments[i];
         Attachment at;
         at.cfg = c;
-        if (c.texture_size == 0 || 2 * c.border_size >= c.texture_size) {
-            set_error("attachment %u: texture_size %u / border_size %u", i, c.texture_size, c.border_size);
-            bt_atlas_destroy(a);
-            return BT_ERR_INVALID_ARGUMENT;
-        }
         // pixel sizes: terrain_data/mod.rs:77-84
         const uint32_t px = c.format == BT_FORMAT_R16 ? 2 : c.format == BT_FORMAT_RGB8 ? 3 : 4;
         at.meta = {c.format, c.texture_size, c.border_size, c.texture_size - 2 * c.border_size, config->atlas_size, px, c.texture_size};
@@ -437,6 +458,8 @@ bt_status bt_atlas_create(bt_ctx* ctx, const bt_terrain_config* config, bt_atlas
         at.written.assign(config->atlas_size, 0);
         a->attachments.push_back(at);
     }
+    for (uint32_t i = 0; i < config->atlas_size; i++)  // tile_atlas.rs:307-309
+        a->unused_tiles.push_back({{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, i, {0, 0, 0}});
     *out = a;
     return BT_OK;
 }
@@ -1489,6 +1512,10 @@ extern "C" {
 bt_status bt_preprocessor_preprocess_tile(bt_preprocessor* p, bt_atlas* a, const bt_preprocess_dataset* d, const bt_raster* src) {
     if (!p || !a || !d) return BT_ERR_INVALID_ARGUMENT;
     if (bt_status s = check_dataset(a, d->attachment_index, d->lod_begin, d->lod_end)) return s;
+    if (d->side >= 6u) {  // a cube has six sides (coordinate.rs:17-40: the side tables); a planar terrain uses side 0
+        set_error("dataset side %u", d->side);
+        return BT_ERR_INVALID_ARGUMENT;
+    }
     if (!(d->bottom_right[0] > d->top_left[0]) || !(d->bottom_right[1] > d->top_left[1])) {
         set_error("empty dataset rectangle");
         return BT_ERR_INVALID_ARGUMENT;
