@@ -198,8 +198,8 @@ bt_status to_raster(const Decoded& d, uint32_t format, bt_image* out) {
         return BT_OK;
     }
     if (format == BT_FORMAT_RGBA8) {
-        if (d.bits != 8 || d.channels == 2 || d.channels == 0 || d.channels > 4) {
-            set_error("image has %u channel(s) of %u bits; an Rgba8 attachment needs 8-bit gray, RGB or RGBA", d.channels, d.bits);
+        if (d.bits != 8 || d.channels == 0 || d.channels > 4) {
+            set_error("image has %u channel(s) of %u bits; an Rgba8 attachment needs 8-bit gray, gray + alpha, RGB or RGBA", d.channels, d.bits);
             return BT_ERR_UNSUPPORTED;
         }
         uint8_t* buf = (uint8_t*)malloc(pixels * 4 ? pixels * 4 : 1);
@@ -209,6 +209,9 @@ bt_status to_raster(const Decoded& d, uint32_t format, bt_image* out) {
             if (d.channels == 1) {
                 buf[4 * i] = buf[4 * i + 1] = buf[4 * i + 2] = s[i];
                 buf[4 * i + 3] = 255;
+            } else if (d.channels == 2) {  // LumaA8: gray replicated, its alpha kept
+                buf[4 * i] = buf[4 * i + 1] = buf[4 * i + 2] = s[2 * i];
+                buf[4 * i + 3] = s[2 * i + 1];
             } else {
                 buf[4 * i] = s[d.channels * i];
                 buf[4 * i + 1] = s[d.channels * i + 1];

@@ -122,8 +122,8 @@ typedef struct bt_raster {
 
 /* A decoded source image in host memory, ready to be handed over as a bt_raster (on_device = 0).  Replaces
  * `asset_server.load(path)` + preprocessor_load_tile (preprocessor.rs:240, 401-422; formats/tiff.rs:14-62): a 16-bit
- * grayscale PNG / TIFF decodes to R16 texels (host byte order), an 8-bit gray / RGB / RGBA PNG or TIFF to Rgba8 (alpha
- * 255 where the file has none, like Bevy's Image::from_dynamic).  PNG: non-interlaced, 8 / 16 bit.  TIFF: classic
+ * grayscale PNG / TIFF decodes to R16 texels (host byte order), an 8-bit gray / gray + alpha / RGB / RGBA PNG or TIFF to Rgba8 (gray
+ * replicated, alpha 255 where the file has none, like Bevy's Image::from_dynamic).  PNG: non-interlaced, 8 / 16 bit.  TIFF: classic
  * (II / MM), strips or tiles, uncompressed / LZW / deflate / PackBits, horizontal predictor.  Anything else:
  * BT_ERR_UNSUPPORTED.  `data` is owned by the library until bt_image_free. */
 typedef struct bt_image {
