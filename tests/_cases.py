@@ -71,7 +71,12 @@ def assert_atlas_equal(atlas, oracle, attachment=0):
     n = len(ours)
     if n == 0:
         return 0
-    data = atlas.download_tiles(attachment, 0, max(i for _, i in ours) + 1)
+    used = max(i for _, i in ours) + 1
+    guard = min(2, atlas.config.atlas_size - used)  # the layers behind the last tile: nothing may have written them (zero since bt_atlas_create)
+    data = atlas.download_tiles(attachment, 0, used + guard)
+    assigned = {i for _, i in ours}
+    stray = [i for i in range(used + guard) if i not in assigned and data[i].any()]
+    assert not stray, f"layers {stray[:5]} hold no tile and are not zero"
     bad = []
     for coord, idx in theirs:
         exp = oracle.tile(attachment, idx)
