@@ -1,4 +1,4 @@
-"""examples/*.py — the reference's preprocess_planar.rs, preprocess_spherical.rs and minimal.rs on this library — run end to end (small synthesised
+"""examples/*.py — the reference's preprocess_planar.rs, preprocess_spherical.rs, minimal.rs and spherical.rs on this library — run end to end (small synthesised
 sources): the tile counts the reference's examples produce, and a decoded source goes through the same path the parity tests pin."""
 import os
 import subprocess
@@ -44,3 +44,6 @@ def test_spherical_example(tmp_path):
     out = run("preprocess_spherical.py", "--assets", assets, "--size", "256")
     assert "height: 2046 tiles" in out, out
     assert len(bt.tc_decode(open(os.path.join(assets, "terrains", "spherical", "config.tc"), "rb").read())) == 2046
+    out = run("spherical.py", "--assets", assets, "--frames", "24")
+    frames = [l for l in out.splitlines() if l.startswith("frame")]
+    assert int(frames[-1].split("final tiles")[1].split()[0]) > 100 and "(0 failed)" in out and " 0 tile loads" not in out, out
