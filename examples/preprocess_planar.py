@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""examples/preprocess_planar.rs, line for line, on the MI355X library.
+"""examples/preprocess_planar.rs on the MI355X library: the same configuration and the same builder calls.
 
 The reference builds the queue in `setup` and lets Bevy's schedule drain it over many frames, saving tiles as they finish
 (preprocessor.rs:345-422).  Here the same builder calls queue the same tasks and `run_streamed` is that whole span — source files decoded and

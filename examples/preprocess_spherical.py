@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""examples/preprocess_spherical.rs, line for line, on the MI355X library: six cube-face height rasters -> 2046 tiles of 512^2
+"""examples/preprocess_spherical.rs on the MI355X library (the same configuration and builder calls): six cube-face height rasters -> 2046 tiles of 512^2
 (LODs 0-4) with the cross-face borders stitched, `assets/terrains/spherical/data/height/*.bin` + `config.tc`.
 
     python examples/preprocess_spherical.py [--assets DIR] [--size 2048]
