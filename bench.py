@@ -616,13 +616,14 @@ def main():
         step()
     fence()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    stride = max(1, min(8, args.steps // 5))  # instrumented steps: every 8th of the default 200, at least five of a short run
     t0 = time.perf_counter()
     start.record(stream)
     for i in range(args.steps):
-        # one stream: per-launch HIP events (the roofline's launch durations) on every 4th step, each costs ~3 us of stream
-        # time; several jobs in flight: none here — a launch that shares the GPU with another job's says nothing about
-        # the kernel, the durations come from the one-stream pass below
-        step(profile=depth == 1 and (i % 4 == 0) and not os.environ.get("BT_BENCH_NO_LAUNCH_EVENTS"))
+        # one stream: per-launch HIP events (the roofline's launch durations) on every `stride`-th step — each event costs ~2.6 us of
+        # stream time, an instrumented step ~10 us more than a plain one; several jobs in flight: none here — a launch that shares the
+        # GPU with another job's says nothing about the kernel, the durations come from the one-stream pass below
+        step(profile=depth == 1 and (i % stride == 0) and not os.environ.get("BT_BENCH_NO_LAUNCH_EVENTS"))
     stops = []
     for d, _, _ in lanes[:depth]:  # the K steps are over when the last lane's stream has drained
         e = torch.cuda.Event(enable_timing=True)
@@ -748,13 +749,13 @@ def main():
             closure = {"error": repr(e)}
 
     # N = 1 with several jobs in flight: the same K steps once more on ONE stream — the step time without overlap, and the
-    # undisturbed per-launch durations the roofline is computed from (HIP events on that stream, every 4th step)
+    # undisturbed per-launch durations the roofline is computed from (HIP events on that stream, every `stride`-th step)
     one_stream_ms = None
     if job is None and depth > 1:
         fence()
         start.record(stream)
         for i in range(args.steps):
-            step(profile=(i % 4 == 0) and not os.environ.get("BT_BENCH_NO_LAUNCH_EVENTS"), lane=0)
+            step(profile=(i % stride == 0) and not os.environ.get("BT_BENCH_NO_LAUNCH_EVENTS"), lane=0)
         stop.record(stream)
         fence()
         one_stream_ms = start.elapsed_time(stop) / args.steps
@@ -924,8 +925,8 @@ def main():
                             "frac_of_copy": ((closure["copy_floor_ms"] / dominant["avg_ms"]) if closure and closure.get("copy_floor_ms") and dominant["kind"] == "fused_main" else None),
                             "kernel_over_skeleton": ((dominant["avg_ms"] / closure["skeleton_ms"]) if closure and closure.get("skeleton_ms") and dominant["kind"] == "fused_main" else None),
                             "closure": closure,
-                            "launch_timing": ("HIP events on the launching stream, every 4th step of the timed K steps" if depth == 1 else
-                                              f"HIP events on the launching stream, every 4th step of the one-stream pass of the same K steps "
+                            "launch_timing": (f"HIP events on the launching stream, every {stride}th step of the timed K steps" if depth == 1 else
+                                              f"HIP events on the launching stream, every {stride}th step of the one-stream pass of the same K steps "
                                               f"(in the timed pass {depth} jobs share the GPU: a launch's span there is not the kernel's duration)")}
     if cube:
         args.no_cpu_baseline = args.no_end_to_end = True  # the side measurements belong to the headline workload
