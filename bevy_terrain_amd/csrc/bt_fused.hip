@@ -670,7 +670,9 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     // the tile's x edge is also the x neighbour's apron column (stitch.wgsl:79-88); with that neighbour absent the
     // own apron repeats the edge column (stitch.wgsl:105-118) and the edge column's thread writes all b of them.
     // Per thread and level: element offset of the first extra texel in the row of centre row 0, and how many.
-    auto make_xpush = [&](uint32_t shift, uint32_t self, uint32_t cx, uint32_t& off, uint32_t& count) {
+    // (the target layer and the offset inside it travel separately: layer x tile texels passes 2^32 in an atlas of more than 16384 tiles of 512^2)
+    auto make_xpush = [&](uint32_t shift, uint32_t self, uint32_t cx, uint32_t& layer, uint32_t& off, uint32_t& count) {
+        layer = 0;
         off = 0;
         count = 0;
         if (!is_centre || self == kInvalid) return;
@@ -681,21 +683,23 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         const uint32_t n = grid_lookup(A, it.side, A.lod - shift, int(it.x >> shift) + (left ? -1 : 1), int(it.y >> shift));
         const uint32_t j = left ? cx : cx - (c - b);
         if (n != kInvalid) {
-            off = n * tile_texels + b * T + (left ? o + j : j);
+            layer = n;
+            off = b * T + (left ? o + j : j);
             count = 1;
         } else if (left ? cx == 0 : cx == c - 1) {
-            off = self * tile_texels + b * T + (left ? 0u : o);
+            layer = self;
+            off = b * T + (left ? 0u : o);
             count = b;
         }
     };
-    uint32_t x4_off, x4_count, x3_off, x3_count;
-    make_xpush(1, A.levels >= 2 ? self4 : kInvalid, cx4, x4_off, x4_count);
-    make_xpush(2, A.levels >= 3 ? self3 : kInvalid, cx3, x3_off, x3_count);
+    uint32_t x4_layer, x4_off, x4_count, x3_layer, x3_off, x3_count;
+    make_xpush(1, A.levels >= 2 ? self4 : kInvalid, cx4, x4_layer, x4_off, x4_count);
+    make_xpush(2, A.levels >= 3 ? self3 : kInvalid, cx3, x3_layer, x3_off, x3_count);
     auto xpush4 = [&](uint32_t cy, uint16_t v) {  // cy: centre row in the parent tile
-        for (uint32_t e = 0; e < x4_count; e++) A.atlas[x4_off + cy * T + e] = v;
+        for (uint32_t e = 0; e < x4_count; e++) A.atlas[uint64_t(x4_layer) * tile_texels + x4_off + cy * T + e] = v;
     };
     auto xpush3 = [&](uint32_t cy, uint16_t v) {
-        for (uint32_t e = 0; e < x3_count; e++) A.atlas[x3_off + cy * T + e] = v;
+        for (uint32_t e = 0; e < x3_count; e++) A.atlas[uint64_t(x3_layer) * tile_texels + x3_off + cy * T + e] = v;
     };
     // LDS offsets of this thread's four source columns (idle lanes read column 0 and store nothing)
     const uint32_t la0 = uint32_t(axa.i0 - xa), la1 = uint32_t(axa.i1 - xa), lb0 = uint32_t(axb.i0 - xa), lb1 = uint32_t(axb.i1 - xa);
@@ -1053,7 +1057,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             }
                         }
                         if (x4_count && !BT_ABLATE(A, 4u)) {  // a few lanes of a tile; one texel each unless the x neighbour is absent
-                            uint16_t* t = A.atlas + x4_off + cy4_first * T;
+                            uint16_t* t = A.atlas + uint64_t(x4_layer) * tile_texels + x4_off + cy4_first * T;
 #pragma unroll
                             for (uint32_t j = 0; j < 4; j++) t[j * T] = uint16_t(q[j]);
                             if (x4_count > 1)
@@ -1085,7 +1089,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
                             const uint32_t row3 = (b + cy3_first + (even ? 0u : 1u)) * T;
                             if (is_centre && !BT_ABLATE(A, 64u)) tile3[row3 + b + cx3] = uint16_t(w3);
                             if (x3_count && !BT_ABLATE(A, 64u)) {
-                                uint16_t* t = A.atlas + x3_off + (cy3_first + (even ? 0u : 1u)) * T;
+                                uint16_t* t = A.atlas + uint64_t(x3_layer) * tile_texels + x3_off + (cy3_first + (even ? 0u : 1u)) * T;
                                 t[0] = uint16_t(w3);
                                 if (x3_count > 1)
                                     for (uint32_t e = 1; e < x3_count; e++) t[e] = uint16_t(w3);
@@ -2256,8 +2260,8 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
         // Rgba8: fused_direct (no LDS staging) produces the finest LOD with its aprons and the two parent LODs
         const bool direct = !main_ok && m.format == BT_FORMAT_RGBA8;
         const bool hybrid = !main_ok && !direct;
-        // the kernels keep texel offsets into the atlas in 32 bits
-        if (uint64_t(a->config.atlas_size) * m.texture_size * m.texture_size >= (1ull << 32)) return false;
+        // (layer x tile texels is formed in 64 bits everywhere: an attachment of 2^32 texels or more — 16384 tiles of 512^2 — takes the fused plans
+        // like any other; rounds 2 - 6 sent such atlases to the batched kernels, found with a GEBCO-sized job at the end of round 6)
         const uint32_t lod_hi = splits[0]->coord.lod;
         uint32_t lod_lo = lod_hi;
         for (const Task* t : downs) lod_lo = std::min(lod_lo, t->coord.lod);

@@ -1200,3 +1200,50 @@ def test_streamed_run_cube_with_two_attachments_like_the_spherical_example(devic
     oracle.clear_attachment(0).clear_attachment(1)
     oracle.preprocess_spherical(0, heights, (0, lods)).preprocess_spherical(1, albedos, (0, lods)).run(O.usable_cores())
     assert K.assert_atlas_equal(roots[1][1], oracle, 0) == 126 and K.assert_atlas_equal(roots[1][1], oracle, 1) == 126
+
+
+@pytest.mark.parametrize("kind", ["planar_r16", "planar_rgba8", "cube_r16", "cube_rgba8"])
+def test_tiles_in_layers_beyond_2_to_32_texels(device, kind):
+    """An attachment of more than 2^32 texels (16384 tiles of 512^2; GEBCO-scale terrains have 21845+): the job's tiles sit in layers 16400 and up,
+    where layer x tile texels no longer fits 32 bits.  Rounds 2 - 6 sent such atlases to the batched kernels (4 x slower); now they take the fused
+    plans — every tile byte for byte against the oracle at (index - 16400), and the layers a wrapped offset would hit (index mod 16384) still zero."""
+    shift, T, b = 16400, 512, 2
+    fmt = O.FORMAT_RGBA8 if kind.endswith("rgba8") else O.FORMAT_R16
+    cube = kind.startswith("cube")
+    lods = 2 if cube else 3
+    n = 1100 if cube else 2200
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=shift + 40, path="terrains/high", **({} if cube else dict(model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))))
+    cfg.add_attachment(bt.AttachmentConfig(name="att", texture_size=T, border_size=b, format=K.FMT[fmt]))
+    atlas = bt.TileAtlas.new(cfg, device)
+    for i in range(shift):  # occupy the first 16400 layers (coordinates no job touches)
+        atlas.get_or_allocate_tile(bt.TileCoordinate(0, 30, i, 0))
+    server = bt.AssetServer()
+    oracle = O.OracleAtlas(lods, 64, cube, [(T, b, 1, fmt)])
+    pre = bt.Preprocessor.new().clear_attachment(0, atlas)
+    if cube:
+        faces = [K.random_raster(fmt, n, n, 900 + s, holes=0.02) for s in range(6)]
+        paths = [f"f{s}" for s in range(6)]
+        for path, f in zip(paths, faces):
+            server.insert(path, f)
+        pre.preprocess_spherical(bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lods)), server, atlas)
+        oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(16)
+    else:
+        src = K.random_raster(fmt, n, n, 901, holes=0.02)
+        server.insert("src", src)
+        pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="src", lod_range=range(0, lods)), server, atlas)
+        oracle.clear_attachment(0).preprocess_tile(0, src, (0, lods)).run(16)
+    pre.run(atlas, keep_queue=True)
+    st = pre.stats()
+    assert st["fused_jobs"] == 1 and st["generic_jobs"] == 0, st
+    expected = oracle.tiles()
+    for rerun in (False, True):  # fresh (previous values taken as zero) and onto the written tiles (previous values fetched)
+        if rerun:
+            pre.run(atlas)
+        ours = [((c.side, c.lod, c.x, c.y), i - shift) for c, i in atlas.tiles() if c.lod < 30]
+        assert ours == expected
+        data = atlas.download_tiles(0, shift, len(expected))
+        bad = [coord for coord, idx in expected if not np.array_equal(data[idx], oracle.tile(0, idx))]
+        assert not bad, (rerun, len(bad), bad[:4])
+        low = atlas.download_tiles(0, 0, 96)
+        assert not low.any(), "a wrapped 32-bit offset wrote into the first layers"
+        assert not atlas.download_tiles(0, shift + len(expected), 2).any()
