@@ -641,21 +641,31 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     const uint32_t dma_off_main = min(uint32_t(xa) * 2u + dma_lane * 16u, uint32_t(raster.pitch) - 16u);
     const uint32_t dma_off_tail = min(uint32_t(xa) * 2u + 1024u + (dma_lane & 1u) * 16u, uint32_t(raster.pitch) - 16u);
     auto dma_issue = [&](uint16_t* s_dst, int ymin, uint32_t slots) {
-        static_assert(!kDma || kP == 528, "the DMA variant assumes 1056-byte LDS rows");
+        static_assert(!kDma || kP == 528 || kP == 0, "the DMA variants: 1056-byte LDS rows, or a run-time pitch");
         const lds_bytes dst = (lds_bytes)reinterpret_cast<uint8_t*>(s_dst);
         // (the wave index through v_readfirstlane: as a function of tid the row pointer was computed per lane — two 64-bit vector
         // multiply-adds per row; every instruction, scalar or vector, takes a turn of the SIMD's one issue port: git history, tools/experiments/issue_probe.hip)
         for (uint32_t slot = uint32_t(__builtin_amdgcn_readfirstlane(int(tid >> 6))); slot < slots; slot += 4u) {
             const global_bytes row = data + uint64_t(uint32_t(ymin) + slot) * raster.pitch;
-            if (BT_ABLATE(A, 32768u))  // (32768: the non-temporal policy on the source stream — timing experiment)
+            if constexpr (kP == 528) {
+                if (BT_ABLATE(A, 32768u))  // (32768: the non-temporal policy on the source stream — timing experiment)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + dma_off_main),
+                                                     (__attribute__((address_space(3))) void*)(dst + slot * (kP * 2u)), 16, 0, 2);
+                else
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + dma_off_main),
-                                                 (__attribute__((address_space(3))) void*)(dst + slot * (kP * 2u)), 16, 0, 2);
-            else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + dma_off_main),
-                                             (__attribute__((address_space(3))) void*)(dst + slot * (kP * 2u)), 16, 0, 0);
-            if (dma_lane < 2u)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + dma_off_tail),
-                                                 (__attribute__((address_space(3))) void*)(dst + slot * (kP * 2u) + 1024u), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(dst + slot * (kP * 2u)), 16, 0, 0);
+                if (dma_lane < 2u)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + dma_off_tail),
+                                                     (__attribute__((address_space(3))) void*)(dst + slot * (kP * 2u) + 1024u), 16, 0, 0);
+            } else {
+                // a run-time pitch (a source-to-tile ratio away from 1: wider and more rows than the register staging can batch): the row in
+                // 1 KB pieces, the last one with the lanes it has texels for
+                const uint32_t row_bytes = P * 2u;  // a multiple of 16
+                for (uint32_t piece = 0; piece < row_bytes; piece += 1024u)
+                    if (piece + dma_lane * 16u < row_bytes)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + min(uint32_t(xa) * 2u + piece + dma_lane * 16u, uint32_t(raster.pitch) - 16u)),
+                                                         (__attribute__((address_space(3))) void*)(dst + slot * row_bytes + piece), 16, 0, 0);
+            }
         }
     };
 
@@ -2180,6 +2190,7 @@ struct FusedJobDev {  // one fused launch of a compiled queue
     uint32_t attachment;
     uint32_t lds_pad = 0;    // profiling build only (BT_FUSED_LDS_PAD at plan time): extra dynamic LDS per workgroup
     bool dma = false;        // fused_main stages through LDS-DMA (every raster of the job 16-byte aligned in base and pitch)
+    bool dma_only = false;   // ... and only so: the window has more 16-byte pieces than the register staging batches (run-time-pitch DMA variant)
     std::vector<MainItem> host_items;  // fused_main's / fused_direct's items as uploaded (tile-row order): streamed runs cut fused_main's into bands, fused_source_window reads both
     bool direct = false;     // a fused_direct launch (reads the source texel by texel: no staged window)
     uint32_t seam_first = 0;  // fused_tail with seam workgroups: its tasks are p->tasks_dev[seam_first ...] (args.seam_count of them)
@@ -2600,8 +2611,19 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             // kernel variant that reads the source directly
             // the staging loop holds one batch of 8 x 16-byte loads per thread: the window must fit that too
             // and its byte offsets from the first row are kept in 32 bits
-            main_job.args.lds_rows = (2 * rows_needed * pitch * 2 <= budget && rows_needed * (pitch / 8) <= 256 * 4 &&
-                                      (rows_needed + 1) * max_pitch < (1ull << 31)) ? uint32_t(rows_needed) : 0u;
+            // (the register staging holds one batch of 4 x 16-byte loads per thread: a window of more pieces than that — ratios from ~1.2 up at
+            // T = 512 — is staged by LDS-DMA alone, when every raster of the job is 16-byte aligned; rounds 2 - 6 sent such jobs to the unstaged kernel)
+            const bool fits_lds = 2 * rows_needed * pitch * 2 <= budget && (rows_needed + 1) * max_pitch < (1ull << 31);
+            const bool fits_batch = rows_needed * (pitch / 8) <= 256 * 4;
+            bool aligned = true;
+            for (const Task* t : splits) {
+                const RasterDev& r = p->rasters[t->raster].dev;
+                if (((reinterpret_cast<uintptr_t>(r.data) | r.pitch) & 15u) != 0) aligned = false;
+            }
+            // (and by choice at T = 512, where it measured 2 % faster than the register staging on a 86400 x 43200 job; at T = 256 — half-empty
+            // 1 KB pieces — the register staging is 6 % faster and stays)
+            main_job.dma_only = fits_lds && aligned && pitch <= 4096 && (!fits_batch || m.texture_size == 512);
+            main_job.args.lds_rows = fits_lds && (fits_batch || main_job.dma_only) ? uint32_t(rows_needed) : 0u;
             main_job.dma = main_job.args.lds_rows != 0;
             main_job.args.rotate_priority = 1;
 #ifdef BT_DEBUG_HOOKS
@@ -2612,7 +2634,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                 if (((reinterpret_cast<uintptr_t>(r.data) | r.pitch) & 15u) != 0) main_job.dma = false;
             }
 #ifdef BT_DEBUG_HOOKS
-            if (const char* e = getenv("BT_FUSED_DMA")) main_job.dma = main_job.dma && atoi(e) != 0;
+            if (const char* e = getenv("BT_FUSED_DMA")) main_job.dma = main_job.dma && (atoi(e) != 0 || main_job.dma_only);
 #endif
         }
         Launch lm{};
@@ -3015,6 +3037,8 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
             lds = std::min<size_t>(65536, lds + job.lds_pad);  // (occupancy experiments)
             if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528 && job.dma)
                 fused_main_kernel<true, false, 512, 528, true><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
+            else if (job.dma_only)  // a window the register staging cannot batch (a source-to-tile ratio away from 1), or T = 512 at any other pitch: LDS-DMA with a run-time pitch (round 6)
+                fused_main_kernel<true, false, 0, 0, true><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
             else if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528)
                 fused_main_kernel<true, false, 512, 528><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
             else

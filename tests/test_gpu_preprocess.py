@@ -1247,3 +1247,45 @@ def test_tiles_in_layers_beyond_2_to_32_texels(device, kind):
         low = atlas.download_tiles(0, 0, 96)
         assert not low.any(), "a wrapped 32-bit offset wrote into the first layers"
         assert not atlas.download_tiles(0, shift + len(expected), 2).any()
+
+
+@pytest.mark.parametrize("ratio,cube", [(1.23, False), (1.45, False), (0.8, False), (1.3, True)])
+def test_source_to_tile_ratios_staged_by_dma_alone(device, tmp_path, ratio, cube):
+    """T = 512 with a source that is not the size of the tile mosaic (real datasets rarely are: GEBCO's 86400 columns over 128 x 508): from a ratio of
+    ~1.2 the staged window has more 16-byte pieces than the register staging batches, and rounds 2 - 6 then ran the unstaged kernel (1.9 TB/s where the
+    16k job runs at 4.3).  Such windows are now staged by LDS-DMA with a run-time pitch (4.2 TB/s at ratio 1.23): every tile against the oracle — fresh,
+    onto the written atlas (no-data texels fetch their previous value) and through the streamed pipeline."""
+    T, b, lods = 512, 2, 2 if cube else 3
+    n = int(((T - 2 * b) << (lods - 1)) * ratio)
+    cfg = bt.TerrainConfig(lod_count=lods, atlas_size=64, path="terrains/ratio", **({} if cube else dict(model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))))
+    cfg.add_attachment(bt.AttachmentConfig(name="att", texture_size=T, border_size=b, format=bt.AttachmentFormat.R16))
+    oracle = O.OracleAtlas(lods, 64, cube, [(T, b, 1, O.FORMAT_R16)])
+    server = bt.AssetServer()
+    if cube:
+        faces = [K.random_raster(O.FORMAT_R16, n, n, 70 + s, holes=0.03) for s in range(6)]
+        paths = [f"f{s}" for s in range(6)]
+        for path, f in zip(paths, faces):
+            server.insert(path, f)
+        oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(16)
+    else:
+        src = K.random_raster(O.FORMAT_R16, n, n, 71, holes=0.03)
+        server.insert("src", src)
+        oracle.clear_attachment(0).preprocess_tile(0, src, (0, lods)).run(16)
+
+    def queue(atlas, root=None, defer=False):
+        pre = bt.Preprocessor.new().clear_attachment(0, atlas, root)
+        if cube:
+            return pre.preprocess_spherical(bt.SphericalDataset(attachment_index=0, paths=paths, lod_range=range(0, lods)), server, atlas, defer_upload=defer)
+        return pre.preprocess_tile(bt.PreprocessDataset(attachment_index=0, path="src", lod_range=range(0, lods)), server, atlas, defer_upload=defer)
+
+    atlas = bt.TileAtlas.new(cfg, device)
+    pre = queue(atlas)
+    pre.run(atlas, keep_queue=True)
+    assert pre.stats()["fused_jobs"] == 1
+    n_tiles = K.assert_atlas_equal(atlas, oracle)
+    pre.run(atlas)
+    assert K.assert_atlas_equal(atlas, oracle) == n_tiles
+    atlas2 = bt.TileAtlas.new(cfg, device)
+    queue(atlas2, str(tmp_path), defer=True).run_streamed(atlas2, str(tmp_path))
+    assert K.assert_atlas_equal(atlas2, oracle) == n_tiles
+    assert len(os.listdir(atlas2.attachment_directory(str(tmp_path), 0))) == n_tiles
