@@ -101,6 +101,9 @@ struct FusedArgs {
     // run): "the previous value" of a pixel without data (split.wgsl:34-42) IS 0 — taken as a constant instead of fetched from the atlas.  Both
     // reference examples are this case (clear_attachment, then one dataset per attachment: preprocess_planar.rs:16-60).
     uint32_t prev_zero;
+    // fused_main: the tile's 2b apron rows (first / last chunk only) read their source rows from global memory instead of the staged window, which
+    // then holds the centre rows alone — set by the host when that is what lets four workgroups share a CU's LDS (source-to-tile ratios from ~1.25)
+    uint32_t apron_global;
     uint32_t ablate;      // debug only (env BT_FUSED_ABLATE): 1 no pyramid, 2 no finest stores, 4 no parent stores, 64 no grand-parent stores (static path), 8 no staging loads, 16 prologue only, 256 / 512 finest / parent stores without arithmetic (use with 16); skeleton shapes: 65536 parent rows in bursts of four chunks, 262144 parent rows as 16-byte stores, 1048576 finest rows as 16-byte stores
 };
 
@@ -560,8 +563,10 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         bool consecutive = n == kMainRows;
         for (uint32_t i = 0; i < n; i++) consecutive = consecutive && y0[i] == first + int(i);  // also: second row = first + 1
         int lo = first, hi = (y0[n - 1] & 0x7fffffff) + (y0[n - 1] < 0 ? 0 : 1);
-        if (k == 0) lo = min(lo, S.apron[0].y0);
-        if (k == chunks_per_tile - 1) hi = max(hi, S.apron[2 * b - 1].y1);
+        if (!(kDma && kP == 0 && A.apron_global)) {
+            if (k == 0) lo = min(lo, S.apron[0].y0);
+            if (k == chunks_per_tile - 1) hi = max(hi, S.apron[2 * b - 1].y1);
+        }
         S.win_ymin[tid] = lo;
         S.win_slots[tid] = uint32_t(hi - lo + 1) | (consecutive ? 0x80000000u : 0u);
     }
@@ -763,7 +768,15 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             const uint32_t kk = r % b, py = top ? kk : o + kk;
             const int y0 = __builtin_amdgcn_readfirstlane(S.apron[r].y0), y1 = __builtin_amdgcn_readfirstlane(S.apron[r].y1);
             const float fy = S.apron[r].fy, gy = 1.0f - fy;
-            const Texel4 t0 = fetch_row(y0), t1 = fetch_row(y1);
+            Texel4 t0, t1;
+            if (kDma && kP == 0 && A.apron_global) {  // (the run-time-pitch DMA variant only; the window holds the centre rows only: see FusedArgs::apron_global)
+                const global_u16 r0 = (global_u16)(data + uint64_t(y0) * raster.pitch), r1 = (global_u16)(data + uint64_t(y1) * raster.pitch);
+                t0 = convert4(r0[axa.i0], r0[axa.i1], r0[axb.i0], r0[axb.i1]);
+                t1 = convert4(r1[axa.i0], r1[axa.i1], r1[axb.i0], r1[axb.i1]);
+            } else {
+                t0 = fetch_row(y0);
+                t1 = fetch_row(y1);
+            }
             uint32_t va = float_to_unorm16((t0.a0 * gxa + t0.a1 * fxa) * gy + (t1.a0 * gxa + t1.a1 * fxa) * fy);
             uint32_t vb = float_to_unorm16((t0.b0 * gxb + t0.b1 * fxb) * gy + (t1.b0 * gxb + t1.b1 * fxb) * fy);
             if (kKeep && min(min(t0.za, t1.za), min(t0.zb, t1.zb)) == 0) {
@@ -2583,10 +2596,12 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             const uint32_t rows = std::min(kMainRows, m.center_size) + 2 * m.border_size;
             const uint64_t cols_needed = uint64_t(double(m.texture_size - 1) * ratio_x) + 4 + 7;
             uint64_t rows_needed = uint64_t(double(rows - 1) * ratio_y) + 4;  // contiguous source-row range (safe bound)
+            uint64_t exact_core = rows_needed;  // ... of the centre rows alone (without the first / last chunk's apron rows)
             {   // exact: replay the kernel's own window computation for every tile row and chunk (same f32 operations)
                 const uint32_t c = m.center_size, b = m.border_size, chunks = (c + kMainRows - 1) / kMainRows;
                 const float scale = float(1u << lod_hi);
                 uint64_t exact = 1;
+                exact_core = 1;
                 std::vector<std::pair<uint32_t, int>> seen;  // (tile row, raster)
                 for (const Task* t : splits) {
                     const std::pair<uint32_t, int> key(t->coord.y, t->raster);
@@ -2597,6 +2612,7 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                     for (uint32_t k = 0; k < chunks; k++) {
                         const uint32_t r0 = k * kMainRows, r1 = std::min(c, r0 + kMainRows) - 1;
                         int lo = axis(ty, r0).i0, hi = axis(ty, r1).i1;
+                        exact_core = std::max<uint64_t>(exact_core, uint64_t(hi - lo + 1));
                         if (k == 0) lo = std::min(lo, ty > 0 ? axis(ty - 1, c - b).i0 : axis(ty, 0).i0);
                         if (k == chunks - 1) hi = std::max(hi, ty + 1 < n ? axis(ty + 1, b - 1).i1 : axis(ty, c - 1).i1);
                         exact = std::max<uint64_t>(exact, uint64_t(hi - lo + 1));
@@ -2613,6 +2629,26 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             // and its byte offsets from the first row are kept in 32 bits
             // (the register staging holds one batch of 4 x 16-byte loads per thread: a window of more pieces than that — ratios from ~1.2 up at
             // T = 512 — is staged by LDS-DMA alone, when every raster of the job is 16-byte aligned; rounds 2 - 6 sent such jobs to the unstaged kernel)
+            // Four workgroups per CU need <= 40 KB each (160 KB of LDS).  When the window with the apron rows is past that and the centre rows alone are
+            // not (ratios ~1.25 - 1.35 at T = 512; at 1.41 the same step takes the job from two workgroups to three), the apron rows — 2b of a tile's T —
+            // read global memory and the window shrinks: ratio 1.3, 553 -> 3xx us (round 6, profiles/r06_gebco_size.txt)
+            {
+                const uint64_t kQuarter = (160u << 10) / 4, kThird = (160u << 10) / 3, fixed = sizeof(MainShared);
+                const uint64_t with_aprons = fixed + 2 * rows_needed * pitch * 2, core = fixed + 2 * std::min(rows_needed, exact_core) * pitch * 2;
+                auto groups = [&](uint64_t bytes) { return bytes <= kQuarter ? 4 : bytes <= kThird ? 3 : bytes <= (80u << 10) ? 2 : 1; };
+                bool all_aligned = true;
+                for (const Task* t : splits) {
+                    const RasterDev& r = p->rasters[t->raster].dev;
+                    if (((reinterpret_cast<uintptr_t>(r.data) | r.pitch) & 15u) != 0) all_aligned = false;
+                }
+                // (only the run-time-pitch DMA variant knows the mode: aligned rasters, T = 512 or a window past the register batch, not the 528 pitch)
+                const uint64_t core_rows = std::min(rows_needed, exact_core);
+                const bool dma_variant = all_aligned && pitch <= 4096 && pitch != 528 && (m.texture_size == 512 || core_rows * (pitch / 8) > 256 * 4);
+                if (dma_variant && groups(core) > groups(with_aprons)) {
+                    main_job.args.apron_global = 1;
+                    rows_needed = core_rows;
+                }
+            }
             const bool fits_lds = 2 * rows_needed * pitch * 2 <= budget && (rows_needed + 1) * max_pitch < (1ull << 31);
             const bool fits_batch = rows_needed * (pitch / 8) <= 256 * 4;
             bool aligned = true;
@@ -2624,6 +2660,10 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             // 1 KB pieces — the register staging is 6 % faster and stays)
             main_job.dma_only = fits_lds && aligned && pitch <= 4096 && (!fits_batch || m.texture_size == 512);
             main_job.args.lds_rows = fits_lds && (fits_batch || main_job.dma_only) ? uint32_t(rows_needed) : 0u;
+            if (main_job.args.apron_global && main_job.args.lds_rows && !main_job.dma_only) {  // (cannot happen by the conditions above; a window without apron rows in a variant that stages them would overrun)
+                main_job.args.apron_global = 0;
+                main_job.args.lds_rows = 0;
+            }
             main_job.dma = main_job.args.lds_rows != 0;
             main_job.args.rotate_priority = 1;
 #ifdef BT_DEBUG_HOOKS
