@@ -104,6 +104,9 @@ struct FusedArgs {
     // fused_main: the tile's 2b apron rows (first / last chunk only) read their source rows from global memory instead of the staged window, which
     // then holds the centre rows alone — set by the host when that is what lets four workgroups share a CU's LDS (source-to-tile ratios from ~1.25)
     uint32_t apron_global;
+    // fused_main, run-time-pitch DMA variant: ONE staging buffer — the next chunk's rows are requested when every wave has read this chunk's (no overlap inside the
+    // workgroup; the CU's other workgroups cover) — set by the host when two buffers would keep a fourth workgroup off the CU's LDS (ratios from ~1.36 at T = 512)
+    uint32_t single_buffer;
     uint32_t ablate;      // debug only (env BT_FUSED_ABLATE): 1 no pyramid, 2 no finest stores, 4 no parent stores, 64 no grand-parent stores (static path), 8 no staging loads, 16 prologue only, 256 / 512 finest / parent stores without arithmetic (use with 16); skeleton shapes: 65536 parent rows in bursts of four chunks, 262144 parent rows as 16-byte stores, 1048576 finest rows as 16-byte stores
 };
 
@@ -470,7 +473,8 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
     MainShared& S = *reinterpret_cast<MainShared*>(smem);
     uint16_t* s_buf = reinterpret_cast<uint16_t*>(smem + sizeof(MainShared));
     constexpr bool kFix = kStaged && !kGeneric;  // the fast variants: no-data is detected per thread and quad of rows and fixed in place (round 5)
-    const uint32_t buf_texels = A.lds_rows * (kP ? kP : A.lds_pitch);  // two staging buffers (chunk parity)
+    const bool one_buffer = kDma && kP == 0 && A.single_buffer != 0;
+    const uint32_t buf_texels = one_buffer ? 0u : A.lds_rows * (kP ? kP : A.lds_pitch);  // two staging buffers (chunk parity) — or one: every chunk in the same rows
 
     // A workgroup is persistent over a run of row chunks (kMainRows centre rows each) of ONE finest tile:
     // the column parameters, neighbour tables and push constants are computed once, and while chunk k is
@@ -880,7 +884,7 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
             window(k + 1, next_ymin, next_slots);
             if constexpr (kDma) {
                 if (BT_ABLATE(A, 2048u)) __builtin_amdgcn_s_setprio(3);  // (2048: the DMA issue at top priority — timing experiment)
-                if (kDmaPos == 0) dma_issue(s_buf + ((k + 1) & 1u) * buf_texels, next_ymin, next_slots);
+                if (kDmaPos == 0 && !one_buffer) dma_issue(s_buf + ((k + 1) & 1u) * buf_texels, next_ymin, next_slots);
             }
             else if (kStaged && wide && !BT_ABLATE(A, 8u)) stage_issue(next_ymin, next_slots, pre);
         }
@@ -1240,6 +1244,12 @@ __device__ __forceinline__ void fused_main_chunks(const FusedArgs& A, uint32_t i
         }
         ymin = next_ymin;
         slots = next_slots;
+        if constexpr (kDma && kP == 0) {
+            if (one_buffer) {  // every wave is through with this chunk's rows: the next chunk's travel into the same buffer
+                __syncthreads();
+                dma_issue(s_buf, next_ymin, next_slots);
+            }
+        }
         chunk_barrier();
     }
     wg_stamp(2);
@@ -2714,7 +2724,24 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                     rows_needed = core_rows;
                 }
             }
-            const bool fits_lds = 2 * rows_needed * pitch * 2 <= budget && (rows_needed + 1) * max_pitch < (1ull << 31);
+            uint64_t buffers = 2;
+            {   // ... and where even the centre rows alone, twice, leave room for three workgroups or fewer, ONE buffer of them may leave room for four (FusedArgs::single_buffer)
+                const uint64_t kQuarter = (160u << 10) / 4, fixed = sizeof(MainShared);
+                bool all_aligned = true;
+                for (const Task* t : splits) {
+                    const RasterDev& r = p->rasters[t->raster].dev;
+                    if (((reinterpret_cast<uintptr_t>(r.data) | r.pitch) & 15u) != 0) all_aligned = false;
+                }
+                const uint64_t core_rows = std::min(rows_needed, exact_core);
+                const bool dma_variant = all_aligned && pitch <= 4096 && pitch != 528 && (m.texture_size == 512 || core_rows * (pitch / 8) > 256 * 4);
+                if (dma_variant && fixed + 2 * rows_needed * pitch * 2 > kQuarter && fixed + core_rows * pitch * 2 <= kQuarter) {
+                    main_job.args.single_buffer = 1;
+                    main_job.args.apron_global = 1;
+                    rows_needed = core_rows;
+                    buffers = 1;
+                }
+            }
+            const bool fits_lds = buffers * rows_needed * pitch * 2 <= budget && (rows_needed + 1) * max_pitch < (1ull << 31);
             const bool fits_batch = rows_needed * (pitch / 8) <= 256 * 4;
             bool aligned = true;
             for (const Task* t : splits) {
@@ -2725,8 +2752,9 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             // 1 KB pieces — the register staging is 6 % faster and stays)
             main_job.dma_only = fits_lds && aligned && pitch <= 4096 && (!fits_batch || m.texture_size == 512);
             main_job.args.lds_rows = fits_lds && (fits_batch || main_job.dma_only) ? uint32_t(rows_needed) : 0u;
-            if (main_job.args.apron_global && main_job.args.lds_rows && !main_job.dma_only) {  // (cannot happen by the conditions above; a window without apron rows in a variant that stages them would overrun)
+            if ((main_job.args.apron_global || main_job.args.single_buffer) && main_job.args.lds_rows && !main_job.dma_only) {  // (cannot happen by the conditions above; a window without apron rows in a variant that stages them would overrun)
                 main_job.args.apron_global = 0;
+                main_job.args.single_buffer = 0;
                 main_job.args.lds_rows = 0;
             }
             main_job.dma = main_job.args.lds_rows != 0;
@@ -3141,7 +3169,7 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
     } else if (l.kind == kLaunchFusedMain) {
         const uint32_t blocks = job.args.item_count * job.args.groups;
         if (job.args.lds_rows) {
-            size_t lds = sizeof(MainShared) + 2 * size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
+            size_t lds = sizeof(MainShared) + (job.args.single_buffer ? 1 : 2) * size_t(job.args.lds_rows) * job.args.lds_pitch * 2;
             lds = std::min<size_t>(65536, lds + job.lds_pad);  // (occupancy experiments)
             if (job.args.m.texture_size == 512 && job.args.lds_pitch == 528 && job.dma)
                 fused_main_kernel<true, false, 512, 528, true><<<blocks, 256, lds, p->ctx->stream>>>(job.args);
