@@ -1810,9 +1810,6 @@ __device__ __forceinline__ uint32_t quad_dpp(uint32_t v) {
 
 constexpr uint32_t kDirectRows = 4, kDirectMaxBlocks = 16;
 
-// kSkips: a source finer than the tile grid (ratios above 1: the host decides per job) — an output row's upper source row may lie one past the chain; up to two
-// such rows of a block get that row through two extra slots of the request (14 loads per request instead of 10, every wait counted for 14)
-template <bool kSkips>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_direct_rgba8_kernel(FusedArgs A) {
     constexpr uint32_t kRows = kDirectRows;
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
@@ -1849,8 +1846,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         int chain, y_first, y_last;
         uint32_t byte_lo, byte_hi;  // y_first x the raster's pitch
         int rep;                    // bit r (r >= 1): row r uses the same two source rows as row r - 1 (a source coarser than the tiles: round 6)
-        int skip;                   // bit r (r >= 1, kSkips): row r's upper source row is the one BEHIND row r - 1's lower one (a source finer than the tiles)
-        int pad[1];
+        int pad[2];
     };
     __shared__ Axis s_ay[kDirectMaxBlocks * kRows];
     __shared__ float2 s_wy[kDirectMaxBlocks * kRows];  // (fy, 1 - fy) of the row: read at a uniform address, used from vector registers
@@ -1866,24 +1862,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // one row apart — or the same row, where the source's first / last row is clamped (the tiles along the raster's top and bottom)
         // — or row r repeats row r - 1's pair (a source coarser than the tile grid, ratios below 1: round 6; rounds 2 - 5 sent every such block down the
         // general path, which requests nothing ahead: 0.9 M tiles/s at ratio 0.71 where the chained blocks of ratio 1.008 run at 1.75)
-        BlockInfo bi = BlockInfo{0, 0, -1, 0u, 0u, 0, 0, {0}};
+        BlockInfo bi = BlockInfo{0, 0, -1, 0u, 0u, 0, {0, 0}};
         if (blk_begin + tid < blk_end && (blk_begin + tid) * kRows + kRows <= c) {
             const Axis* ay = s_ay + tid * kRows;
             bool ok = true;
-            int chain = 0x100, rep = 0, skip = 0, skips = 0;
+            int chain = 0x100, rep = 0;
             for (uint32_t r = 0; ok && r < kRows; r++) {
                 const int d = ay[r].i1 - ay[r].i0;
                 ok = d == 0 || d == 1;
                 if (r == 0 || ay[r].i0 == ay[r - 1].i1) chain |= d << r;  // the next source row of the chain: one further down (or the same, clamped)
                 else if (ay[r].i0 == ay[r - 1].i0 && ay[r].i1 == ay[r - 1].i1) rep |= 1 << r;  // the same pair again: the chain stands still
-                else if (kSkips && ay[r].i0 == ay[r - 1].i1 + 1 && skips < 2) {  // one source row is passed over: the chain steps 1 + d, the upper row rides in an extra slot
-                    chain |= d << r;
-                    skip |= 1 << r;
-                    skips++;
-                } else ok = false;
+                else ok = false;
             }
             const uint64_t bytes = uint64_t(uint32_t(ay[0].i0)) * raster.pitch;
-            if (ok) bi = BlockInfo{chain, ay[0].i0, ay[kRows - 1].i1, uint32_t(bytes), uint32_t(bytes >> 32), rep, skip, {0}};
+            if (ok) bi = BlockInfo{chain, ay[0].i0, ay[kRows - 1].i1, uint32_t(bytes), uint32_t(bytes >> 32), rep, {0, 0}};
         }
         s_blk[tid] = bi;
     }
@@ -1953,8 +1945,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
         // The blocks of a sweep form a software pipeline over two register sets (the loop is unrolled by two so that no set is ever
         // copied): block k's texels are requested when block k - 2 has consumed its own, in front of that block's stores.
-        constexpr uint32_t kSlots = kRows + 1 + (kSkips ? 2 : 0);  // (slots kRows + 1, kRows + 2: the upper rows of the block's first / second skipping row)
-        uint32_t set_a0[kSlots], set_a1[kSlots], set_b0[kSlots], set_b1[kSlots];
+        uint32_t set_a0[kRows + 1], set_a1[kRows + 1], set_b0[kRows + 1], set_b1[kRows + 1];
         BlockInfo info_a, info_b;
         H4p carry_top = H4p{{0.0f, 0.0f}, {0.0f, 0.0f}};
         uint32_t carry_z = 0;
@@ -1963,23 +1954,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const BlockInfo* v = s_blk + (blk - blk_begin);
             return BlockInfo{__builtin_amdgcn_readfirstlane(v->chain), __builtin_amdgcn_readfirstlane(v->y_first), __builtin_amdgcn_readfirstlane(v->y_last),
                              uint32_t(__builtin_amdgcn_readfirstlane(int(v->byte_lo))), uint32_t(__builtin_amdgcn_readfirstlane(int(v->byte_hi))),
-                             __builtin_amdgcn_readfirstlane(v->rep), kSkips ? __builtin_amdgcn_readfirstlane(v->skip) : 0, {0}};
+                             __builtin_amdgcn_readfirstlane(v->rep), {0, 0}};
         };
         // Always 2 x (kRows + 1) loads, whatever the block: the hand-counted waits below rely on it.  A block that takes the general
         // path (chain 0) gets row 0 kRows + 1 times into registers nobody reads.  Issued from assembly and waited for by hand
         // (arrived() below): the compiler's own counted waits assume the fewest operations in flight over all paths of this control
         // flow and end up waiting for the other set and for the stores as well.
-        auto request = [&](const BlockInfo& bi, uint32_t (&d0)[kSlots], uint32_t (&d1)[kSlots]) {
+        auto request = [&](const BlockInfo& bi, uint32_t (&d0)[kRows + 1], uint32_t (&d1)[kRows + 1]) {
             global_bytes_t rowp = data + (uint64_t(bi.byte_lo) | uint64_t(bi.byte_hi) << 32);
-            global_bytes_t xrow0 = rowp, xrow1 = rowp;  // (kSkips) the rows of the two extra slots; a block without skipping rows reads its first row into them
             if (BT_ABLATE(A, 8u)) {  // (8: no source loads)
 #pragma unroll
-                for (uint32_t j = 0; j < kSlots; j++) {
+                for (uint32_t j = 0; j <= kRows; j++) {
                     d0[j] = 0x01010101u * (tid + j + 1u) | 1u;
                     d1[j] = 0x01010101u * (tid + j + 2u) | 1u;
                 }
-                return;
-            } else if (__builtin_expect(bi.chain == 0x10F && bi.skip == 0 && narrow, 1)) {  // kRows + 1 consecutive rows: one base, the rows in the lane offsets
+            } else if (__builtin_expect(bi.chain == 0x10F && narrow, 1)) {  // kRows + 1 consecutive rows: one base, the rows in the lane offsets
 #pragma unroll
                 for (uint32_t j = 0; j <= kRows; j++)
                     asm volatile("global_load_dword %0, %2, %4\n\tglobal_load_dword %1, %3, %4" : "=&v"(d0[j]), "=&v"(d1[j]) : "v"(lo0[j]), "v"(lo1[j]), "s"(rowp));
@@ -1987,44 +1976,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                 for (uint32_t j = 0; j <= kRows; j++) {
                     asm volatile("global_load_dword %0, %2, %4\n\tglobal_load_dword %1, %3, %4" : "=&v"(d0[j]), "=&v"(d1[j]) : "v"(off0), "v"(off1), "s"(rowp));
-                    if (kSkips && j >= 1 && j < kRows && ((uint32_t(bi.skip) >> j) & 1u)) {  // slot j holds row j - 1's lower source row: row j's upper one is the next, its lower one the chain's next
-                        rowp += raster.pitch;
-                        if ((uint32_t(bi.skip) & ((1u << j) - 1u)) == 0) xrow0 = rowp; else xrow1 = rowp;
-                    }
                     rowp += (uint32_t(bi.chain) >> j) & 1u ? raster.pitch : 0u;
                 }
-            }
-            if constexpr (kSkips) {
-                asm volatile("global_load_dword %0, %2, %4\n\tglobal_load_dword %1, %3, %4" : "=&v"(d0[kRows + 1]), "=&v"(d1[kRows + 1]) : "v"(off0), "v"(off1), "s"(xrow0));
-                asm volatile("global_load_dword %0, %2, %4\n\tglobal_load_dword %1, %3, %4" : "=&v"(d0[kRows + 2]), "=&v"(d1[kRows + 2]) : "v"(off0), "v"(off1), "s"(xrow1));
             }
         };
         // row j of a set has arrived when at most the set's later rows and the other set's request (always issued after it: kRows + 1
         // pairs) are in flight; whatever else was issued in between only makes the count conservative
-        // (kSkips: kRows + 3 pairs per request — the set's two extra slots are issued last, behind its chain)
         auto arrived = [&](uint32_t j, uint32_t& t0, uint32_t& t1) {
-            if constexpr (!kSkips) {
-                switch (j) {
-                    case 0: asm volatile("s_waitcnt vmcnt(18)" : "+v"(t0), "+v"(t1)); break;
-                    case 1: asm volatile("s_waitcnt vmcnt(16)" : "+v"(t0), "+v"(t1)); break;
-                    case 2: asm volatile("s_waitcnt vmcnt(14)" : "+v"(t0), "+v"(t1)); break;
-                    case 3: asm volatile("s_waitcnt vmcnt(12)" : "+v"(t0), "+v"(t1)); break;
-                    default: asm volatile("s_waitcnt vmcnt(10)" : "+v"(t0), "+v"(t1)); break;
-                }
-            } else {
-                switch (j) {  // in flight at most: the chain's later pairs + the two extra pairs + the other set's 7 pairs
-                    case 0: asm volatile("s_waitcnt vmcnt(26)" : "+v"(t0), "+v"(t1)); break;
-                    case 1: asm volatile("s_waitcnt vmcnt(24)" : "+v"(t0), "+v"(t1)); break;
-                    case 2: asm volatile("s_waitcnt vmcnt(22)" : "+v"(t0), "+v"(t1)); break;
-                    case 3: asm volatile("s_waitcnt vmcnt(20)" : "+v"(t0), "+v"(t1)); break;
-                    case 4: asm volatile("s_waitcnt vmcnt(18)" : "+v"(t0), "+v"(t1)); break;
-                    case 5: asm volatile("s_waitcnt vmcnt(16)" : "+v"(t0), "+v"(t1)); break;  // the first extra pair
-                    default: asm volatile("s_waitcnt vmcnt(14)" : "+v"(t0), "+v"(t1)); break;  // the second
-                }
+            switch (j) {
+                case 0: asm volatile("s_waitcnt vmcnt(18)" : "+v"(t0), "+v"(t1)); break;
+                case 1: asm volatile("s_waitcnt vmcnt(16)" : "+v"(t0), "+v"(t1)); break;
+                case 2: asm volatile("s_waitcnt vmcnt(14)" : "+v"(t0), "+v"(t1)); break;
+                case 3: asm volatile("s_waitcnt vmcnt(12)" : "+v"(t0), "+v"(t1)); break;
+                default: asm volatile("s_waitcnt vmcnt(10)" : "+v"(t0), "+v"(t1)); break;
             }
         };
-        static_assert(kRows == 4, "arrived() counts 2 x (kRows + 1) (kSkips: + 2) loads per request");
-        auto block = [&](uint32_t blk, BlockInfo& bi, uint32_t (&raw0)[kSlots], uint32_t (&raw1)[kSlots]) {
+        static_assert(kRows == 4, "arrived() counts 2 x (kRows + 1) loads per request");
+        auto block = [&](uint32_t blk, BlockInfo& bi, uint32_t (&raw0)[kRows + 1], uint32_t (&raw1)[kRows + 1]) {
             if (--prio_left == 0) {
                 prio_left = prio_step;
                 prio_level++;
@@ -2067,17 +2035,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         z = min(z, z_row);
                         bot = hrow_rgba8_packed(raw0[r + 1], raw1[r + 1], ax.fr);
                     }
-                    H4p upper = again ? held : top;
-                    if constexpr (kSkips) {
-                        if (r > 0 && ((uint32_t(bi.skip) >> r) & 1u) != 0) {  // (wave-uniform) the upper row is the one behind the chain's: the block's first or second extra slot
-                            const bool second = (uint32_t(bi.skip) & ((1u << r) - 1u)) != 0;
-                            if (second) arrived(kRows + 2, raw0[kRows + 2], raw1[kRows + 2]);
-                            else arrived(kRows + 1, raw0[kRows + 1], raw1[kRows + 1]);
-                            const uint32_t x0 = second ? raw0[kRows + 2] : raw0[kRows + 1], x1 = second ? raw1[kRows + 2] : raw1[kRows + 1];
-                            z = min(z, min(x0 & 0xFFu, x1 & 0xFFu));
-                            upper = hrow_rgba8_packed(x0, x1, ax.fr);
-                        }
-                    }
+                    const H4p upper = again ? held : top;
                     const float2 w = wy[r];
                     out[r] = vmix_rgba8_weights(upper, bot, w.x, w.y);
                     held = upper;
@@ -2270,7 +2228,6 @@ struct FusedJobDev {  // one fused launch of a compiled queue
     uint32_t lds_pad = 0;    // profiling build only (BT_FUSED_LDS_PAD at plan time): extra dynamic LDS per workgroup
     bool dma = false;        // fused_main stages through LDS-DMA (every raster of the job 16-byte aligned in base and pitch)
     bool dma_only = false;   // ... and only so: the window has more 16-byte pieces than the register staging batches (run-time-pitch DMA variant)
-    bool direct_skips = false;  // fused_direct: the source is finer than the tile grid in y (ratio above 1): the variant whose chained blocks may pass over source rows
     std::vector<MainItem> host_items;  // fused_main's / fused_direct's items as uploaded (tile-row order): streamed runs cut fused_main's into bands, fused_source_window reads both
     bool direct = false;     // a fused_direct launch (reads the source texel by texel: no staged window)
     uint32_t seam_first = 0;  // fused_tail with seam workgroups: its tasks are p->tasks_dev[seam_first ...] (args.seam_count of them)
@@ -2604,14 +2561,6 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             job.all_layers = all_layers;
             job.tly = args.tly;
             job.bry = args.bry;
-            {   // source rows per tile row: above 1 output rows pass over source rows.  From 1.02 (one block in twelve) the variant that keeps such blocks on the
-                // requests-ahead path pays for its four extra loads per block; the BASELINE configs (4096 over 4064, 8192 over 8128: one block in 32) stay on the other
-                const double mosaic = double(m.center_size) * double(1u << lod_hi);
-                for (const Task* t : splits) {
-                    const RasterDev& r = p->rasters[t->raster].dev;
-                    if (double(r.height) / (double(args.bry - args.tly) * mosaic) > 1.02) job.direct_skips = true;
-                }
-            }
             {   // row blocks per workgroup: as many as keep at least one resident generation (1024 workgroups) busy
                 const uint64_t blocks = uint64_t(items.size()) * ((m.center_size + kDirectRows - 1) / kDirectRows);
                 job.args.groups = uint32_t(std::min<uint64_t>(kDirectMaxBlocks, std::max<uint64_t>(1, (blocks + 1023) / 1024)));
@@ -3162,10 +3111,7 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
     if (l.kind == kLaunchFusedDirect) {
         const uint32_t blocks_per_tile = (job.args.m.center_size + kDirectRows - 1) / kDirectRows;
         const uint32_t wgs_per_tile = (blocks_per_tile + job.args.groups - 1) / job.args.groups;
-        if (job.direct_skips)  // a source finer than the tile grid: blocks whose rows pass over source rows keep the requests-ahead path (round 6)
-            fused_direct_rgba8_kernel<true><<<job.args.item_count * wgs_per_tile, 256, 0, p->ctx->stream>>>(job.args);
-        else
-            fused_direct_rgba8_kernel<false><<<job.args.item_count * wgs_per_tile, 256, 0, p->ctx->stream>>>(job.args);
+        fused_direct_rgba8_kernel<<<job.args.item_count * wgs_per_tile, 256, 0, p->ctx->stream>>>(job.args);
     } else if (l.kind == kLaunchFusedMain) {
         const uint32_t blocks = job.args.item_count * job.args.groups;
         if (job.args.lds_rows) {
