@@ -1249,26 +1249,32 @@ def test_tiles_in_layers_beyond_2_to_32_texels(device, kind):
         assert not atlas.download_tiles(0, shift + len(expected), 2).any()
 
 
-@pytest.mark.parametrize("ratio,cube", [(1.23, False), (1.45, False), (0.8, False), (1.3, True)])
-def test_source_to_tile_ratios_staged_by_dma_alone(device, tmp_path, ratio, cube):
+@pytest.mark.parametrize("ratio,cube,fmt", [(1.23, False, O.FORMAT_R16), (1.45, False, O.FORMAT_R16), (0.8, False, O.FORMAT_R16), (1.3, True, O.FORMAT_R16),
+                                            (1.41, False, O.FORMAT_R16), (1.8, False, O.FORMAT_R16), (1.5, True, O.FORMAT_R16),
+                                            (0.71, False, O.FORMAT_RGBA8), (0.93, False, O.FORMAT_RGBA8), (1.04, False, O.FORMAT_RGBA8), (1.2, False, O.FORMAT_RGBA8),
+                                            (1.41, False, O.FORMAT_RGBA8), (1.52, False, O.FORMAT_RGBA8), (1.3, True, O.FORMAT_RGBA8), (0.8, True, O.FORMAT_RGBA8)])
+def test_source_to_tile_ratios_staged_by_dma_alone(device, tmp_path, ratio, cube, fmt):
     """T = 512 with a source that is not the size of the tile mosaic (real datasets rarely are: GEBCO's 86400 columns over 128 x 508): from a ratio of
     ~1.2 the staged window has more 16-byte pieces than the register staging batches, and rounds 2 - 6 then ran the unstaged kernel (1.9 TB/s where the
-    16k job runs at 4.3).  Such windows are now staged by LDS-DMA with a run-time pitch (4.2 TB/s at ratio 1.23): every tile against the oracle — fresh,
-    onto the written atlas (no-data texels fetch their previous value) and through the streamed pipeline."""
+    16k job runs at 4.3).  Such windows are now staged by LDS-DMA with a run-time pitch (4.2 TB/s at ratio 1.23) — with the apron rows from global memory
+    (ratios ~1.25 - 1.35) or ONE staging buffer (from ~1.36) where that keeps four workgroups on a CU: every tile against the oracle — fresh, onto the written
+    atlas (no-data texels fetch their previous value) and through the streamed pipeline.
+    Rgba8 (fused_direct): its requests-ahead path took only blocks whose rows step through the source one row at a time; now also rows that repeat the pair
+    above (ratios below 1).  Ratios above 1 still take its general path (the 14-load variant built for them was backed out: profiles/r06_gebco_size.txt)."""
     T, b, lods = 512, 2, 2 if cube else 3
     n = int(((T - 2 * b) << (lods - 1)) * ratio)
     cfg = bt.TerrainConfig(lod_count=lods, atlas_size=64, path="terrains/ratio", **({} if cube else dict(model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))))
-    cfg.add_attachment(bt.AttachmentConfig(name="att", texture_size=T, border_size=b, format=bt.AttachmentFormat.R16))
-    oracle = O.OracleAtlas(lods, 64, cube, [(T, b, 1, O.FORMAT_R16)])
+    cfg.add_attachment(bt.AttachmentConfig(name="att", texture_size=T, border_size=b, format=K.FMT[fmt]))
+    oracle = O.OracleAtlas(lods, 64, cube, [(T, b, 1, fmt)])
     server = bt.AssetServer()
     if cube:
-        faces = [K.random_raster(O.FORMAT_R16, n, n, 70 + s, holes=0.03) for s in range(6)]
+        faces = [K.random_raster(fmt, n, n, 70 + s, holes=0.03) for s in range(6)]
         paths = [f"f{s}" for s in range(6)]
         for path, f in zip(paths, faces):
             server.insert(path, f)
         oracle.clear_attachment(0).preprocess_spherical(0, faces, (0, lods)).run(16)
     else:
-        src = K.random_raster(O.FORMAT_R16, n, n, 71, holes=0.03)
+        src = K.random_raster(fmt, n, n, 71, holes=0.03)
         server.insert("src", src)
         oracle.clear_attachment(0).preprocess_tile(0, src, (0, lods)).run(16)
 

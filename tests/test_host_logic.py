@@ -294,3 +294,39 @@ def test_tile_helpers_take_coordinates_that_are_not_tiles():
         L.bt_tile_children(_ffi.TileCoordinateC(side, lod, x, y), C.cast(out, C.POINTER(_ffi.TileCoordinateC)))
         buf = C.create_string_buffer(64)
         assert L.bt_tile_name(_ffi.TileCoordinateC(side, lod, x, y), buf, 64) > 0
+
+
+def test_fused_direct_keeps_its_in_flight_registers_in_place(tmp_path):
+    """fused_direct issues its source loads from inline assembly, two blocks ahead, and waits for them by hand-counted s_waitcnt: the compiler believes a
+    loaded register holds its value from the load instruction on.  That is only true if it never COPIES such a register (a live-range split, a spill) between
+    the load and the wait that covers it — a copy taken early is stale, and the load then lands in a register that may be somebody else's.  Round 6 met both
+    (a 14-load variant for sources finer than the tile grid: one wave's block of wrong pixels in ~10^4 jobs, then deterministically with more registers tied;
+    backed out, profiles/r06_gebco_size.txt).  This pins the shape of the compiled kernel: no scratch, and no register copy of a load destination in front of a wait."""
+    src = os.path.join(ROOT, "bevy_terrain_amd", "csrc", "bt_fused.hip")
+    out = str(tmp_path / "fused.s")
+    cc = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950",
+                         "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src), "-S", "--cuda-device-only", "-o", out, src], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    text = open(out).read()
+    m = re.search(r"\n(_ZN2bt\S*fused_direct_rgba8_kernel\S*):.*?\.end_amdhsa_kernel", text, flags=re.S)
+    assert m, "fused_direct_rgba8_kernel not found in the ISA"
+    body = m.group(0).split("\n")
+    assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", m.group(0)), "fused_direct spills to scratch: a spilled in-flight register is a stale one"
+    dests, inside = set(), False
+    for line in body:
+        inside = "ASMSTART" in line or (inside and "ASMEND" not in line)
+        mm = re.match(r"\s*global_load_dword (v\d+),", line)
+        if inside and mm:
+            dests.add(mm.group(1))
+    assert len(dests) == 20, sorted(dests)  # two sets of (4 rows + 1) x 2 columns
+    waits = [i for i, line in enumerate(body) if re.match(r"\s*s_waitcnt vmcnt\(\d+\)\s*$", line) and "ASMSTART" in body[i - 1]]
+    assert len(waits) >= 10
+    copies = []
+    for w in waits:
+        for line in body[max(0, w - 8):w - 1]:
+            mm = re.match(r"\s*v_mov_b(32|64)_e32\s+\S+,\s*(v\d+|v\[\d+:\d+\])", line)
+            if mm:
+                regs = [mm.group(2)] if "[" not in mm.group(2) else [f"v{k}" for k in range(int(mm.group(2)[2:].split(":")[0]), int(mm.group(2).split(":")[1][:-1]) + 1)]
+                if any(r in dests for r in regs):
+                    copies.append(line.strip())
+    assert not copies, f"load destinations are copied in front of a hand-counted wait: {copies[:6]}"
