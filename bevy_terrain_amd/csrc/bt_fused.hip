@@ -1810,6 +1810,9 @@ __device__ __forceinline__ uint32_t quad_dpp(uint32_t v) {
 
 constexpr uint32_t kDirectRows = 4, kDirectMaxBlocks = 16;
 
+// kRep: a source coarser than the tile grid in y (ratios below 1: the host decides per job) — the chain of a block may stand still (BlockInfo::rep).  The BASELINE
+// shapes (4096 over 4064, 8192 over 8128) run the kernel without it: the select it needs costs config 2's albedo job 2 % (same-lease A/B, round 6)
+template <bool kRep>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_direct_rgba8_kernel(FusedArgs A) {
     constexpr uint32_t kRows = kDirectRows;
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
@@ -1871,7 +1874,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const int d = ay[r].i1 - ay[r].i0;
                 ok = d == 0 || d == 1;
                 if (r == 0 || ay[r].i0 == ay[r - 1].i1) chain |= d << r;  // the next source row of the chain: one further down (or the same, clamped)
-                else if (ay[r].i0 == ay[r - 1].i0 && ay[r].i1 == ay[r - 1].i1) rep |= 1 << r;  // the same pair again: the chain stands still
+                else if (kRep && ay[r].i0 == ay[r - 1].i0 && ay[r].i1 == ay[r - 1].i1) rep |= 1 << r;  // the same pair again: the chain stands still
                 else ok = false;
             }
             const uint64_t bytes = uint64_t(uint32_t(ay[0].i0)) * raster.pitch;
@@ -1954,7 +1957,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const BlockInfo* v = s_blk + (blk - blk_begin);
             return BlockInfo{__builtin_amdgcn_readfirstlane(v->chain), __builtin_amdgcn_readfirstlane(v->y_first), __builtin_amdgcn_readfirstlane(v->y_last),
                              uint32_t(__builtin_amdgcn_readfirstlane(int(v->byte_lo))), uint32_t(__builtin_amdgcn_readfirstlane(int(v->byte_hi))),
-                             __builtin_amdgcn_readfirstlane(v->rep), {0, 0}};
+                             kRep ? __builtin_amdgcn_readfirstlane(v->rep) : 0, {0, 0}};
         };
         // Always 2 x (kRows + 1) loads, whatever the block: the hand-counted waits below rely on it.  A block that takes the general
         // path (chain 0) gets row 0 kRows + 1 times into registers nobody reads.  Issued from assembly and waited for by hand
@@ -2023,24 +2026,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     z = min(raw0[0] & 0xFFu, raw1[0] & 0xFFu);
                     top = hrow_rgba8_packed(raw0[0], raw1[0], ax.fr);
                 }
-                H4p held = top;      // the upper row of the previous output row (a repeated pair keeps it)
-                uint32_t z_row = 1;
+                if constexpr (!kRep) {
 #pragma unroll
-                for (uint32_t r = 0; r < kRows; r++) {
-                    arrived(r + 1, raw0[r + 1], raw1[r + 1]);
-                    const bool again = r > 0 && ((uint32_t(bi.rep) >> r) & 1u) != 0;  // (wave-uniform) the same pair as the row above: nothing new to blend
-                    H4p bot = top;
-                    if (!again) {
-                        z_row = min(raw0[r + 1] & 0xFFu, raw1[r + 1] & 0xFFu);
+                    for (uint32_t r = 0; r < kRows; r++) {
+                        arrived(r + 1, raw0[r + 1], raw1[r + 1]);
+                        const uint32_t z_row = min(raw0[r + 1] & 0xFFu, raw1[r + 1] & 0xFFu);
                         z = min(z, z_row);
-                        bot = hrow_rgba8_packed(raw0[r + 1], raw1[r + 1], ax.fr);
+                        const H4p bot = hrow_rgba8_packed(raw0[r + 1], raw1[r + 1], ax.fr);
+                        const float2 w = wy[r];
+                        out[r] = vmix_rgba8_weights(top, bot, w.x, w.y);
+                        top = bot;
+                        if (r + 1 == kRows) carry_z = z_row;
                     }
-                    const H4p upper = again ? held : top;
-                    const float2 w = wy[r];
-                    out[r] = vmix_rgba8_weights(upper, bot, w.x, w.y);
-                    held = upper;
-                    top = bot;
-                    if (r + 1 == kRows) carry_z = z_row;
+                } else {
+                    H4p held = top;      // the upper row of the previous output row (a repeated pair keeps it)
+                    uint32_t z_row = 1;
+#pragma unroll
+                    for (uint32_t r = 0; r < kRows; r++) {
+                        arrived(r + 1, raw0[r + 1], raw1[r + 1]);
+                        const bool again = r > 0 && ((uint32_t(bi.rep) >> r) & 1u) != 0;  // (wave-uniform) the same pair as the row above: nothing new to blend
+                        H4p bot = top;
+                        if (!again) {
+                            z_row = min(raw0[r + 1] & 0xFFu, raw1[r + 1] & 0xFFu);
+                            z = min(z, z_row);
+                            bot = hrow_rgba8_packed(raw0[r + 1], raw1[r + 1], ax.fr);
+                        }
+                        const H4p upper = again ? held : top;
+                        const float2 w = wy[r];
+                        out[r] = vmix_rgba8_weights(upper, bot, w.x, w.y);
+                        held = upper;
+                        top = bot;
+                        if (r + 1 == kRows) carry_z = z_row;
+                    }
                 }
                 carry_top = top;
                 carry_row = bi.y_last;
@@ -2228,6 +2245,7 @@ struct FusedJobDev {  // one fused launch of a compiled queue
     uint32_t lds_pad = 0;    // profiling build only (BT_FUSED_LDS_PAD at plan time): extra dynamic LDS per workgroup
     bool dma = false;        // fused_main stages through LDS-DMA (every raster of the job 16-byte aligned in base and pitch)
     bool dma_only = false;   // ... and only so: the window has more 16-byte pieces than the register staging batches (run-time-pitch DMA variant)
+    bool direct_rep = false;  // fused_direct: the source is coarser than the tile grid in y (ratio below 1): the variant whose chains may stand still
     std::vector<MainItem> host_items;  // fused_main's / fused_direct's items as uploaded (tile-row order): streamed runs cut fused_main's into bands, fused_source_window reads both
     bool direct = false;     // a fused_direct launch (reads the source texel by texel: no staged window)
     uint32_t seam_first = 0;  // fused_tail with seam workgroups: its tasks are p->tasks_dev[seam_first ...] (args.seam_count of them)
@@ -2561,6 +2579,13 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
             job.all_layers = all_layers;
             job.tly = args.tly;
             job.bry = args.bry;
+            {   // source rows per tile row: below 1 output rows repeat source-row pairs
+                const double mosaic = double(m.center_size) * double(1u << lod_hi);
+                for (const Task* t : splits) {
+                    const RasterDev& r = p->rasters[t->raster].dev;
+                    if (double(r.height) / (double(args.bry - args.tly) * mosaic) < 0.9999) job.direct_rep = true;
+                }
+            }
             {   // row blocks per workgroup: as many as keep at least one resident generation (1024 workgroups) busy
                 const uint64_t blocks = uint64_t(items.size()) * ((m.center_size + kDirectRows - 1) / kDirectRows);
                 job.args.groups = uint32_t(std::min<uint64_t>(kDirectMaxBlocks, std::max<uint64_t>(1, (blocks + 1023) / 1024)));
@@ -3111,7 +3136,10 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
     if (l.kind == kLaunchFusedDirect) {
         const uint32_t blocks_per_tile = (job.args.m.center_size + kDirectRows - 1) / kDirectRows;
         const uint32_t wgs_per_tile = (blocks_per_tile + job.args.groups - 1) / job.args.groups;
-        fused_direct_rgba8_kernel<<<job.args.item_count * wgs_per_tile, 256, 0, p->ctx->stream>>>(job.args);
+        if (job.direct_rep)  // a source coarser than the tile grid: rows repeat the pair above, the chained path follows (round 6)
+            fused_direct_rgba8_kernel<true><<<job.args.item_count * wgs_per_tile, 256, 0, p->ctx->stream>>>(job.args);
+        else
+            fused_direct_rgba8_kernel<false><<<job.args.item_count * wgs_per_tile, 256, 0, p->ctx->stream>>>(job.args);
     } else if (l.kind == kLaunchFusedMain) {
         const uint32_t blocks = job.args.item_count * job.args.groups;
         if (job.args.lds_rows) {

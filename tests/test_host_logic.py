@@ -308,8 +308,13 @@ def test_fused_direct_keeps_its_in_flight_registers_in_place(tmp_path):
                          "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src), "-S", "--cuda-device-only", "-o", out, src], capture_output=True, text=True)
     assert cc.returncode == 0, cc.stderr[-2000:]
     text = open(out).read()
-    m = re.search(r"\n(_ZN2bt\S*fused_direct_rgba8_kernel\S*):.*?\.end_amdhsa_kernel", text, flags=re.S)
-    assert m, "fused_direct_rgba8_kernel not found in the ISA"
+    kernels = list(re.finditer(r"\n(_ZN2bt\S*fused_direct_rgba8_kernel\S*):.*?\.end_amdhsa_kernel", text, flags=re.S))
+    assert len(kernels) == 2, "fused_direct_rgba8_kernel<false> and <true> expected in the ISA"
+    for m in kernels:
+        _check_in_flight_registers(m)
+
+
+def _check_in_flight_registers(m):
     body = m.group(0).split("\n")
     assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", m.group(0)), "fused_direct spills to scratch: a spilled in-flight register is a stale one"
     dests, inside = set(), False
