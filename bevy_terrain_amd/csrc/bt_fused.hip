@@ -1812,8 +1812,13 @@ constexpr uint32_t kDirectRows = 4, kDirectMaxBlocks = 16;
 
 // kRep: a source coarser than the tile grid in y (ratios below 1: the host decides per job) — the chain of a block may stand still (BlockInfo::rep).  The BASELINE
 // shapes (4096 over 4064, 8192 over 8128) run the kernel without it: the select it needs costs config 2's albedo job 2 % (same-lease A/B, round 6)
-template <bool kRep>
+// kSkips: a source finer than the tile grid in y (ratios above 1.02) — an output row's upper source row may lie one past the chain (BlockInfo::skip); up to two such rows of
+// a block get that row through two extra pairs requested with the block — by PLAIN loads into ordinary variables: the compiler waits for them in its own (conservative) way.
+// The first version issued them from assembly like the chain's and was backed out: a register with an assembly-issued load in flight is not safe from the compiler
+// (profiles/r06_gebco_size.txt).
+template <bool kRep, bool kSkips = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void fused_direct_rgba8_kernel(FusedArgs A) {
+    static_assert(!(kRep && kSkips), "a job's source is coarser or finer than its tile grid, not both");
     constexpr uint32_t kRows = kDirectRows;
     const uint32_t T = A.m.texture_size, b = A.m.border_size, c = A.m.center_size;
     const uint32_t blocks_per_tile = (c + kRows - 1) / kRows;
@@ -1849,7 +1854,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         int chain, y_first, y_last;
         uint32_t byte_lo, byte_hi;  // y_first x the raster's pitch
         int rep;                    // bit r (r >= 1): row r uses the same two source rows as row r - 1 (a source coarser than the tiles: round 6)
-        int pad[2];
+        int skip;                   // bit r (r >= 1, kSkips): row r's upper source row is the one BEHIND row r - 1's lower one (a source finer than the tiles)
+        int pad[1];
     };
     __shared__ Axis s_ay[kDirectMaxBlocks * kRows];
     __shared__ float2 s_wy[kDirectMaxBlocks * kRows];  // (fy, 1 - fy) of the row: read at a uniform address, used from vector registers
@@ -1865,20 +1871,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // one row apart — or the same row, where the source's first / last row is clamped (the tiles along the raster's top and bottom)
         // — or row r repeats row r - 1's pair (a source coarser than the tile grid, ratios below 1: round 6; rounds 2 - 5 sent every such block down the
         // general path, which requests nothing ahead: 0.9 M tiles/s at ratio 0.71 where the chained blocks of ratio 1.008 run at 1.75)
-        BlockInfo bi = BlockInfo{0, 0, -1, 0u, 0u, 0, {0, 0}};
+        BlockInfo bi = BlockInfo{0, 0, -1, 0u, 0u, 0, 0, {0}};
         if (blk_begin + tid < blk_end && (blk_begin + tid) * kRows + kRows <= c) {
             const Axis* ay = s_ay + tid * kRows;
             bool ok = true;
-            int chain = 0x100, rep = 0;
+            int chain = 0x100, rep = 0, skip = 0, skips = 0;
             for (uint32_t r = 0; ok && r < kRows; r++) {
                 const int d = ay[r].i1 - ay[r].i0;
                 ok = d == 0 || d == 1;
                 if (r == 0 || ay[r].i0 == ay[r - 1].i1) chain |= d << r;  // the next source row of the chain: one further down (or the same, clamped)
                 else if (kRep && ay[r].i0 == ay[r - 1].i0 && ay[r].i1 == ay[r - 1].i1) rep |= 1 << r;  // the same pair again: the chain stands still
-                else ok = false;
+                else if (kSkips && ay[r].i0 == ay[r - 1].i1 + 1 && skips < 2) {  // one source row is passed over: the chain steps 1 + d, the upper row comes by an extra pair
+                    chain |= d << r;
+                    skip |= 1 << r;
+                    skips++;
+                } else ok = false;
             }
             const uint64_t bytes = uint64_t(uint32_t(ay[0].i0)) * raster.pitch;
-            if (ok) bi = BlockInfo{chain, ay[0].i0, ay[kRows - 1].i1, uint32_t(bytes), uint32_t(bytes >> 32), rep, {0, 0}};
+            if (ok) bi = BlockInfo{chain, ay[0].i0, ay[kRows - 1].i1, uint32_t(bytes), uint32_t(bytes >> 32), rep, skip, {0}};
         }
         s_blk[tid] = bi;
     }
@@ -1949,6 +1959,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // The blocks of a sweep form a software pipeline over two register sets (the loop is unrolled by two so that no set is ever
         // copied): block k's texels are requested when block k - 2 has consumed its own, in front of that block's stores.
         uint32_t set_a0[kRows + 1], set_a1[kRows + 1], set_b0[kRows + 1], set_b1[kRows + 1];
+        uint32_t extra_a[4] = {0u, 0u, 0u, 0u}, extra_b[4] = {0u, 0u, 0u, 0u};  // (kSkips) the upper rows of a block's first / second passing row: texel pairs (i0, i1), plain loads
         BlockInfo info_a, info_b;
         H4p carry_top = H4p{{0.0f, 0.0f}, {0.0f, 0.0f}};
         uint32_t carry_z = 0;
@@ -1957,21 +1968,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const BlockInfo* v = s_blk + (blk - blk_begin);
             return BlockInfo{__builtin_amdgcn_readfirstlane(v->chain), __builtin_amdgcn_readfirstlane(v->y_first), __builtin_amdgcn_readfirstlane(v->y_last),
                              uint32_t(__builtin_amdgcn_readfirstlane(int(v->byte_lo))), uint32_t(__builtin_amdgcn_readfirstlane(int(v->byte_hi))),
-                             kRep ? __builtin_amdgcn_readfirstlane(v->rep) : 0, {0, 0}};
+                             kRep ? __builtin_amdgcn_readfirstlane(v->rep) : 0, kSkips ? __builtin_amdgcn_readfirstlane(v->skip) : 0, {0}};
         };
         // Always 2 x (kRows + 1) loads, whatever the block: the hand-counted waits below rely on it.  A block that takes the general
         // path (chain 0) gets row 0 kRows + 1 times into registers nobody reads.  Issued from assembly and waited for by hand
         // (arrived() below): the compiler's own counted waits assume the fewest operations in flight over all paths of this control
         // flow and end up waiting for the other set and for the stores as well.
-        auto request = [&](const BlockInfo& bi, uint32_t (&d0)[kRows + 1], uint32_t (&d1)[kRows + 1]) {
+        auto request = [&](const BlockInfo& bi, uint32_t (&d0)[kRows + 1], uint32_t (&d1)[kRows + 1], uint32_t (&extra)[4]) {
             global_bytes_t rowp = data + (uint64_t(bi.byte_lo) | uint64_t(bi.byte_hi) << 32);
+            global_bytes_t xrow0 = rowp, xrow1 = rowp;
             if (BT_ABLATE(A, 8u)) {  // (8: no source loads)
 #pragma unroll
                 for (uint32_t j = 0; j <= kRows; j++) {
                     d0[j] = 0x01010101u * (tid + j + 1u) | 1u;
                     d1[j] = 0x01010101u * (tid + j + 2u) | 1u;
                 }
-            } else if (__builtin_expect(bi.chain == 0x10F && narrow, 1)) {  // kRows + 1 consecutive rows: one base, the rows in the lane offsets
+            } else if (__builtin_expect(bi.chain == 0x10F && bi.skip == 0 && narrow, 1)) {  // kRows + 1 consecutive rows: one base, the rows in the lane offsets
 #pragma unroll
                 for (uint32_t j = 0; j <= kRows; j++)
                     asm volatile("global_load_dword %0, %2, %4\n\tglobal_load_dword %1, %3, %4" : "=&v"(d0[j]), "=&v"(d1[j]) : "v"(lo0[j]), "v"(lo1[j]), "s"(rowp));
@@ -1979,7 +1991,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                 for (uint32_t j = 0; j <= kRows; j++) {
                     asm volatile("global_load_dword %0, %2, %4\n\tglobal_load_dword %1, %3, %4" : "=&v"(d0[j]), "=&v"(d1[j]) : "v"(off0), "v"(off1), "s"(rowp));
+                    if (kSkips && j >= 1 && j < kRows && ((uint32_t(bi.skip) >> j) & 1u)) {  // slot j holds row j - 1's lower source row: row j's upper one is the next, its lower one the chain's next
+                        rowp += raster.pitch;
+                        if ((uint32_t(bi.skip) & ((1u << j) - 1u)) == 0) xrow0 = rowp; else xrow1 = rowp;
+                    }
                     rowp += (uint32_t(bi.chain) >> j) & 1u ? raster.pitch : 0u;
+                }
+            }
+            if constexpr (kSkips) {
+                if (bi.skip != 0) {  // (wave-uniform) plain loads: ordinary variables, the compiler's own waits
+                    extra[0] = *(global_u32_t)(xrow0 + off0);
+                    extra[1] = *(global_u32_t)(xrow0 + off1);
+                    extra[2] = *(global_u32_t)(xrow1 + off0);
+                    extra[3] = *(global_u32_t)(xrow1 + off1);
                 }
             }
         };
@@ -1995,7 +2019,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         };
         static_assert(kRows == 4, "arrived() counts 2 x (kRows + 1) loads per request");
-        auto block = [&](uint32_t blk, BlockInfo& bi, uint32_t (&raw0)[kRows + 1], uint32_t (&raw1)[kRows + 1]) {
+        auto block = [&](uint32_t blk, BlockInfo& bi, uint32_t (&raw0)[kRows + 1], uint32_t (&raw1)[kRows + 1], uint32_t (&extra)[4]) {
             if (--prio_left == 0) {
                 prio_left = prio_step;
                 prio_level++;
@@ -2027,12 +2051,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     top = hrow_rgba8_packed(raw0[0], raw1[0], ax.fr);
                 }
                 if constexpr (!kRep) {
+                    const uint32_t x_first0 = extra[0], x_first1 = extra[1], x_second0 = extra[2], x_second1 = extra[3];  // (kSkips: requested with this block's chain)
 #pragma unroll
                     for (uint32_t r = 0; r < kRows; r++) {
                         arrived(r + 1, raw0[r + 1], raw1[r + 1]);
                         const uint32_t z_row = min(raw0[r + 1] & 0xFFu, raw1[r + 1] & 0xFFu);
                         z = min(z, z_row);
                         const H4p bot = hrow_rgba8_packed(raw0[r + 1], raw1[r + 1], ax.fr);
+                        if constexpr (kSkips) {
+                            if (r > 0 && ((uint32_t(bi.skip) >> r) & 1u) != 0) {  // (wave-uniform) the upper row is the one behind the chain's: the block's first or second extra pair
+                                const bool second = (uint32_t(bi.skip) & ((1u << r) - 1u)) != 0;
+                                const uint32_t x0 = second ? x_second0 : x_first0, x1 = second ? x_second1 : x_first1;
+                                z = min(z, min(x0 & 0xFFu, x1 & 0xFFu));
+                                top = hrow_rgba8_packed(x0, x1, ax.fr);
+                            }
+                        }
                         const float2 w = wy[r];
                         out[r] = vmix_rgba8_weights(top, bot, w.x, w.y);
                         top = bot;
@@ -2068,7 +2101,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             // order, so a wait for a request covers everything issued before it.  Requests issued behind the previous block's stores (as
             // a plain prefetch would) make every block wait for a store acknowledge.
             bi = block_info(blk + 2u);
-            request(bi, raw0, raw1);
+            request(bi, raw0, raw1, extra);
             if (__builtin_expect(chained, 1)) {
                 if (__builtin_expect(__ballot(used && z == 0u) != 0ull, 0)) {
                     fast = false;  // (wave-uniform) the general path below redoes the block
@@ -2175,13 +2208,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         };
         if (BT_ABLATE(A, 16u)) continue;  // (16: set-up and aprons only — timing experiment)
         info_a = block_info(blk_begin);
-        request(info_a, set_a0, set_a1);
+        request(info_a, set_a0, set_a1, extra_a);
         info_b = block_info(blk_begin + 1u);
-        request(info_b, set_b0, set_b1);
+        request(info_b, set_b0, set_b1, extra_b);
         for (uint32_t blk = blk_begin;;) {  // (no path from one use of a set to its next use without the other set's block in between: the counted waits rely on it)
-            block(blk, info_a, set_a0, set_a1);
+            block(blk, info_a, set_a0, set_a1, extra_a);
             if (++blk >= blk_end) break;
-            block(blk, info_b, set_b0, set_b1);
+            block(blk, info_b, set_b0, set_b1, extra_b);
             if (++blk >= blk_end) break;
         }
         stamp(2u + cx0 / 256u);
@@ -2246,6 +2279,7 @@ struct FusedJobDev {  // one fused launch of a compiled queue
     bool dma = false;        // fused_main stages through LDS-DMA (every raster of the job 16-byte aligned in base and pitch)
     bool dma_only = false;   // ... and only so: the window has more 16-byte pieces than the register staging batches (run-time-pitch DMA variant)
     bool direct_rep = false;  // fused_direct: the source is coarser than the tile grid in y (ratio below 1): the variant whose chains may stand still
+    bool direct_skips = false;  // ... finer (ratio above 1.02): the variant whose chains may pass over a source row
     std::vector<MainItem> host_items;  // fused_main's / fused_direct's items as uploaded (tile-row order): streamed runs cut fused_main's into bands, fused_source_window reads both
     bool direct = false;     // a fused_direct launch (reads the source texel by texel: no staged window)
     uint32_t seam_first = 0;  // fused_tail with seam workgroups: its tasks are p->tasks_dev[seam_first ...] (args.seam_count of them)
@@ -2583,7 +2617,9 @@ bool fused_plan(bt_preprocessor* p, bt_atlas* a, std::vector<TaskDev>& tasks, st
                 const double mosaic = double(m.center_size) * double(1u << lod_hi);
                 for (const Task* t : splits) {
                     const RasterDev& r = p->rasters[t->raster].dev;
-                    if (double(r.height) / (double(args.bry - args.tly) * mosaic) < 0.9999) job.direct_rep = true;
+                    const double ratio = double(r.height) / (double(args.bry - args.tly) * mosaic);
+                    if (ratio < 0.9999) job.direct_rep = true;
+                    if (ratio > 1.02) job.direct_skips = true;  // (the BASELINE shapes, 1.008, pass over a row in one block of 32: they stay on the plain kernel)
                 }
             }
             {   // row blocks per workgroup: as many as keep at least one resident generation (1024 workgroups) busy
@@ -3138,6 +3174,8 @@ bt_status fused_launch_range(bt_preprocessor* p, bt_atlas* a, const Launch& l, u
         const uint32_t wgs_per_tile = (blocks_per_tile + job.args.groups - 1) / job.args.groups;
         if (job.direct_rep)  // a source coarser than the tile grid: rows repeat the pair above, the chained path follows (round 6)
             fused_direct_rgba8_kernel<true><<<job.args.item_count * wgs_per_tile, 256, 0, p->ctx->stream>>>(job.args);
+        else if (job.direct_skips && !job.direct_rep)  // a source finer than the tile grid: rows pass over source rows, the chained path follows with two extra (plain) loads per block
+            fused_direct_rgba8_kernel<false, true><<<job.args.item_count * wgs_per_tile, 256, 0, p->ctx->stream>>>(job.args);
         else
             fused_direct_rgba8_kernel<false><<<job.args.item_count * wgs_per_tile, 256, 0, p->ctx->stream>>>(job.args);
     } else if (l.kind == kLaunchFusedMain) {

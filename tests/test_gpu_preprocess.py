@@ -1260,7 +1260,7 @@ def test_source_to_tile_ratios_staged_by_dma_alone(device, tmp_path, ratio, cube
     (ratios ~1.25 - 1.35) or ONE staging buffer (from ~1.36) where that keeps four workgroups on a CU: every tile against the oracle — fresh, onto the written
     atlas (no-data texels fetch their previous value) and through the streamed pipeline.
     Rgba8 (fused_direct): its requests-ahead path took only blocks whose rows step through the source one row at a time; now also rows that repeat the pair
-    above (ratios below 1).  Ratios above 1 still take its general path (the 14-load variant built for them was backed out: profiles/r06_gebco_size.txt)."""
+    above (ratios below 1) and, in a variant of its own (ratios above 1.02), rows that pass over a source row — up to two per block (1.52 is past that), the passed-to rows by plain loads."""
     T, b, lods = 512, 2, 2 if cube else 3
     n = int(((T - 2 * b) << (lods - 1)) * ratio)
     cfg = bt.TerrainConfig(lod_count=lods, atlas_size=64, path="terrains/ratio", **({} if cube else dict(model=bt.TerrainModel.planar((0, 0, 0), 1000.0, 0.0, 1.0))))

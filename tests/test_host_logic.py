@@ -309,7 +309,7 @@ def test_fused_direct_keeps_its_in_flight_registers_in_place(tmp_path):
     assert cc.returncode == 0, cc.stderr[-2000:]
     text = open(out).read()
     kernels = list(re.finditer(r"\n(_ZN2bt\S*fused_direct_rgba8_kernel\S*):.*?\.end_amdhsa_kernel", text, flags=re.S))
-    assert len(kernels) == 2, "fused_direct_rgba8_kernel<false> and <true> expected in the ISA"
+    assert len(kernels) == 3, "fused_direct_rgba8_kernel<false, false>, <true, false> and <false, true> expected in the ISA"
     for m in kernels:
         _check_in_flight_registers(m)
 
